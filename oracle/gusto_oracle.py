@@ -1,0 +1,251 @@
+"""ctypes binding of the CPU ORACLE (oracle/libgusto_oracle.so).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.  See oracle/gusto_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libgusto_oracle.so")
+
+MAXN, MAXM = 13, 6
+FREEFLYER_SE2, DUBINS_CAR, ASTROBEE_SE3, ASTROBEE_SE3_MANIFOLD = 0, 1, 2, 3
+MODEL_DIMS = {0: (6, 3), 1: (3, 1), 2: (12, 6), 3: (13, 6)}
+SCP_STATUS = {0: "NA", 1: "OK", 2: "InaccurateModel", 3: "ViolatesConstraints", 4: "TrustRegionViolated"}
+SOLVER_STATUS = {0: "NA", 1: "OPTIMAL", 2: "ALMOST_LOCALLY_SOLVED", 3: "FAILED"}
+STOP_REASON = {0: "MaxIter", 1: "Converged", 2: "SubproblemFailed", 3: "OmegaMaxExceeded"}
+
+
+class ScpParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ("Delta0", "omega0", "omega_max", "eps", "rho0", "rho1", "beta_succ", "beta_fail", "gamma_fail",
+                 "convergence_threshold")]
+
+
+class ModelParams(C.Structure):
+    _fields_ = [("mass", C.c_double), ("Jdiag", C.c_double * 3), ("radius", C.c_double), ("clearance", C.c_double),
+                ("hard_limit_vel", C.c_double), ("hard_limit_accel", C.c_double), ("hard_limit_omega", C.c_double),
+                ("hard_limit_alpha", C.c_double), ("dubins_v", C.c_double), ("dubins_k", C.c_double),
+                ("u_max", C.c_double), ("u_min", C.c_double), ("x_max", C.c_double * MAXN),
+                ("x_min", C.c_double * MAXN), ("n_robot_comp", C.c_int), ("comp_off", (C.c_double * 3) * 2)]
+
+
+class IpmOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("tol_acc", C.c_double), ("mu_floor", C.c_double), ("tr_tol", C.c_double),
+                ("max_iter", C.c_int)]
+
+
+class SubInfo(C.Structure):
+    _fields_ = [("obj", C.c_double), ("res_p", C.c_double), ("res_d", C.c_double), ("mu", C.c_double),
+                ("iters", C.c_int), ("status", C.c_int)]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    src = [os.path.join(_HERE, f) for f in ("gusto_oracle.c", "gusto_oracle.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.go_create.restype = C.c_void_p
+        L.go_create.argtypes = [C.c_int, C.c_int, C.POINTER(ScpParams), C.POINTER(ModelParams), C.c_int, C.c_void_p,
+                                C.c_int, C.c_void_p]
+        L.go_destroy.argtypes = [C.c_void_p]
+        L.go_set_ipm_opts.argtypes = [C.c_void_p, C.POINTER(IpmOpts)]
+        L.go_set_problem.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, C.c_void_p, C.c_void_p]
+        L.go_solve.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.go_get_traj.argtypes = [C.c_void_p, _dp, _dp]
+        L.go_get_status.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5
+        L.go_hist_len.argtypes = [C.c_void_p]
+        L.go_get_history.argtypes = [C.c_void_p] + [C.c_void_p] * 15
+        L.go_get_dual.argtypes = [C.c_void_p, _dp]
+        L.go_subproblem.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp,
+                                    C.POINTER(SubInfo)]
+        L.go_rows_count.argtypes = [C.c_void_p]
+        L.go_rows_get.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 13
+        L.go_dynamics.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
+        L.go_signed_distance.restype = C.c_double
+        L.go_signed_distance.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _dp]
+        L.go_trust_region_ratio.restype = C.c_double
+        L.go_trust_region_ratio.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.go_cost_true.restype = C.c_double
+        L.go_cost_true.argtypes = [C.c_void_p, _dp]
+        L.go_convergence_metric.restype = C.c_double
+        L.go_convergence_metric.argtypes = [C.c_void_p, _dp, _dp]
+        L.go_convex_ineq_satisfied.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double]
+        L.go_init_straightline.argtypes = [C.c_void_p, _dp, _dp]
+        L.go_solve_batch.argtypes = [C.c_int, C.c_int, C.POINTER(ScpParams), C.POINTER(ModelParams), C.c_int,
+                                     C.c_void_p, C.c_int, C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int,
+                                     _dp, _dp, _ip, _ip, _ip, _ip]
+        _lib = L
+    return _lib
+
+
+def default_params(model):
+    sp, mp = ScpParams(), ModelParams()
+    lib().go_default_params(C.c_int(model), C.byref(sp), C.byref(mp))
+    return sp, mp
+
+
+def _arr(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class Oracle:
+    """One oracle problem instance (model, horizon, environment)."""
+
+    def __init__(self, model, N, boxes=None, spheres=None, scp_params=None, model_params=None, ipm_opts=None):
+        self.L = lib()
+        self.model, self.N = model, N
+        self.n, self.m = MODEL_DIMS[model]
+        sp, mp = default_params(model)
+        self.sp = scp_params or sp
+        self.mp = model_params or mp
+        self.boxes = _arr(boxes if boxes is not None else np.zeros((0, 6))).reshape(-1, 6)
+        self.spheres = _arr(spheres if spheres is not None else np.zeros((0, 4))).reshape(-1, 4)
+        self.h = self.L.go_create(model, N, C.byref(self.sp), C.byref(self.mp), len(self.boxes),
+                                  self.boxes.ctypes.data, len(self.spheres), self.spheres.ctypes.data)
+        if not self.h:
+            raise RuntimeError("go_create failed")
+        if ipm_opts is not None:
+            self.L.go_set_ipm_opts(self.h, C.byref(ipm_opts))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.go_destroy(self.h)
+            self.h = None
+
+    # -- problem / solve ---------------------------------------------------------------------
+    def set_problem(self, x_init, goal_lo, goal_hi, tf, X0=None, U0=None):
+        self._x0 = None if X0 is None else _arr(X0)
+        self._u0 = None if U0 is None else _arr(U0)
+        self.L.go_set_problem(self.h, _arr(x_init), _arr(goal_lo), _arr(goal_hi), float(tf),
+                              None if X0 is None else self._x0.ctypes.data,
+                              None if U0 is None else self._u0.ctypes.data)
+
+    def solve(self, max_iter=30, force=False):
+        self.L.go_solve(self.h, int(max_iter), int(bool(force)))
+        return self.result()
+
+    def traj(self):
+        X = np.zeros((self.N, self.n))
+        U = np.zeros((self.N, self.m))
+        self.L.go_get_traj(self.h, X, U)
+        return X, U
+
+    def result(self):
+        X, U = self.traj()
+        vals = [C.c_int() for _ in range(5)]
+        self.L.go_get_status(self.h, *[C.byref(v) for v in vals])
+        it, conv, succ, stop, ipm = [v.value for v in vals]
+        h = self.L.go_hist_len(self.h)
+        cap = 4 * h + 64
+        d = {k: np.zeros(cap) for k in ("J_true", "J_full", "conv", "Delta", "omega", "rho")}
+        i = {k: np.zeros(cap, dtype=np.int32) for k in ("accept", "scp_status", "solver_status", "tr_sat", "cvx_sat",
+                                                        "ipm_iters")}
+        nJt, nJf, nrho = C.c_int(), C.c_int(), C.c_int()
+        P = lambda a: a.ctypes.data
+        self.L.go_get_history(self.h, P(d["J_true"]), C.addressof(nJt), P(d["J_full"]), C.addressof(nJf), P(d["conv"]),
+                              P(d["Delta"]), P(d["omega"]), P(d["rho"]), C.addressof(nrho), P(i["accept"]),
+                              P(i["scp_status"]), P(i["solver_status"]), P(i["tr_sat"]), P(i["cvx_sat"]),
+                              P(i["ipm_iters"]))
+        out = dict(X=X, U=U, iterations=it, converged=bool(conv), successful=bool(succ), stop_reason=stop,
+                   total_ipm_iters=ipm)
+        out["J_true"] = d["J_true"][:nJt.value].copy()
+        out["J_full"] = d["J_full"][:nJf.value].copy()
+        out["rho"] = d["rho"][:nrho.value].copy()
+        for k in ("conv", "Delta", "omega"):
+            out[k] = d[k][:h].copy()
+        for k in i:
+            out[k] = i[k][:h].copy()
+        dual = np.zeros(self.n)
+        self.L.go_get_dual(self.h, dual)
+        out["dual"] = dual
+        return out
+
+    # -- pieces ------------------------------------------------------------------------------
+    def subproblem(self, Xp, Up, Delta, omega, toggle):
+        Xn, Un, dual = np.zeros((self.N, self.n)), np.zeros((self.N, self.m)), np.zeros(self.n)
+        info = SubInfo()
+        st = self.L.go_subproblem(self.h, _arr(Xp), _arr(Up), Delta, omega, toggle, Xn, Un, dual, C.byref(info))
+        return dict(X=Xn, U=Un, dual=dual, status=st, obj=info.obj, iters=info.iters, res_p=info.res_p,
+                    res_d=info.res_d, mu=info.mu)
+
+    def rows(self):
+        out = []
+        for i in range(self.L.go_rows_count(self.h)):
+            k, isu, kind, nnz = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            idx = np.zeros(MAXN, dtype=np.int32)
+            a, v0, b = np.zeros(MAXN), np.zeros(MAXN), np.zeros(MAXN)
+            c0, mul, off, sl, lam = (C.c_double() for _ in range(5))
+            A = C.addressof
+            self.L.go_rows_get(self.h, i, A(k), A(isu), A(kind), A(nnz), idx.ctypes.data, a.ctypes.data,
+                               v0.ctypes.data, b.ctypes.data, A(c0), A(mul), A(off), A(sl), A(lam))
+            z = nnz.value
+            out.append(dict(k=k.value, isu=isu.value, kind=kind.value, idx=idx[:z].copy(), a=a[:z].copy(),
+                            v0=v0[:z].copy(), b=b[:z].copy(), c0=c0.value, mul=mul.value, off=off.value,
+                            slack=sl.value, lam=lam.value))
+        return out
+
+    def dynamics(self, x, u):
+        f, A, B = np.zeros(self.n), np.zeros((self.n, self.n)), np.zeros((self.n, self.m))
+        self.L.go_dynamics(self.h, _arr(x), _arr(u), f, A, B)
+        return f, A, B
+
+    def signed_distance(self, comp, r, i):
+        nh = np.zeros(3)
+        r3 = np.zeros(3)
+        r3[:len(r)] = r
+        d = self.L.go_signed_distance(self.h, comp, r3, i, nh)
+        return d, nh
+
+    def trust_region_ratio(self, X, U, Xp, Up):
+        return self.L.go_trust_region_ratio(self.h, _arr(X), _arr(U), _arr(Xp), _arr(Up))
+
+    def cost_true(self, U):
+        return self.L.go_cost_true(self.h, _arr(U))
+
+    def convergence_metric(self, X, Xp):
+        return self.L.go_convergence_metric(self.h, _arr(X), _arr(Xp))
+
+    def convex_ineq_satisfied(self, X, Xp, Up, toggle):
+        return bool(self.L.go_convex_ineq_satisfied(self.h, _arr(X), _arr(Xp), _arr(Up), toggle))
+
+    def init_straightline(self):
+        X, U = np.zeros((self.N, self.n)), np.zeros((self.N, self.m))
+        self.L.go_init_straightline(self.h, X, U)
+        return X, U
+
+
+def solve_batch(model, N, boxes, spheres, x_init, goal_lo, goal_hi, tf, max_iter=30, nthreads=0, scp_params=None,
+                model_params=None):
+    """CPU baseline: B independent problems through go_solve_batch (OpenMP over problems)."""
+    L = lib()
+    n, m = MODEL_DIMS[model]
+    sp, mp = default_params(model)
+    sp, mp = scp_params or sp, model_params or mp
+    boxes = _arr(boxes if boxes is not None else np.zeros((0, 6))).reshape(-1, 6)
+    spheres = _arr(spheres if spheres is not None else np.zeros((0, 4))).reshape(-1, 4)
+    x_init, goal_lo, goal_hi, tf = _arr(x_init), _arr(goal_lo), _arr(goal_hi), _arr(tf)
+    B = x_init.shape[0]
+    X, U = np.zeros((B, N, n)), np.zeros((B, N, m))
+    conv, succ, its, ipm = (np.zeros(B, dtype=np.int32) for _ in range(4))
+    L.go_solve_batch(model, N, C.byref(sp), C.byref(mp), len(boxes), boxes.ctypes.data, len(spheres),
+                     spheres.ctypes.data, B, x_init, goal_lo, goal_hi, tf, max_iter, nthreads, X, U, conv, succ, its,
+                     ipm)
+    return dict(X=X, U=U, converged=conv.astype(bool), successful=succ.astype(bool), iterations=its, ipm_iters=ipm)
