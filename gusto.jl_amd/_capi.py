@@ -1,0 +1,234 @@
+"""ctypes binding of libgusto_hip.so (include/gusto_hip.h).  No fallback: if the HIP library is missing or no
+GPU is present the functions raise -- the product never routes through a CPU path."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libgusto_hip.so")
+MAXN, MAXM = 13, 6
+
+FREEFLYER_SE2, DUBINS_CAR, ASTROBEE_SE3, ASTROBEE_SE3_MANIFOLD = 0, 1, 2, 3
+MODEL_DIMS = {0: (6, 3), 1: (3, 1), 2: (12, 6), 3: (13, 6)}
+SCP_STATUS = {0: "NA", 1: "OK", 2: "InaccurateModel", 3: "ViolatesConstraints", 4: "TrustRegionViolated"}
+SOLVER_STATUS = {0: "NA", 1: "OPTIMAL", 2: "ALMOST_LOCALLY_SOLVED", 3: "FAILED"}
+STOP_REASON = {0: "MaxIter", 1: "Converged", 2: "SubproblemFailed", 3: "OmegaMaxExceeded"}
+
+# every symbol include/gusto_hip.h declares
+SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims", "gusto_create", "gusto_destroy",
+           "gusto_last_error", "gusto_set_params", "gusto_set_ipm_opts", "gusto_set_env", "gusto_set_stream",
+           "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_last_solve_ms", "gusto_get_traj",
+           "gusto_get_traj_dev", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_subproblem"]
+
+
+class ScpParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ("Delta0", "omega0", "omega_max", "eps", "rho0", "rho1", "beta_succ", "beta_fail", "gamma_fail",
+                 "convergence_threshold")]
+
+
+class ModelParams(C.Structure):
+    _fields_ = [("mass", C.c_double), ("Jdiag", C.c_double * 3), ("radius", C.c_double), ("clearance", C.c_double),
+                ("hard_limit_vel", C.c_double), ("hard_limit_accel", C.c_double), ("hard_limit_omega", C.c_double),
+                ("hard_limit_alpha", C.c_double), ("dubins_v", C.c_double), ("dubins_k", C.c_double),
+                ("u_max", C.c_double), ("u_min", C.c_double), ("x_max", C.c_double * MAXN),
+                ("x_min", C.c_double * MAXN), ("n_robot_comp", C.c_int), ("comp_off", (C.c_double * 3) * 2)]
+
+
+class IpmOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("tol_acc", C.c_double), ("mu_floor", C.c_double), ("tr_tol", C.c_double),
+                ("max_iter", C.c_int)]
+
+
+class History(C.Structure):
+    _fields_ = [("hist_cap", C.c_int), ("n_hist", C.c_void_p), ("nJ", C.c_void_p), ("n_rho", C.c_void_p),
+                ("J_true", C.c_void_p), ("J_full", C.c_void_p), ("convergence_measure", C.c_void_p),
+                ("Delta", C.c_void_p), ("omega", C.c_void_p), ("rho", C.c_void_p), ("accept_solution", C.c_void_p),
+                ("scp_status", C.c_void_p), ("solver_status", C.c_void_p), ("trust_region_satisfied", C.c_void_p),
+                ("convex_ineq_satisfied", C.c_void_p), ("ipm_iters", C.c_void_p)]
+
+
+def build(force=False, verbose=False):
+    """Compile libgusto_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(_ROOT, "include", "gusto_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(_ROOT, "include"), "-shared",
+           "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", os.path.join(csrc, "gusto_hip.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+def lib():
+    """Load the HIP library; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                               "(hipcc --offload-arch=gfx950); gusto.jl_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, ci = C.c_void_p, C.c_int
+        L.gusto_last_error.restype = C.c_char_p
+        L.gusto_last_error.argtypes = [vp]
+        L.gusto_default_params.argtypes = [ci, C.POINTER(ScpParams), C.POINTER(ModelParams)]
+        L.gusto_default_ipm_opts.argtypes = [C.POINTER(IpmOpts)]
+        L.gusto_model_dims.argtypes = [ci, C.POINTER(ci), C.POINTER(ci)]
+        L.gusto_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci]
+        L.gusto_destroy.argtypes = [vp]
+        L.gusto_set_params.argtypes = [vp, C.POINTER(ScpParams), C.POINTER(ModelParams)]
+        L.gusto_set_ipm_opts.argtypes = [vp, C.POINTER(IpmOpts)]
+        L.gusto_set_env.argtypes = [vp, ci, vp, ci, vp]
+        L.gusto_set_stream.argtypes = [vp, vp]
+        L.gusto_set_problems.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
+        L.gusto_set_problems_dev.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
+        L.gusto_solve.argtypes = [vp, ci, ci]
+        L.gusto_last_solve_ms.argtypes = [vp, C.POINTER(C.c_double)]
+        L.gusto_get_traj.argtypes = [vp, vp, vp]
+        L.gusto_get_traj_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        L.gusto_get_status.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.gusto_get_dual.argtypes = [vp, vp]
+        L.gusto_get_history.argtypes = [vp, C.POINTER(History)]
+        L.gusto_subproblem.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def default_params(model):
+    sp, mp = ScpParams(), ModelParams()
+    rc = lib().gusto_default_params(model, C.byref(sp), C.byref(mp))
+    if rc:
+        raise ValueError(f"gusto_default_params({model}) -> {rc}")
+    return sp, mp
+
+
+def default_ipm_opts():
+    o = IpmOpts()
+    lib().gusto_default_ipm_opts(C.byref(o))
+    return o
+
+
+def _arr(a, dtype=np.float64):
+    return np.ascontiguousarray(np.asarray(a, dtype=dtype))
+
+
+class GustoError(RuntimeError):
+    pass
+
+
+class BatchSolver:
+    """Thin owner of one gusto_handle: a batch of SCP problems of one model on one GPU."""
+
+    def __init__(self, model, N, batch_cap, hist_cap=64, device=0, boxes=None, spheres=None, scp_params=None,
+                 model_params=None, ipm_opts=None):
+        self.L = lib()
+        self.model, self.N, self.batch_cap, self.hist_cap = model, N, batch_cap, hist_cap
+        self.n, self.m = MODEL_DIMS[model]
+        self.h = C.c_void_p()
+        rc = self.L.gusto_create(C.byref(self.h), model, N, batch_cap, hist_cap, device)
+        if rc:
+            msg = self.L.gusto_last_error(self.h if self.h else None)
+            self.h = C.c_void_p()
+            raise GustoError(f"gusto_create -> {rc}: {msg.decode() if msg else ''}")
+        self.B = 0
+        if scp_params is not None or model_params is not None:
+            self._chk(self.L.gusto_set_params(self.h, C.byref(scp_params) if scp_params is not None else None,
+                                              C.byref(model_params) if model_params is not None else None), "set_params")
+        if ipm_opts is not None:
+            self._chk(self.L.gusto_set_ipm_opts(self.h, C.byref(ipm_opts)), "set_ipm_opts")
+        self.set_env(boxes, spheres)
+
+    def _chk(self, rc, what):
+        if rc:
+            msg = self.L.gusto_last_error(self.h)
+            raise GustoError(f"gusto_{what} -> {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h:
+            self.L.gusto_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_env(self, boxes=None, spheres=None):
+        self.boxes = _arr(boxes if boxes is not None else np.zeros((0, 6))).reshape(-1, 6)
+        self.spheres = _arr(spheres if spheres is not None else np.zeros((0, 4))).reshape(-1, 4)
+        self._chk(self.L.gusto_set_env(self.h, len(self.boxes), self.boxes.ctypes.data, len(self.spheres),
+                                       self.spheres.ctypes.data), "set_env")
+
+    def set_problems(self, x_init, goal_lo, goal_hi, tf, X0=None, U0=None):
+        x_init, goal_lo, goal_hi = _arr(x_init).reshape(-1, self.n), _arr(goal_lo).reshape(-1, self.n), \
+            _arr(goal_hi).reshape(-1, self.n)
+        B = x_init.shape[0]
+        tf = _arr(np.broadcast_to(np.asarray(tf, dtype=np.float64), (B,)))
+        self._keep = (x_init, goal_lo, goal_hi, tf, None if X0 is None else _arr(X0), None if U0 is None else _arr(U0))
+        self._chk(self.L.gusto_set_problems(self.h, B, x_init.ctypes.data, goal_lo.ctypes.data, goal_hi.ctypes.data,
+                                            tf.ctypes.data, None if X0 is None else self._keep[4].ctypes.data,
+                                            None if U0 is None else self._keep[5].ctypes.data), "set_problems")
+        self.B = B
+
+    def solve(self, max_iter=30, force=False):
+        self._chk(self.L.gusto_solve(self.h, int(max_iter), int(bool(force))), "solve")
+
+    def last_solve_ms(self):
+        ms = C.c_double()
+        self._chk(self.L.gusto_last_solve_ms(self.h, C.byref(ms)), "last_solve_ms")
+        return ms.value
+
+    def traj(self):
+        X, U = np.zeros((self.B, self.N, self.n)), np.zeros((self.B, self.N, self.m))
+        self._chk(self.L.gusto_get_traj(self.h, X.ctypes.data, U.ctypes.data), "get_traj")
+        return X, U
+
+    def status(self):
+        a = [np.zeros(self.B, dtype=np.int32) for _ in range(5)]
+        self._chk(self.L.gusto_get_status(self.h, *[x.ctypes.data for x in a]), "get_status")
+        return dict(iterations=a[0], converged=a[1].astype(bool), successful=a[2].astype(bool), stop_reason=a[3],
+                    ipm_iters=a[4])
+
+    def dual(self):
+        d = np.zeros((self.B, self.n))
+        self._chk(self.L.gusto_get_dual(self.h, d.ctypes.data), "get_dual")
+        return d
+
+    def history(self):
+        B, H = self.B, self.hist_cap
+        dk = ("J_true", "J_full", "convergence_measure", "Delta", "omega", "rho")
+        ik = ("accept_solution", "scp_status", "solver_status", "trust_region_satisfied", "convex_ineq_satisfied",
+              "ipm_iters")
+        out = {k: np.zeros((B, H)) for k in dk}
+        out.update({k: np.zeros((B, H), dtype=np.int32) for k in ik})
+        cnt = {k: np.zeros(B, dtype=np.int32) for k in ("n_hist", "nJ", "n_rho")}
+        hs = History()
+        hs.hist_cap = H
+        for k, v in list(out.items()) + list(cnt.items()):
+            setattr(hs, k, v.ctypes.data)
+        self._chk(self.L.gusto_get_history(self.h, C.byref(hs)), "get_history")
+        out.update(cnt)
+        return out
+
+    def subproblem(self, Xp, Up, Delta, omega, toggle):
+        B = self.B
+        Xp, Up = _arr(Xp).reshape(B, self.N, self.n), _arr(Up).reshape(B, self.N, self.m)
+        Delta, omega, toggle = (_arr(np.broadcast_to(np.asarray(v, dtype=np.float64), (B,))) for v in
+                                (Delta, omega, toggle))
+        Xn, Un, obj = np.zeros_like(Xp), np.zeros_like(Up), np.zeros(B)
+        st, it = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        self._chk(self.L.gusto_subproblem(self.h, B, Xp.ctypes.data, Up.ctypes.data, Delta.ctypes.data,
+                                          omega.ctypes.data, toggle.ctypes.data, Xn.ctypes.data, Un.ctypes.data,
+                                          obj.ctypes.data, st.ctypes.data, it.ctypes.data), "subproblem")
+        return dict(X=Xn, U=Un, obj=obj, status=st, iters=it, dual=self.dual())

@@ -1,0 +1,278 @@
+// common.hpp -- shared definitions for the batched GuSTO SCP kernels (gfx950 / CDNA4, wave64, fp64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "gusto_hip.h"
+
+namespace gusto {
+
+#define GD __device__ __forceinline__
+
+// row kinds of the convex subproblem (scp_gusto.jl:192-314)
+constexpr int ROW_HARD = 0;     // hard inequality (convex_control_ineq, BoxGoal rows)          :213-221,236-245
+constexpr int ROW_PEN = 1;      // L1-penalised state inequality, part of the post-check         :281-295
+constexpr int ROW_PEN_TR = 2;   // L1-penalised trust region, not part of the post-check         :265-279
+constexpr int ROW_PEN_EQ = 3;   // j=2 half of a penalised equality, |h| < eps post-check        :297-311
+constexpr int ROW_HARD_EQ = 4;  // j=1 half of a penalised equality: 0 <= s1 <= w*h + eps
+GD bool row_is_hard(int kind) { return kind == ROW_HARD || kind == ROW_HARD_EQ; }
+
+// per-row interior point state, stored [var][slot][k] so that lane k's accesses coalesce
+constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5, RS_DS = 6, RS_KA = 7, RS_KB = 8,
+              RS_NVAR = 9;
+
+template <int MODEL> struct MT;
+template <> struct MT<GUSTO_FREEFLYER_SE2> {
+    static constexpr int n = 6, m = 3, WS = 2, NFIX = 3, NHU = 2;
+    static constexpr bool LTI = true, HAS_OBS = true;
+};
+template <> struct MT<GUSTO_DUBINS_CAR> {
+    static constexpr int n = 3, m = 1, WS = 2, NFIX = 6, NHU = 2;
+    static constexpr bool LTI = false, HAS_OBS = false;
+};
+template <> struct MT<GUSTO_ASTROBEE_SE3> {
+    static constexpr int n = 12, m = 6, WS = 3, NFIX = 3, NHU = 2;
+    static constexpr bool LTI = false, HAS_OBS = true;
+};
+template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
+    static constexpr int n = 13, m = 6, WS = 3, NFIX = 5, NHU = 2;
+    static constexpr bool LTI = false, HAS_OBS = true;
+};
+
+// symmetric packed index (upper triangle, row-major)
+GD constexpr int sidx(int i, int j, int n) {
+    return i <= j ? i * n - i * (i - 1) / 2 + (j - i) : j * n - j * (j - 1) / 2 + (i - j);
+}
+
+// per-problem global workspace, offsets in doubles
+struct WsLayout {
+    int nslot;
+    size_t rowstate, obs_nh, obs_c0, obs_mask, PG, QQ, Paft, Piaft, K, Sinv, D, Phicl, total;
+};
+template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n, m = T::m, NZ = n + m;
+    WsLayout L;
+    L.nslot = T::NFIX + n_obs + 2 * n + T::NHU;
+    size_t o = 0;
+    auto take = [&](size_t c) { size_t r = o; o += (c + 1) & ~size_t(1); return r; };
+    L.rowstate = take((size_t)RS_NVAR * L.nslot * N);
+    L.obs_nh = take((size_t)n_obs * T::WS * N);
+    L.obs_c0 = take((size_t)n_obs * N);
+    L.obs_mask = take((size_t)N);
+    L.PG = take((size_t)(T::LTI ? 1 : N) * n * NZ);
+    L.QQ = take((size_t)N * (NZ * (NZ + 1) / 2));
+    L.Paft = take((size_t)N * n * n);
+    L.Piaft = take((size_t)N * n * n);
+    L.K = take((size_t)N * m * n);
+    L.Sinv = take((size_t)N * m * m);
+    L.D = take((size_t)N * m * n);
+    L.Phicl = take((size_t)N * n * n);
+    L.total = o;
+    return L;
+}
+
+// LDS layout, offsets in doubles
+struct LdsLayout {
+    int Xw, Uw, Xp, Up, dY, rd, pv, cv, rv, qrd, nu, nun, qu, dv;  // N-vectors
+    int sP, sPi, sPG, sT, sHh, sZ, sK, sD, sSinv, sGd, misc;
+    int total;
+};
+template <int MODEL> inline LdsLayout make_lds_layout(int N) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n, m = T::m, NZ = n + m;
+    LdsLayout L;
+    int o = 0;
+    auto take = [&](int c) { int r = o; o += c; return r; };
+    L.Xw = take(N * n); L.Uw = take(N * m); L.Xp = take(N * n); L.Up = take(N * m);
+    L.dY = take(N * n); L.rd = take(N * n); L.pv = take(N * n); L.cv = take(N * n); L.rv = take(N * n);
+    L.qrd = take(N * n); L.nu = take(N * n); L.nun = take(N * n); L.qu = take(N * m); L.dv = take(N * m);
+    L.sP = take(n * n); L.sPi = take(n * n); L.sPG = take(2 * n * NZ); L.sT = take(n * NZ); L.sHh = take(NZ * NZ);
+    L.sZ = take(NZ * n); L.sK = take(m * n); L.sD = take(m * n); L.sSinv = take(m * m); L.sGd = take(2 * n * n);
+    L.misc = take(64);
+    L.total = o;
+    return L;
+}
+
+// kernel arguments
+struct KParams {
+    int N, B, n_obs, n_box, n_sph, hist_cap, max_iter, force, mode;  // mode 0: SCP solve, 1: one subproblem
+    gusto_scp_params sp;
+    gusto_model_params mp;
+    gusto_ipm_opts io;
+    const double* box;  // [n_box][6]
+    const double* sph;  // [n_sph][4]
+    double* X;          // [B][N][n]  SCPS.traj.X
+    double* U;          // [B][N][m]
+    const double *x_init, *goal_lo, *goal_hi, *tf;
+    // subproblem mode
+    const double *sub_Delta, *sub_omega, *sub_toggle;
+    double *sub_X, *sub_U, *sub_obj;
+    int *sub_status, *sub_iters;
+    // SCP state and histories
+    int* st_i;     // [B][8]: iterations, converged, successful, stop_reason, total_ipm, n_hist, nJ, n_rho
+    double* st_d;  // [B][2+MAXN]: toggle, spare, dual[n]
+    double *J_true, *J_full, *conv, *Delta, *omega, *rho;                       // [B][hist_cap]
+    int *accept, *scp_status, *solver_status, *tr_sat, *cvx_sat, *ipm_it;      // [B][hist_cap]
+    double* ws;
+    WsLayout wl;
+    LdsLayout ll;
+};
+constexpr int ST_ITER = 0, ST_CONV = 1, ST_SUCC = 2, ST_STOP = 3, ST_IPM = 4, ST_NHIST = 5, ST_NJ = 6, ST_NRHO = 7, ST_NI = 8;
+constexpr int SD_TOGGLE = 0, SD_DUAL = 2, SD_ND = 2 + GUSTO_MAXN;
+
+// ---- block-wide reductions (every thread of the block must call) -----------------------------------
+struct OpMax { GD double operator()(double a, double b) const { return fmax(a, b); } };
+struct OpMin { GD double operator()(double a, double b) const { return fmin(a, b); } };
+struct OpSum { GD double operator()(double a, double b) const { return a + b; } };
+
+template <class Op> GD double wave_reduce(double v, Op op) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// NaN-propagating max: used for residuals so that a NaN iterate is detected
+GD double nanmax(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
+struct OpNanMax { GD double operator()(double a, double b) const { return nanmax(a, b); } };
+
+template <class Op> GD double block_reduce(double v, Op op, double* sred) {
+    v = wave_reduce(v, op);
+    if (blockDim.x <= 64) return v;
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sred[w] = v;
+    __syncthreads();
+    double r = sred[0];
+    for (int i = 1; i < nw; i++) r = op(r, sred[i]);
+    return r;
+}
+
+// ---- small dense helpers on register arrays (fully unrolled) ---------------------------------------
+template <int n> GD bool inv_gauss_jordan(const double* A, double* Ainv) {
+    double W[n][2 * n];
+#pragma unroll
+    for (int i = 0; i < n; i++)
+#pragma unroll
+        for (int j = 0; j < n; j++) { W[i][j] = A[i * n + j]; W[i][n + j] = (i == j) ? 1.0 : 0.0; }
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < n; c++) {
+        // partial pivoting by conditional row swap (branch-free on register arrays)
+        int piv = c;
+        double best = fabs(W[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < n; r++) {
+            const double v = fabs(W[r][c]);
+            if (v > best) { best = v; piv = r; }
+        }
+        if (best == 0.0) ok = false;
+#pragma unroll
+        for (int r = c + 1; r < n; r++) {
+            if (r == piv) {
+#pragma unroll
+                for (int j = 0; j < 2 * n; j++) { const double t = W[c][j]; W[c][j] = W[r][j]; W[r][j] = t; }
+            }
+        }
+        const double d = 1.0 / W[c][c];
+#pragma unroll
+        for (int j = 0; j < 2 * n; j++) W[c][j] *= d;
+#pragma unroll
+        for (int r = 0; r < n; r++) {
+            if (r != c) {
+                const double f = W[r][c];
+#pragma unroll
+                for (int j = 0; j < 2 * n; j++) W[r][j] -= f * W[c][j];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < n; i++)
+#pragma unroll
+        for (int j = 0; j < n; j++) Ainv[i * n + j] = W[i][n + j];
+    return ok;
+}
+
+// SPD inverse through Cholesky (same arithmetic order as the reference restatement); S, Sinv row-major m x m
+template <int m> GD bool inv_spd(const double* S, double* Sinv) {
+    double L[m][m], Li[m][m];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < m; i++)
+#pragma unroll
+        for (int j = 0; j < m; j++) { L[i][j] = 0; Li[i][j] = 0; }
+#pragma unroll
+    for (int j = 0; j < m; j++) {
+        double d = S[j * m + j];
+#pragma unroll
+        for (int l = 0; l < j; l++) d -= L[j][l] * L[j][l];
+        if (!(d > 0.0)) ok = false;
+        d = sqrt(d);
+        L[j][j] = d;
+#pragma unroll
+        for (int i = j + 1; i < m; i++) {
+            double s = S[i * m + j];
+#pragma unroll
+            for (int l = 0; l < j; l++) s -= L[i][l] * L[j][l];
+            L[i][j] = s / d;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < m; j++) {
+        Li[j][j] = 1.0 / L[j][j];
+#pragma unroll
+        for (int i = j + 1; i < m; i++) {
+            double s = 0;
+#pragma unroll
+            for (int l = j; l < i; l++) s -= L[i][l] * Li[l][j];
+            Li[i][j] = s / L[i][i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < m; i++)
+#pragma unroll
+        for (int j = 0; j < m; j++) {
+            double s = 0;
+#pragma unroll
+            for (int l = (i > j ? i : j); l < m; l++) s += Li[l][i] * Li[l][j];
+            Sinv[i * m + j] = s;
+        }
+    return ok;
+}
+
+// runtime-size SPD inverse in memory (LDS), single thread; used for the ng x ng goal system
+GD bool inv_spd_rt(const double* S, double* Sinv, double* Lw, int n) {
+    bool ok = true;
+    for (int i = 0; i < n * n; i++) { Lw[i] = 0; Sinv[i] = 0; }
+    for (int j = 0; j < n; j++) {
+        double d = S[j * n + j];
+        for (int l = 0; l < j; l++) d -= Lw[j * n + l] * Lw[j * n + l];
+        if (!(d > 0.0)) ok = false;
+        d = sqrt(d);
+        Lw[j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = S[i * n + j];
+            for (int l = 0; l < j; l++) s -= Lw[i * n + l] * Lw[j * n + l];
+            Lw[i * n + j] = s / d;
+        }
+    }
+    // Sinv <- L^{-1} (lower), then Lw <- L^{-T} L^{-1}
+    for (int j = 0; j < n; j++) {
+        Sinv[j * n + j] = 1.0 / Lw[j * n + j];
+        for (int i = j + 1; i < n; i++) {
+            double s = 0;
+            for (int l = j; l < i; l++) s -= Lw[i * n + l] * Sinv[l * n + j];
+            Sinv[i * n + j] = s / Lw[i * n + i];
+        }
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double s = 0;
+            for (int l = (i > j ? i : j); l < n; l++) s += Sinv[l * n + i] * Sinv[l * n + j];
+            Lw[i * n + j] = s;
+        }
+    for (int i = 0; i < n * n; i++) Sinv[i] = Lw[i];
+    return ok;
+}
+
+}  // namespace gusto

@@ -1,0 +1,419 @@
+// gusto_hip.hip -- host side of libgusto_hip.so: the C ABI of include/gusto_hip.h over the HIP kernels.
+// There is no CPU fallback: every entry point needs a gfx950 device and fails loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "scp.hpp"
+
+using namespace gusto;
+
+struct gusto_handle_s {
+    int model = 0, n = 0, m = 0, N = 0, batch_cap = 0, hist_cap = 0, device = 0, B = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    gusto_scp_params sp{};
+    gusto_model_params mp{};
+    gusto_ipm_opts io{};
+    int n_box = 0, n_sph = 0;
+    double *d_box = nullptr, *d_sph = nullptr;
+    double *d_X = nullptr, *d_U = nullptr, *d_xinit = nullptr, *d_glo = nullptr, *d_ghi = nullptr, *d_tf = nullptr;
+    int* d_sti = nullptr;
+    double* d_std = nullptr;
+    double *d_Jt = nullptr, *d_Jf = nullptr, *d_conv = nullptr, *d_Delta = nullptr, *d_omega = nullptr, *d_rho = nullptr;
+    int *d_acc = nullptr, *d_scp = nullptr, *d_sol = nullptr, *d_tr = nullptr, *d_cvx = nullptr, *d_ipm = nullptr;
+    double* d_ws = nullptr;
+    size_t ws_doubles = 0;
+    double *d_subD = nullptr, *d_subW = nullptr, *d_subT = nullptr, *d_subX = nullptr, *d_subU = nullptr, *d_subObj = nullptr;
+    int *d_subSt = nullptr, *d_subIt = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0;
+    bool have_problems = false;
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+#define HIPCHK(h, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            std::string msg_ = std::string(#call) + ": " + hipGetErrorString(e_);             \
+            if (h) (h)->err = msg_;                                                            \
+            g_err = msg_;                                                                      \
+            return GUSTO_ERR_HIP;                                                              \
+        }                                                                                      \
+    } while (0)
+
+template <class Tp> static hipError_t dalloc(Tp** p, size_t count) {
+    return hipMalloc(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(Tp));
+}
+
+extern "C" {
+
+int gusto_model_dims(int model, int* n, int* m) {
+    switch (model) {
+    case GUSTO_FREEFLYER_SE2: *n = 6; *m = 3; return GUSTO_OK;
+    case GUSTO_DUBINS_CAR: *n = 3; *m = 1; return GUSTO_OK;
+    case GUSTO_ASTROBEE_SE3: *n = 12; *m = 6; return GUSTO_OK;
+    case GUSTO_ASTROBEE_SE3_MANIFOLD: *n = 13; *m = 6; return GUSTO_OK;
+    }
+    return GUSTO_ERR_ARG;
+}
+
+int gusto_default_params(int model, gusto_scp_params* sp, gusto_model_params* mp) {
+    int n, m;
+    if (gusto_model_dims(model, &n, &m) || !sp || !mp) return GUSTO_ERR_ARG;
+    memset(sp, 0, sizeof(*sp));
+    memset(mp, 0, sizeof(*mp));
+    sp->omega_max = 1.0e10; sp->beta_succ = 2.0; sp->beta_fail = 0.5; sp->omega0 = 1.0;
+    mp->n_robot_comp = 1;
+    const double pi = 3.14159265358979323846;
+    switch (model) {
+    case GUSTO_FREEFLYER_SE2:  // freeflyer_se2.jl:15-39, robot/freeflyer.jl:28-62
+        sp->Delta0 = 3.0; sp->eps = 1.0e-2; sp->rho0 = 0.1; sp->rho1 = 0.3; sp->gamma_fail = 10.0;
+        sp->convergence_threshold = 1.0e-2;
+        mp->mass = 0.5 * (15.36 + 18.08);
+        mp->Jdiag[0] = mp->Jdiag[1] = mp->Jdiag[2] = 0.184;
+        mp->radius = 0.157; mp->clearance = 0.05;
+        mp->hard_limit_vel = 0.2;
+        mp->hard_limit_accel = 2 * 0.185 / mp->mass;
+        mp->hard_limit_omega = 20 * pi / 180;
+        mp->hard_limit_alpha = (1.0 / (0.184 / 6.43)) * 0.593;
+        mp->n_robot_comp = 2;  // body + arm cylinder (freeflyer.jl:53-57)
+        mp->comp_off[1][1] = 0.15;
+        break;
+    case GUSTO_DUBINS_CAR:  // dubins_car.jl:22-52
+        sp->Delta0 = 10000.0; sp->eps = 1.0e-6; sp->rho0 = 0.4; sp->rho1 = 1.5; sp->gamma_fail = 5.0;
+        sp->convergence_threshold = 1e-4;
+        mp->dubins_v = 2.0; mp->dubins_k = 1.0;
+        mp->x_max[0] = 100.0; mp->x_max[1] = 100.0; mp->x_max[2] = 2 * pi;
+        for (int i = 0; i < 3; i++) mp->x_min[i] = -mp->x_max[i];
+        mp->u_max = 10.0; mp->u_min = -10.0;
+        mp->clearance = 0.01;
+        break;
+    case GUSTO_ASTROBEE_SE3:           // astrobee_se3.jl:16-40, robot/astrobee3D.jl:15-33
+    case GUSTO_ASTROBEE_SE3_MANIFOLD:  // astrobee_se3_manifold.jl:18-46
+        if (model == GUSTO_ASTROBEE_SE3) {
+            sp->Delta0 = 10.0; sp->eps = 1.0e-6; sp->rho0 = 0.01; sp->rho1 = 0.05; sp->gamma_fail = 5.0;
+            sp->convergence_threshold = 1e-2;
+        } else {
+            sp->Delta0 = 1000.0; sp->eps = 1.0e-1; sp->rho0 = 0.01; sp->rho1 = 100.0; sp->gamma_fail = 5.0;
+            sp->convergence_threshold = 1e-4;
+        }
+        mp->mass = 7.0;
+        mp->Jdiag[0] = mp->Jdiag[1] = mp->Jdiag[2] = 0.1083;
+        mp->radius = sqrt(3.0) * 0.5 * 0.305;
+        mp->clearance = 0.03;
+        mp->hard_limit_vel = 0.5; mp->hard_limit_accel = 0.1;
+        mp->hard_limit_omega = 45 * pi / 180; mp->hard_limit_alpha = 50 * pi / 180;
+        break;
+    }
+    return GUSTO_OK;
+}
+
+int gusto_default_ipm_opts(gusto_ipm_opts* o) {
+    if (!o) return GUSTO_ERR_ARG;
+    o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = 1e-11; o->tr_tol = 1e-6; o->max_iter = 60;
+    return GUSTO_OK;
+}
+
+const char* gusto_last_error(gusto_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int gusto_create(gusto_handle* out, int model, int N, int batch_cap, int hist_cap, int device) {
+    int n, m;
+    if (!out || gusto_model_dims(model, &n, &m) || N < 3 || N > 256 || batch_cap < 1 || hist_cap < 4) {
+        g_err = "gusto_create: bad argument (need 3 <= N <= 256, batch_cap >= 1, hist_cap >= 4)";
+        return GUSTO_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_err = "gusto_create: no usable HIP device (libgusto_hip has no CPU fallback)";
+        return GUSTO_ERR_NO_DEVICE;
+    }
+    gusto_handle h = new gusto_handle_s();
+    h->model = model; h->n = n; h->m = m; h->N = N; h->batch_cap = batch_cap; h->hist_cap = hist_cap; h->device = device;
+    gusto_default_params(model, &h->sp, &h->mp);
+    gusto_default_ipm_opts(&h->io);
+    *out = h;
+    HIPCHK(h, hipSetDevice(device));
+    HIPCHK(h, hipStreamCreate(&h->stream));
+    h->own_stream = true;
+    HIPCHK(h, hipEventCreate(&h->ev0));
+    HIPCHK(h, hipEventCreate(&h->ev1));
+    const size_t B = batch_cap, H = hist_cap;
+    HIPCHK(h, dalloc(&h->d_X, B * N * n)); HIPCHK(h, dalloc(&h->d_U, B * N * m));
+    HIPCHK(h, dalloc(&h->d_xinit, B * n)); HIPCHK(h, dalloc(&h->d_glo, B * n)); HIPCHK(h, dalloc(&h->d_ghi, B * n));
+    HIPCHK(h, dalloc(&h->d_tf, B));
+    HIPCHK(h, dalloc(&h->d_sti, B * ST_NI)); HIPCHK(h, dalloc(&h->d_std, B * SD_ND));
+    HIPCHK(h, dalloc(&h->d_Jt, B * H)); HIPCHK(h, dalloc(&h->d_Jf, B * H)); HIPCHK(h, dalloc(&h->d_conv, B * H));
+    HIPCHK(h, dalloc(&h->d_Delta, B * H)); HIPCHK(h, dalloc(&h->d_omega, B * H)); HIPCHK(h, dalloc(&h->d_rho, B * H));
+    HIPCHK(h, dalloc(&h->d_acc, B * H)); HIPCHK(h, dalloc(&h->d_scp, B * H)); HIPCHK(h, dalloc(&h->d_sol, B * H));
+    HIPCHK(h, dalloc(&h->d_tr, B * H)); HIPCHK(h, dalloc(&h->d_cvx, B * H)); HIPCHK(h, dalloc(&h->d_ipm, B * H));
+    HIPCHK(h, dalloc(&h->d_subD, B)); HIPCHK(h, dalloc(&h->d_subW, B)); HIPCHK(h, dalloc(&h->d_subT, B));
+    HIPCHK(h, dalloc(&h->d_subX, B * N * n)); HIPCHK(h, dalloc(&h->d_subU, B * N * m)); HIPCHK(h, dalloc(&h->d_subObj, B));
+    HIPCHK(h, dalloc(&h->d_subSt, B)); HIPCHK(h, dalloc(&h->d_subIt, B));
+    HIPCHK(h, dalloc(&h->d_box, 1)); HIPCHK(h, dalloc(&h->d_sph, 1));
+    return GUSTO_OK;
+}
+
+int gusto_destroy(gusto_handle h) {
+    if (!h) return GUSTO_ERR_ARG;
+    hipSetDevice(h->device);
+    void* ptrs[] = {h->d_X, h->d_U, h->d_xinit, h->d_glo, h->d_ghi, h->d_tf, h->d_sti, h->d_std, h->d_Jt, h->d_Jf, h->d_conv,
+                    h->d_Delta, h->d_omega, h->d_rho, h->d_acc, h->d_scp, h->d_sol, h->d_tr, h->d_cvx, h->d_ipm, h->d_ws,
+                    h->d_subD, h->d_subW, h->d_subT, h->d_subX, h->d_subU, h->d_subObj, h->d_subSt, h->d_subIt, h->d_box, h->d_sph};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return GUSTO_OK;
+}
+
+int gusto_set_params(gusto_handle h, const gusto_scp_params* sp, const gusto_model_params* mp) {
+    if (!h) return GUSTO_ERR_ARG;
+    if (sp) h->sp = *sp;
+    if (mp) h->mp = *mp;
+    return GUSTO_OK;
+}
+int gusto_set_ipm_opts(gusto_handle h, const gusto_ipm_opts* o) {
+    if (!h || !o) return GUSTO_ERR_ARG;
+    h->io = *o;
+    return GUSTO_OK;
+}
+int gusto_set_stream(gusto_handle h, void* s) {
+    if (!h) return GUSTO_ERR_ARG;
+    if (h->own_stream && h->stream) { hipStreamDestroy(h->stream); h->own_stream = false; }
+    if (s) { h->stream = (hipStream_t)s; }
+    else { HIPCHK(h, hipStreamCreate(&h->stream)); h->own_stream = true; }
+    return GUSTO_OK;
+}
+
+int gusto_set_env(gusto_handle h, int n_box, const double* box, int n_sph, const double* sph) {
+    if (!h || n_box < 0 || n_sph < 0 || (n_box && !box) || (n_sph && !sph)) return GUSTO_ERR_ARG;
+    if (n_box + n_sph > 64) { h->err = "gusto_set_env: at most 64 keep-out components"; return GUSTO_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    hipFree(h->d_box); hipFree(h->d_sph);
+    h->d_box = h->d_sph = nullptr;
+    HIPCHK(h, dalloc(&h->d_box, (size_t)6 * n_box)); HIPCHK(h, dalloc(&h->d_sph, (size_t)4 * n_sph));
+    if (n_box) HIPCHK(h, hipMemcpy(h->d_box, box, sizeof(double) * 6 * n_box, hipMemcpyHostToDevice));
+    if (n_sph) HIPCHK(h, hipMemcpy(h->d_sph, sph, sizeof(double) * 4 * n_sph, hipMemcpyHostToDevice));
+    h->n_box = n_box; h->n_sph = n_sph;
+    return GUSTO_OK;
+}
+
+}  // extern "C"
+
+// ---- kernel dispatch ---------------------------------------------------------------------------------
+template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B) {
+    using T = MT<MODEL>;
+    memset(&P, 0, sizeof(P));
+    P.N = h->N; P.B = B; P.n_box = h->n_box; P.n_sph = h->n_sph;
+    P.n_obs = T::HAS_OBS ? h->n_box + h->n_sph : 0;
+    P.hist_cap = h->hist_cap;
+    P.sp = h->sp; P.mp = h->mp; P.io = h->io;
+    P.box = h->d_box; P.sph = h->d_sph; P.X = h->d_X; P.U = h->d_U;
+    P.x_init = h->d_xinit; P.goal_lo = h->d_glo; P.goal_hi = h->d_ghi; P.tf = h->d_tf;
+    P.sub_Delta = h->d_subD; P.sub_omega = h->d_subW; P.sub_toggle = h->d_subT; P.sub_X = h->d_subX; P.sub_U = h->d_subU;
+    P.sub_obj = h->d_subObj; P.sub_status = h->d_subSt; P.sub_iters = h->d_subIt;
+    P.st_i = h->d_sti; P.st_d = h->d_std;
+    P.J_true = h->d_Jt; P.J_full = h->d_Jf; P.conv = h->d_conv; P.Delta = h->d_Delta; P.omega = h->d_omega; P.rho = h->d_rho;
+    P.accept = h->d_acc; P.scp_status = h->d_scp; P.solver_status = h->d_sol; P.tr_sat = h->d_tr; P.cvx_sat = h->d_cvx;
+    P.ipm_it = h->d_ipm;
+    P.wl = make_ws_layout<MODEL>(h->N, P.n_obs);
+    P.ll = make_lds_layout<MODEL>(h->N);
+    const size_t need = P.wl.total * (size_t)h->batch_cap;
+    if (need > h->ws_doubles) {
+        if (h->d_ws) hipFree(h->d_ws);
+        h->d_ws = nullptr; h->ws_doubles = 0;
+        HIPCHK(h, dalloc(&h->d_ws, need));
+        h->ws_doubles = need;
+    }
+    P.ws = h->d_ws;
+    return GUSTO_OK;
+}
+
+template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_iter, int force) {
+    KParams P;
+    int rc = fill_params<MODEL>(h, P, h->B);
+    if (rc) return rc;
+    P.mode = mode; P.max_iter = max_iter; P.force = force;
+    const int NT = 64 * ((h->N + 63) / 64);
+    const size_t lds = (size_t)P.ll.total * sizeof(double);
+    if (lds > 160 * 1024) { h->err = "problem does not fit the 160 KiB LDS of a CU"; return GUSTO_ERR_ARG; }
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&scp_kernel<MODEL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(scp_kernel<MODEL>, dim3(h->B), dim3(NT), lds, h->stream, P);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_ms = ms;
+    return GUSTO_OK;
+}
+
+template <int MODEL> static int launch_init(gusto_handle h, bool straight) {
+    KParams P;
+    int rc = fill_params<MODEL>(h, P, h->B);
+    if (rc) return rc;
+    if (straight) {
+        const int tot = h->B * h->N;
+        hipLaunchKernelGGL(init_straightline_kernel<MODEL>, dim3((tot + 255) / 256), dim3(256), 0, h->stream, P);
+        HIPCHK(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(reset_state_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, P);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GUSTO_OK;
+}
+
+#define DISPATCH(h, expr)                                                                    \
+    switch ((h)->model) {                                                                    \
+    case GUSTO_FREEFLYER_SE2: { constexpr int MODEL = GUSTO_FREEFLYER_SE2; return expr; }    \
+    case GUSTO_DUBINS_CAR: { constexpr int MODEL = GUSTO_DUBINS_CAR; return expr; }          \
+    case GUSTO_ASTROBEE_SE3: { constexpr int MODEL = GUSTO_ASTROBEE_SE3; return expr; }      \
+    case GUSTO_ASTROBEE_SE3_MANIFOLD: { constexpr int MODEL = GUSTO_ASTROBEE_SE3_MANIFOLD; return expr; } \
+    default: return GUSTO_ERR_ARG;                                                           \
+    }
+
+static int do_init(gusto_handle h, bool straight) { DISPATCH(h, launch_init<MODEL>(h, straight)); }
+static int do_scp(gusto_handle h, int mode, int max_iter, int force) { DISPATCH(h, launch_scp<MODEL>(h, mode, max_iter, force)); }
+
+extern "C" {
+
+static int set_problems_impl(gusto_handle h, int B, const double* x_init, const double* glo, const double* ghi,
+                             const double* tf, const double* X0, const double* U0, hipMemcpyKind kind) {
+    if (!h || B < 1 || B > h->batch_cap || !x_init || !glo || !ghi || !tf || ((X0 == nullptr) != (U0 == nullptr))) {
+        if (h) h->err = "gusto_set_problems: bad argument";
+        return GUSTO_ERR_ARG;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = h->n, m = h->m, N = h->N;
+    h->B = B;
+    HIPCHK(h, hipMemcpyAsync(h->d_xinit, x_init, sizeof(double) * B * n, kind, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_glo, glo, sizeof(double) * B * n, kind, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_ghi, ghi, sizeof(double) * B * n, kind, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_tf, tf, sizeof(double) * B, kind, h->stream));
+    if (X0) {
+        HIPCHK(h, hipMemcpyAsync(h->d_X, X0, sizeof(double) * B * N * n, kind, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_U, U0, sizeof(double) * B * N * m, kind, h->stream));
+    }
+    int rc = do_init(h, X0 == nullptr);
+    if (rc) return rc;
+    h->have_problems = true;
+    return GUSTO_OK;
+}
+
+int gusto_set_problems(gusto_handle h, int B, const double* x_init, const double* glo, const double* ghi, const double* tf,
+                       const double* X0, const double* U0) {
+    return set_problems_impl(h, B, x_init, glo, ghi, tf, X0, U0, hipMemcpyHostToDevice);
+}
+int gusto_set_problems_dev(gusto_handle h, int B, const double* x_init, const double* glo, const double* ghi,
+                           const double* tf, const double* X0, const double* U0) {
+    return set_problems_impl(h, B, x_init, glo, ghi, tf, X0, U0, hipMemcpyDeviceToDevice);
+}
+
+int gusto_solve(gusto_handle h, int max_iter, int force) {
+    if (!h || max_iter < 0) return GUSTO_ERR_ARG;
+    if (!h->have_problems) { h->err = "gusto_solve: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    return do_scp(h, 0, max_iter, force ? 1 : 0);
+}
+
+int gusto_last_solve_ms(gusto_handle h, double* ms) {
+    if (!h || !ms) return GUSTO_ERR_ARG;
+    *ms = h->last_ms;
+    return GUSTO_OK;
+}
+
+int gusto_get_traj(gusto_handle h, double* X, double* U) {
+    if (!h || !h->have_problems) return GUSTO_ERR_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (X) HIPCHK(h, hipMemcpy(X, h->d_X, sizeof(double) * h->B * h->N * h->n, hipMemcpyDeviceToHost));
+    if (U) HIPCHK(h, hipMemcpy(U, h->d_U, sizeof(double) * h->B * h->N * h->m, hipMemcpyDeviceToHost));
+    return GUSTO_OK;
+}
+int gusto_get_traj_dev(gusto_handle h, const double** X, const double** U) {
+    if (!h) return GUSTO_ERR_ARG;
+    if (X) *X = h->d_X;
+    if (U) *U = h->d_U;
+    return GUSTO_OK;
+}
+
+int gusto_get_status(gusto_handle h, int* iterations, int* converged, int* successful, int* stop, int* ipm) {
+    if (!h || !h->have_problems) return GUSTO_ERR_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<int> st((size_t)h->B * ST_NI);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_sti, sizeof(int) * st.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->B; b++) {
+        if (iterations) iterations[b] = st[(size_t)b * ST_NI + ST_ITER];
+        if (converged) converged[b] = st[(size_t)b * ST_NI + ST_CONV];
+        if (successful) successful[b] = st[(size_t)b * ST_NI + ST_SUCC];
+        if (stop) stop[b] = st[(size_t)b * ST_NI + ST_STOP];
+        if (ipm) ipm[b] = st[(size_t)b * ST_NI + ST_IPM];
+    }
+    return GUSTO_OK;
+}
+
+int gusto_get_dual(gusto_handle h, double* dual) {
+    if (!h || !dual || !h->have_problems) return GUSTO_ERR_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<double> sd((size_t)h->B * SD_ND);
+    HIPCHK(h, hipMemcpy(sd.data(), h->d_std, sizeof(double) * sd.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->B; b++)
+        for (int i = 0; i < h->n; i++) dual[(size_t)b * h->n + i] = sd[(size_t)b * SD_ND + SD_DUAL + i];
+    return GUSTO_OK;
+}
+
+int gusto_get_history(gusto_handle h, gusto_history* o) {
+    if (!h || !o || !h->have_problems) return GUSTO_ERR_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    o->hist_cap = h->hist_cap;
+    const size_t cnt = (size_t)h->B * h->hist_cap;
+    std::vector<int> st((size_t)h->B * ST_NI);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_sti, sizeof(int) * st.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->B; b++) {
+        if (o->n_hist) o->n_hist[b] = st[(size_t)b * ST_NI + ST_NHIST];
+        if (o->nJ) o->nJ[b] = st[(size_t)b * ST_NI + ST_NJ];
+        if (o->n_rho) o->n_rho[b] = st[(size_t)b * ST_NI + ST_NRHO];
+    }
+#define CPD(dst, src) if (dst) HIPCHK(h, hipMemcpy(dst, src, sizeof(*(dst)) * cnt, hipMemcpyDeviceToHost))
+    CPD(o->J_true, h->d_Jt); CPD(o->J_full, h->d_Jf); CPD(o->convergence_measure, h->d_conv); CPD(o->Delta, h->d_Delta);
+    CPD(o->omega, h->d_omega); CPD(o->rho, h->d_rho); CPD(o->accept_solution, h->d_acc); CPD(o->scp_status, h->d_scp);
+    CPD(o->solver_status, h->d_sol); CPD(o->trust_region_satisfied, h->d_tr); CPD(o->convex_ineq_satisfied, h->d_cvx);
+    CPD(o->ipm_iters, h->d_ipm);
+#undef CPD
+    return GUSTO_OK;
+}
+
+int gusto_subproblem(gusto_handle h, int B, const double* Xp, const double* Up, const double* Delta, const double* omega,
+                     const double* toggle, double* Xn, double* Un, double* obj, int* status, int* iters) {
+    if (!h || !h->have_problems || B != h->B || !Xp || !Up || !Delta || !omega || !toggle) {
+        if (h) h->err = "gusto_subproblem: call gusto_set_problems with the same B first";
+        return GUSTO_ERR_STATE;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = h->n, m = h->m, N = h->N;
+    HIPCHK(h, hipMemcpy(h->d_X, Xp, sizeof(double) * B * N * n, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_U, Up, sizeof(double) * B * N * m, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_subD, Delta, sizeof(double) * B, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_subW, omega, sizeof(double) * B, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_subT, toggle, sizeof(double) * B, hipMemcpyHostToDevice));
+    int rc = do_scp(h, 1, 0, 0);
+    if (rc) return rc;
+    if (Xn) HIPCHK(h, hipMemcpy(Xn, h->d_subX, sizeof(double) * B * N * n, hipMemcpyDeviceToHost));
+    if (Un) HIPCHK(h, hipMemcpy(Un, h->d_subU, sizeof(double) * B * N * m, hipMemcpyDeviceToHost));
+    if (obj) HIPCHK(h, hipMemcpy(obj, h->d_subObj, sizeof(double) * B, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(h, hipMemcpy(status, h->d_subSt, sizeof(int) * B, hipMemcpyDeviceToHost));
+    if (iters) HIPCHK(h, hipMemcpy(iters, h->d_subIt, sizeof(int) * B, hipMemcpyDeviceToHost));
+    return GUSTO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+// rows.hpp -- the stage-local inequality rows of the convex subproblem and the per-row interior point algebra.
+//
+// The reference registers constraint functions per model in SCPConstraints(SCPP) (freeflyer_se2.jl:338-390,
+// dubins_car.jl:184-226, astrobee_se3.jl:322-379, astrobee_se3_manifold.jl:533-608) and JuMP expands them
+// into rows (scp_gusto.jl:192-314).  Here a model is a compile-time "row program": visit_rows<MODEL> walks
+// the rows of one knot and hands each to an Op functor; every row is either a diagonal quadratic or a linear
+// function of x_k or of u_k, so an Op only ever touches a fixed index window [I0, I0+CNT).
+#pragma once
+#include <type_traits>
+
+#include "models.hpp"
+
+namespace gusto {
+
+template <int CNT> struct RowEv {
+    double g;        // scaled row value  ghat = mul * raw - off
+    double raw;      // the reference's constraint function value
+    double gr[CNT];  // gradient of ghat on its window
+    double hd[CNT];  // Hessian diagonal of ghat on its window
+};
+
+template <int MODEL> struct RowCtx {
+    const KParams* P;
+    int N, k, nslot;
+    double kappa, omega, Delta;
+    const double* xp;      // linearisation state of this knot
+    uint64_t mask;         // active obstacle rows (dist < obstacle_toggle_distance)
+    const double* obs_nh;  // [n_obs][WS][N]
+    const double* obs_c0;  // [n_obs][N]
+    const double* goal_lo;
+    const double* goal_hi;
+};
+
+template <int I, int E, class F> GD void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
+template <bool ISU, int I0, int CNT, class Op>
+GD void quad_row(Op& op, int slot, int kind, const double* v, const double* a, const double* v0, double c0,
+                 double mul, double off) {
+    RowEv<CNT> ev;
+    double g = c0;
+#pragma unroll
+    for (int j = 0; j < CNT; j++) {
+        const double e = v[I0 + j] - (v0 ? v0[j] : 0.0);
+        g += a[j] * e * e;
+        ev.gr[j] = mul * (2 * a[j] * e);
+        ev.hd[j] = mul * 2 * a[j];
+    }
+    ev.raw = g;
+    ev.g = mul * g - off;
+    op.template row<ISU, I0, CNT>(slot, kind, ev);
+}
+template <bool ISU, int I0, int CNT, class Op>
+GD void lin_row(Op& op, int slot, int kind, const double* v, const double* b, double c0, double mul, double off) {
+    RowEv<CNT> ev;
+    double g = c0;
+#pragma unroll
+    for (int j = 0; j < CNT; j++) {
+        g += b[j] * v[I0 + j];
+        ev.gr[j] = mul * b[j];
+        ev.hd[j] = 0.0;
+    }
+    ev.raw = g;
+    ev.g = mul * g - off;
+    op.template row<ISU, I0, CNT>(slot, kind, ev);
+}
+
+// ---- the row programs ------------------------------------------------------------------------------
+template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const double* xs, const double* us, Op& op) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n;
+    const gusto_model_params& mp = c.P->mp;
+    const double kw = c.kappa * c.omega;
+    const int slot_obs = T::NFIX, slot_goal = T::NFIX + c.P->n_obs, slot_u = slot_goal + 2 * n;
+    double one[n];
+#pragma unroll
+    for (int j = 0; j < n; j++) one[j] = 1.0;
+
+    if constexpr (MODEL == GUSTO_FREEFLYER_SE2 || MODEL == GUSTO_ASTROBEE_SE3 || MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD) {
+        constexpr bool is2 = MODEL == GUSTO_FREEFLYER_SE2, man = MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD;
+        constexpr int nv = is2 ? 2 : 3, iw = is2 ? 5 : (man ? 10 : 9), nw = is2 ? 1 : 3;
+        int slot = 0;
+        if constexpr (!man) {  // stri_state_trust_region (freeflyer_se2.jl:323-326): w*||x-xp||^2 - Delta <= s
+            quad_row<false, 0, n>(op, slot++, ROW_PEN_TR, xs, one, c.xp, 0.0, kw, c.kappa * c.Delta);
+        } else {
+            // cse_quaternion_norm (manifold.jl:308-313), penalised as a +-eps pair (scp_gusto.jl:297-311)
+            const double* qp = c.xp + 6;
+            const double qn = sqrt(qp[0] * qp[0] + qp[1] * qp[1] + qp[2] * qp[2] + qp[3] * qp[3]);
+            double bp[4], bm[4], c0 = qn - 1.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { bp[j] = qp[j] / qn; bm[j] = -bp[j]; c0 -= qp[j] * qp[j] / qn; }
+            lin_row<false, 6, 4>(op, slot++, ROW_HARD_EQ, xs, bm, -c0, kw, c.kappa * c.P->sp.eps);
+            lin_row<false, 6, 4>(op, slot++, ROW_PEN_EQ, xs, bp, c0, kw, c.kappa * c.P->sp.eps);
+            const double m1 = -1.0;  // csi_orientation_sign (manifold.jl:316-319)
+            lin_row<false, 6, 1>(op, slot++, ROW_PEN, xs, &m1, 0.0, kw, 0.0);
+        }
+        // csi_translational_velocity_bound / csi_angular_velocity_bound (freeflyer_se2.jl:225-233)
+        quad_row<false, 3, nv>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
+        quad_row<false, iw, nw>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_omega * mp.hard_limit_omega, kw, 0.0);
+        // ncsi_*_obstacle_avoidance_*_convexified (freeflyer_se2.jl:265-288): clearance - (d + nhat.(r - r0))
+        uint64_t mk = c.mask;
+        while (mk) {
+            const int i = __ffsll((unsigned long long)mk) - 1;
+            mk &= mk - 1;
+            double b[T::WS];
+#pragma unroll
+            for (int j = 0; j < T::WS; j++) b[j] = -c.obs_nh[((size_t)i * T::WS + j) * c.N + c.k];
+            lin_row<false, 0, T::WS>(op, slot_obs + i, ROW_PEN, xs, b, c.obs_c0[(size_t)i * c.N + c.k], kw, 0.0);
+        }
+        if (c.k < c.N - 1) {  // cci_*_accel_bound on k = 1..N-1 only (freeflyer_se2.jl:236-245,380-381)
+            constexpr int nf = is2 ? 2 : 3, im = is2 ? 2 : 3, nm = is2 ? 1 : 3;
+            double af[nf], am[nm];
+#pragma unroll
+            for (int j = 0; j < nf; j++) af[j] = 1.0 / (mp.mass * mp.mass);
+#pragma unroll
+            for (int j = 0; j < nm; j++) { const double ji = 1.0 / mp.Jdiag[is2 ? 2 : j]; am[j] = ji * ji; }
+            quad_row<true, 0, nf>(op, slot_u, ROW_HARD, us, af, nullptr, -mp.hard_limit_accel * mp.hard_limit_accel,
+                                  1.0 / (mp.hard_limit_accel * mp.hard_limit_accel), 0.0);
+            quad_row<true, im, nm>(op, slot_u + 1, ROW_HARD, us, am, nullptr, -mp.hard_limit_alpha * mp.hard_limit_alpha,
+                                   1.0 / (mp.hard_limit_alpha * mp.hard_limit_alpha), 0.0);
+        }
+    } else {  // DubinsCar: csi_max/min_bound_constraints, cci_max/min_bound_constraints (dynamics.jl:56-81)
+        static_for<0, n>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const double p1 = 1.0, m1 = -1.0;
+            lin_row<false, i, 1>(op, i, ROW_PEN, xs, &p1, -mp.x_max[i], kw, 0.0);
+            lin_row<false, i, 1>(op, n + i, ROW_PEN, xs, &m1, mp.x_min[i], kw, 0.0);
+        });
+        if (c.k < c.N - 1) {
+            const double p1 = 1.0, m1 = -1.0;
+            lin_row<true, 0, 1>(op, slot_u, ROW_HARD, us, &p1, -mp.u_max, 1.0 / fabs(mp.u_max), 0.0);
+            lin_row<true, 0, 1>(op, slot_u + 1, ROW_HARD, us, &m1, mp.u_min, 1.0 / fabs(mp.u_min), 0.0);
+        }
+    }
+    if (c.k == c.N - 1) {  // csbci_goal_constraints: BoxGoal rows are hard (dynamics.jl:37-42, scp_gusto.jl:236-245)
+        static_for<0, n>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const double lo = c.goal_lo[i], hi = c.goal_hi[i];
+            if (lo != hi) {
+                const double hw = (isfinite(hi) && isfinite(lo)) ? 0.5 * (hi - lo) : 1.0;
+                const double sc = 1.0 / fmax(1e-3, fmin(1.0, hw));
+                const double p1 = 1.0, m1 = -1.0;
+                if (isfinite(hi)) lin_row<false, i, 1>(op, slot_goal + 2 * i, ROW_HARD, xs, &p1, -hi, sc, 0.0);
+                if (isfinite(lo)) lin_row<false, i, 1>(op, slot_goal + 2 * i + 1, ROW_HARD, xs, &m1, lo, sc, 0.0);
+            }
+        });
+    }
+}
+
+// ---- per-row state access --------------------------------------------------------------------------
+struct RowState {
+    double* base;
+    int nslot, N, k;
+    GD double& at(int var, int slot) const { return base[((size_t)var * nslot + slot) * N + k]; }
+};
+
+// ---- the Ops ---------------------------------------------------------------------------------------
+// start point: slacks strictly interior, penalised multipliers centred (lam_a = lam_b = 1/2)
+struct OpInit {
+    RowState rs;
+    int ncomp = 0;
+    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
+        if (row_is_hard(kind)) {
+            const double t = fmax(-ev.g, 1e-2);
+            rs.at(RS_T, slot) = t; rs.at(RS_LAM, slot) = 0.1 / t; rs.at(RS_LAMB, slot) = 0.0; rs.at(RS_S, slot) = 0.0;
+            ncomp += 1;
+        } else {
+            const double s = fmax(ev.g, 0.0) + 1.0;
+            rs.at(RS_S, slot) = s; rs.at(RS_T, slot) = s - ev.g; rs.at(RS_LAM, slot) = 0.5; rs.at(RS_LAMB, slot) = 0.5;
+            ncomp += 2;
+        }
+    }
+};
+
+// residuals + condensed Hessian:  H += sigma * grad grad^T + lam * hess,  dual residual += lam * grad
+template <int n, int m> struct OpResidHess {
+    RowState rs;
+    double *Hx, *Hu, *rdx, *rdu;
+    double comp = 0, maxrp = 0;
+    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
+        const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
+        double sig, rp;
+        if (row_is_hard(kind)) {
+            rp = ev.g + t;
+            comp += t * lam;
+            sig = lam / t;
+        } else {
+            const double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
+            rp = ev.g - s + t;
+            comp += t * lam + s * lamb;
+            sig = lam / (t + lam * s / lamb);
+        }
+        maxrp = nanmax(maxrp, fabs(rp));
+        double* H = ISU ? Hu : Hx;
+        double* r = ISU ? rdu : rdx;
+        constexpr int dim = ISU ? m : n;
+#pragma unroll
+        for (int a = 0; a < CNT; a++) {
+            r[I0 + a] += lam * ev.gr[a];
+#pragma unroll
+            for (int b = a; b < CNT; b++) H[sidx(I0 + a, I0 + b, dim)] += sig * ev.gr[a] * ev.gr[b];
+            H[sidx(I0 + a, I0 + a, dim)] += lam * ev.hd[a];
+        }
+    }
+};
+
+// right-hand side of the Newton system: g += coef * grad, coef = predicted new multiplier at dz = 0
+struct OpRhs {
+    RowState rs;
+    double *gx, *gu;
+    int pass;
+    double mu_t;
+    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
+        const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
+        const double ka = pass ? rs.at(RS_KA, slot) : 0.0;
+        double coef;
+        if (row_is_hard(kind)) {
+            const double rp = ev.g + t;
+            coef = (mu_t - ka + lam * rp) / t;
+        } else {
+            const double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
+            const double kb = pass ? rs.at(RS_KB, slot) : 0.0;
+            const double rp = ev.g - s + t;
+            const double D = t + lam * s / lamb;
+            const double rho0 = mu_t - t * lam - ka + lam * rp - (lam / lamb) * (mu_t - s * lamb - kb);
+            coef = lam + rho0 / D;
+        }
+        double* g = ISU ? gu : gx;
+#pragma unroll
+        for (int a = 0; a < CNT; a++) g[I0 + a] += coef * ev.gr[a];
+    }
+};
+
+GD double max_step(double a, double v, double dv, double tau) {
+    if (dv < 0) { const double c = -tau * v / dv; if (c < a) a = c; }
+    return a;
+}
+
+// row steps (dt, dlam, ds) from the primal step and the fraction-to-boundary step length
+struct OpStep {
+    RowState rs;
+    const double *dxs, *dus;
+    int pass;
+    double mu_t, tau;
+    double amax = 1.0;
+    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
+        const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
+        const double ka = pass ? rs.at(RS_KA, slot) : 0.0;
+        const double* dv = ISU ? dus : dxs;
+        double w = 0;
+#pragma unroll
+        for (int a = 0; a < CNT; a++) w += ev.gr[a] * dv[I0 + a];
+        double dt, dl, ds;
+        if (row_is_hard(kind)) {
+            const double rp = ev.g + t;
+            dt = -rp - w;
+            dl = (mu_t - t * lam - ka - lam * dt) / t;
+            ds = 0.0;
+        } else {
+            const double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
+            const double kb = pass ? rs.at(RS_KB, slot) : 0.0;
+            const double rp = ev.g - s + t;
+            const double D = t + lam * s / lamb;
+            const double rho0 = mu_t - t * lam - ka + lam * rp - (lam / lamb) * (mu_t - s * lamb - kb);
+            dl = (rho0 + lam * w) / D;
+            ds = (mu_t - s * lamb - kb + s * dl) / lamb;
+            dt = -rp - w + ds;
+            amax = max_step(amax, s, ds, tau);
+            amax = max_step(amax, lamb, -dl, tau);
+        }
+        amax = max_step(amax, t, dt, tau);
+        amax = max_step(amax, lam, dl, tau);
+        rs.at(RS_DT, slot) = dt; rs.at(RS_DL, slot) = dl; rs.at(RS_DS, slot) = ds;
+    }
+};
+
+// complementarity after the affine step + Mehrotra second-order terms
+struct OpAff {
+    RowState rs;
+    double a_aff;
+    double comp = 0;
+    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>&) {
+        const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
+        const double dt = rs.at(RS_DT, slot), dl = rs.at(RS_DL, slot), ds = rs.at(RS_DS, slot);
+        comp += (t + a_aff * dt) * (lam + a_aff * dl);
+        if (!row_is_hard(kind)) {
+            const double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
+            comp += (s + a_aff * ds) * (lamb - a_aff * dl);
+        }
+        rs.at(RS_KA, slot) = dt * dl;
+        rs.at(RS_KB, slot) = -ds * dl;
+    }
+};
+
+struct OpUpdate {
+    RowState rs;
+    double alpha;
+    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>&) {
+        rs.at(RS_T, slot) += alpha * rs.at(RS_DT, slot);
+        rs.at(RS_LAM, slot) += alpha * rs.at(RS_DL, slot);
+        if (!row_is_hard(kind)) {
+            rs.at(RS_S, slot) += alpha * rs.at(RS_DS, slot);
+            rs.at(RS_LAMB, slot) -= alpha * rs.at(RS_DL, slot);
+        }
+    }
+};
+
+struct OpSlackSum {
+    RowState rs;
+    double sum = 0;
+    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>&) {
+        if (!row_is_hard(kind)) sum += rs.at(RS_S, slot);
+    }
+};
+
+// convex_ineq_satisfied_gusto_jump (scp_gusto.jl:316-343): raw row values against eps
+struct OpCheck {
+    double eps;
+    bool ok = true;
+    template <bool ISU, int I0, int CNT> GD void row(int, int kind, const RowEv<CNT>& ev) {
+        if (ISU) return;
+        if (kind == ROW_PEN && ev.raw >= eps) ok = false;
+        if (kind == ROW_PEN_EQ && (ev.raw <= -eps || ev.raw >= eps)) ok = false;
+    }
+};
+
+}  // namespace gusto

@@ -1,0 +1,98 @@
+"""Problem definitions of the benchmark configs: environments as static obstacle tables
+and reproducible random initial states.  Mirrors what the reference's notebooks build with Table(:stanford),
+HyperRectangle obstacles and ProblemDefinition (examples/freeflyerSE2.ipynb cell 2, src/environment/table.jl)."""
+import numpy as np
+
+FT2M = 0.3048
+
+
+def table_stanford_boxes():
+    """Table(:stanford) keep-out slabs (src/environment/table.jl:11-55) as AABBs [min xyz | max xyz]."""
+    lo = np.array([0.0, 0.0, 0.0])
+    hi = np.array([12.0, 9.0, 0.001]) * FT2M
+    a = 10.0
+    b = [([hi[0], -a, -a], [hi[0] + a, a, a]), ([lo[0] - a, -a, -a], [lo[0], a, a]),
+         ([-a, hi[1], -a], [a, hi[1] + a, a]), ([-a, lo[1] - a, -a], [a, lo[1], a])]
+    return np.array([np.concatenate([np.asarray(x, float), np.asarray(y, float)]) for x, y in b])
+
+
+FREEFLYER_OBSTACLE_CENTERS = np.array([
+    [0.460, 0.315, 0.0], [0.201, 1.085, 0.0], [0.540, 2.020, 0.0], [1.374, 0.196, 0.0], [1.063, 1.354, 0.0],
+    [1.365, 2.322, 0.0], [2.221, 0.548, 0.0], [2.077, 1.443, 0.0], [3.098, 1.186, 0.0], [2.837, 2.064, 0.0]])
+
+
+def freeflyer_notebook_boxes():
+    """The 10 inflated box obstacles of examples/freeflyerSE2.ipynb cell 2.  The notebook builds them as
+    HyperRectangle(Vec3f0(...)), i.e. through Float32 -- reproduced by the float32 round trip."""
+    w = np.array([0.27, 0.27, 0.127])
+    infl = 0.05 * np.ones(3)
+    out = []
+    for c in FREEFLYER_OBSTACLE_CENTERS:
+        mn = (c - 0.5 * w - infl + np.array([0.0, 0.0, 0.5 * w[0]])).astype(np.float32).astype(np.float64)
+        sz = (w + 2 * infl).astype(np.float32).astype(np.float64)
+        out.append(np.concatenate([mn, mn + sz]))
+    return np.array(out)
+
+
+def freeflyer_env():
+    """keepout_zones then obstacle_set, the order Workspace(robot, env) uses (src/types.jl:19)."""
+    return np.vstack([table_stanford_boxes(), freeflyer_notebook_boxes()])
+
+
+FREEFLYER_X_INIT = np.array([0.2, 2.4, 0.0, 0.0, 0.0, 0.0])
+FREEFLYER_X_GOAL = np.array([3.0, 0.5, 0.0, 0.05, -0.05, 0.0])
+FREEFLYER_TF = 200.0
+FREEFLYER_RADIUS = 0.157
+
+
+def splitmix64(seed):
+    """splitmix64 stream; doubles = (u >> 11) * 2^-53."""
+    mask = (1 << 64) - 1
+    state = seed & mask
+    while True:
+        state = (state + 0x9E3779B97F4A7C15) & mask
+        z = state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+        z = z ^ (z >> 31)
+        yield (z >> 11) * (2.0 ** -53)
+
+
+def _sdf_rect2(p, lo, hi):
+    dx = max(lo[0] - p[0], 0.0, p[0] - hi[0])
+    dy = max(lo[1] - p[1], 0.0, p[1] - hi[1])
+    if dx > 0 or dy > 0:
+        return float(np.hypot(dx, dy))
+    return -min(p[0] - lo[0], hi[0] - p[0], p[1] - lo[1], hi[1] - p[1])
+
+
+def freeflyer_random_x_init(B, first=0):
+    """Config 2: position uniform over [0.25,3.40]x[0.25,2.49], rejected while the body is closer than 0.10 m to
+    any box; theta = 0, v = omega = 0.  Problem b uses its own splitmix64 stream seeded 0x9E3779B97F4A7C15 + b."""
+    env = freeflyer_env()
+    X = np.zeros((B, 6))
+    for i in range(B):
+        g = splitmix64(0x9E3779B97F4A7C15 + first + i)
+        while True:
+            p = np.array([0.25 + (3.40 - 0.25) * next(g), 0.25 + (2.49 - 0.25) * next(g)])
+            if min(_sdf_rect2(p, bx[0:2], bx[3:5]) for bx in env) - FREEFLYER_RADIUS >= 0.10:
+                break
+        X[i, 0:2] = p
+    return X
+
+
+def freeflyer_batch(B, first=0):
+    """(x_init, goal_lo, goal_hi, tf) of config 2."""
+    x0 = freeflyer_random_x_init(B, first)
+    goal = np.tile(FREEFLYER_X_GOAL, (B, 1))
+    return x0, goal.copy(), goal.copy(), np.full(B, FREEFLYER_TF)
+
+
+def dubins_batch(B, first=0):
+    """Config 3: x_init uniform over [-3,3]^2 x [-pi,pi], goal (0,0,0), tf = 10."""
+    X = np.zeros((B, 3))
+    for i in range(B):
+        g = splitmix64(0x9E3779B97F4A7C15 + first + i)
+        X[i] = [-3 + 6 * next(g), -3 + 6 * next(g), -np.pi + 2 * np.pi * next(g)]
+    goal = np.zeros((B, 3))
+    return X, goal.copy(), goal.copy(), np.full(B, 10.0)

@@ -1,0 +1,138 @@
+/*
+ * gusto_hip.h -- C ABI of libgusto_hip.so: batched GuSTO sequential convex programming on MI355X.
+ *
+ * One call solves a batch of independent SCP problems of one model type on one GPU.  The library
+ * replaces the reference's `solve_method!` plug-in for the GuSTO path,
+ *     solve_gusto_jump!(SCPS, SCPP, solver, max_iter, force; kw...)      src/scp/scp_gusto.jl:49
+ * which is what `solve_SCP!` calls through its function argument           src/traj_opt.jl:47-72
+ * Each entry point names the reference interface it stands in for.
+ *
+ * Conventions: every function returns 0 on success or a negative gusto_rc; per-problem failures are
+ * data (status arrays), never a failing return code.  All pointers are HOST memory unless the name ends
+ * in `_dev`.  Layouts are the reference's Julia column-major X[n,N], U[m,N] per problem, problem index
+ * slowest: X[b][k][i].  A handle is not thread-safe; use one handle per host thread / GPU.
+ */
+#ifndef GUSTO_HIP_H
+#define GUSTO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GUSTO_MAXN 13
+#define GUSTO_MAXM 6
+
+/* typeof(SCPP.PD.model) -> id (src/dynamics/{freeflyer_se2,dubins_car,astrobee_se3,astrobee_se3_manifold}.jl) */
+enum gusto_model_id {
+    GUSTO_FREEFLYER_SE2 = 0,
+    GUSTO_DUBINS_CAR = 1,
+    GUSTO_ASTROBEE_SE3 = 2,
+    GUSTO_ASTROBEE_SE3_MANIFOLD = 3
+};
+
+enum gusto_rc {
+    GUSTO_OK = 0,
+    GUSTO_ERR_ARG = -1,       /* bad argument / unsupported size            */
+    GUSTO_ERR_HIP = -2,       /* HIP runtime error, see gusto_last_error()  */
+    GUSTO_ERR_STATE = -3,     /* call order (e.g. solve before set_problems) */
+    GUSTO_ERR_NO_DEVICE = -4  /* no usable GPU: there is no CPU fallback     */
+};
+
+/* SCPS.scp_status entries (Symbols in scp_gusto.jl:126-146) */
+enum { GUSTO_SCP_NA = 0, GUSTO_SCP_OK = 1, GUSTO_SCP_INACCURATE_MODEL = 2, GUSTO_SCP_VIOLATES_CONSTRAINTS = 3,
+       GUSTO_SCP_TRUST_REGION_VIOLATED = 4 };
+/* SCPS.solver_status entries (MOI termination codes accepted/rejected at scp_gusto.jl:106-111) */
+enum { GUSTO_SOLVER_NA = 0, GUSTO_SOLVER_OPTIMAL = 1, GUSTO_SOLVER_ALMOST = 2, GUSTO_SOLVER_FAILED = 3 };
+/* why the outer loop of a problem stopped */
+enum { GUSTO_STOP_MAXITER = 0, GUSTO_STOP_CONVERGED = 1, GUSTO_STOP_SUBPROBLEM_FAILED = 2, GUSTO_STOP_OMEGA_MAX = 3 };
+
+/* SCPParam + SCPParam_GuSTO (types.jl:65-73, scp_gusto.jl:4-24; per-model values e.g. freeflyer_se2.jl:22-39) */
+typedef struct {
+    double Delta0, omega0, omega_max, eps, rho0, rho1, beta_succ, beta_fail, gamma_fail;
+    double convergence_threshold;
+} gusto_scp_params;
+
+/* robot + model scalars (robot/freeflyer.jl:28-62, robot/astrobee3D.jl:15-33, dubins_car.jl:22-33) */
+typedef struct {
+    double mass, Jdiag[3], radius, clearance;
+    double hard_limit_vel, hard_limit_accel, hard_limit_omega, hard_limit_alpha;
+    double dubins_v, dubins_k, u_max, u_min;
+    double x_max[GUSTO_MAXN], x_min[GUSTO_MAXN];
+    int n_robot_comp;      /* convex robot components looped by trust_region_ratio_gusto */
+    double comp_off[2][3]; /* their offsets in the robot frame                            */
+} gusto_model_params;
+
+/* inner convex solver (stands in for the `kwarg...` forwarded to the optimizer, scp_gusto.jl:82-92) */
+typedef struct {
+    double tol, tol_acc, mu_floor, tr_tol;
+    int max_iter;
+} gusto_ipm_opts;
+
+typedef struct gusto_handle_s* gusto_handle;
+
+/* fills the per-model defaults: SCPParam(model, fft), SCPParam_GuSTO(model), robot constructors */
+int gusto_default_params(int model_id, gusto_scp_params* sp, gusto_model_params* mp);
+int gusto_default_ipm_opts(gusto_ipm_opts* o);
+int gusto_model_dims(int model_id, int* x_dim, int* u_dim);
+
+/* SCPProblem(TOP) for a batch (types.jl:256-259): allocates all device memory for up to batch_cap problems of
+ * N knots and hist_cap SCP iterations of history.  device = HIP device ordinal. */
+int gusto_create(gusto_handle* h, int model_id, int N, int batch_cap, int hist_cap, int device);
+int gusto_destroy(gusto_handle h);
+const char* gusto_last_error(gusto_handle h);
+
+int gusto_set_params(gusto_handle h, const gusto_scp_params* sp, const gusto_model_params* mp);
+int gusto_set_ipm_opts(gusto_handle h, const gusto_ipm_opts* o);
+/* Workspace(robot, env) (types.jl:12-24): keep-out set = keepout_zones then obstacle_set, as AABBs
+ * (min xyz, max xyz) followed by spheres (centre xyz, radius) */
+int gusto_set_env(gusto_handle h, int n_box, const double* box_min_max, int n_sph, const double* sph_c_r);
+/* run on a caller-owned hipStream_t (NULL = the handle's own stream) */
+int gusto_set_stream(gusto_handle h, void* hip_stream);
+
+/* ProblemDefinition + init trajectory + SCPSolution(SCPP, traj_init) for B problems (types.jl:32-39,233):
+ * goal_lo == goal_hi -> PointGoal row, finite lo < hi -> BoxGoal rows, +-Inf -> coordinate has no goal.
+ * X0/U0 == NULL -> init_traj_straightline (freeflyer_se2.jl:97-111).  Resets every history. */
+int gusto_set_problems(gusto_handle h, int B, const double* x_init, const double* goal_lo, const double* goal_hi,
+                       const double* tf, const double* X0, const double* U0);
+/* same, inputs already resident in HBM on the handle's device */
+int gusto_set_problems_dev(gusto_handle h, int B, const double* x_init_dev, const double* goal_lo_dev,
+                           const double* goal_hi_dev, const double* tf_dev, const double* X0_dev,
+                           const double* U0_dev);
+
+/* solve_gusto_jump!(SCPS, SCPP, solver, max_iter, force) for the whole batch (scp_gusto.jl:49-176).
+ * Synchronous.  Re-entrant: a second call resumes every problem (iter_cap = iterations + max_iter, :67). */
+int gusto_solve(gusto_handle h, int max_iter, int force);
+/* GPU time of the last gusto_solve, measured with HIP events on the stream the kernel ran on */
+int gusto_last_solve_ms(gusto_handle h, double* ms);
+
+/* SCPS.traj (X,U) -- TOS.traj aliases it (traj_opt.jl:58) */
+int gusto_get_traj(gusto_handle h, double* X, double* U);
+int gusto_get_traj_dev(gusto_handle h, const double** X_dev, const double** U_dev);
+/* SCPS.iterations / converged / successful per problem, plus stop reason and inner iteration count */
+int gusto_get_status(gusto_handle h, int* iterations, int* converged, int* successful, int* stop_reason,
+                     int* ipm_iters);
+/* SCPS.dual = -dual(init rows) (freeflyer_se2.jl:486-489): [B][n] */
+int gusto_get_dual(gusto_handle h, double* dual);
+
+/* SCPSolution / SCPParam_GuSTO history vectors (types.jl:150-173, scp_gusto.jl:15-19) as [B][hist_cap]
+ * arrays; n_hist[b] entries are valid in the per-iteration vectors, nJ[b] in J_true/J_full and n_rho[b] in
+ * rho (those get one extra leading entry per gusto_solve call, scp_gusto.jl:73-75).  Any pointer may be NULL. */
+typedef struct {
+    int hist_cap;
+    int *n_hist, *nJ, *n_rho;
+    double *J_true, *J_full, *convergence_measure, *Delta, *omega, *rho;
+    int *accept_solution, *scp_status, *solver_status, *trust_region_satisfied, *convex_ineq_satisfied, *ipm_iters;
+} gusto_history;
+int gusto_get_history(gusto_handle h, gusto_history* out);
+
+/* One convex subproblem per problem (what scp_gusto.jl:82-104 builds and solves in one trip), linearised at
+ * (Xp,Up)[b] with the given Delta/omega/obstacle_toggle_distance[b].  Used by the parity tests.
+ * Outputs: Xn,Un [B][N][.], obj [B] (JuMP.objective_value), status [B] (GUSTO_SOLVER_*), iters [B]. */
+int gusto_subproblem(gusto_handle h, int B, const double* Xp, const double* Up, const double* Delta,
+                     const double* omega, const double* toggle, double* Xn, double* Un, double* obj, int* status,
+                     int* iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
