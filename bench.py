@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- converged trajectories/sec of the batched GuSTO SCP hot path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over one batch: straight-line initialisation of every problem,
+then gusto_solve (the whole GuSTO loop: linearisation, convex subproblems, trust-region/penalty updates) until
+every problem of the batch has stopped.  Workload = BASELINE.json configs[1]: freeflyerSE2, batch 4096 random
+initial states, N = 50, fp64, per GPU (weak scaling: every rank solves its own 4096 problems; there is no
+data-path collective -- the problems are independent).  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_KNOTS = 50
+BATCH = 4096
+MAX_ITER = 30
+# algorithmic bytes (restated in DESIGN.md): one KKT solve of freeflyerSE2 N=50 streams
+# 8*N*(nz(nz+1)/2 + n*nz + 2(nz+n)) bytes; one linearisation 8*N*(2(n+m) + n + n^2) bytes
+BYTES_PER_KKT = 8 * N_KNOTS * (9 * 10 // 2 + 6 * 9 + 2 * (9 + 6))       # 51 600
+BYTES_PER_LINEARIZE = 8 * N_KNOTS * (2 * 9 + 6 + 36)                     # 24 000
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(problems, env, n_sample, threads):
+    """The oracle (a C port, NOT the Julia reference) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gusto_oracle as go
+    x0, glo, ghi, tf = problems.freeflyer_batch(n_sample)
+    go.lib()
+    t0 = time.perf_counter()
+    r = go.solve_batch(go.FREEFLYER_SE2, N_KNOTS, env, None, x0, glo, ghi, tf, MAX_ITER, threads)
+    dt = time.perf_counter() - t0
+    return {"value": float(r["converged"].sum() / dt), "unit": "converged trajectories/s", "cores": threads,
+            "kind": "port", "sample": f"first {n_sample} problems of the batch, oracle/libgusto_oracle.so "
+            f"(OpenMP over problems), {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import gusto_jl_amd as g
+    P = g.problems
+    env = P.freeflyer_env()
+    B = args.batch
+    # rank r solves problems [r*B, (r+1)*B): independent shards, no exchange step
+    x0, glo, ghi, tf = P.freeflyer_batch(B, first=rank * B)
+    solver = g.BatchSolver(g.FREEFLYER_SE2, N_KNOTS, B, hist_cap=MAX_ITER + 34, device=local_rank, boxes=env)
+    # inputs resident in HBM before the timed region
+    dev = torch.device("cuda", local_rank)
+    d_x0, d_glo, d_ghi, d_tf = (torch.from_numpy(a).to(dev) for a in (x0, glo, ghi, tf))
+    torch.cuda.synchronize()
+
+    import ctypes as C
+
+    def step():
+        rc = solver.L.gusto_set_problems_dev(solver.h, B, d_x0.data_ptr(), d_glo.data_ptr(), d_ghi.data_ptr(),
+                                             d_tf.data_ptr(), None, None)
+        if rc:
+            raise RuntimeError(f"gusto_set_problems_dev -> {rc}")
+        solver.B = B
+        solver.solve(MAX_ITER)
+        return solver.last_solve_ms()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        kernel_ms.append(step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = solver.status()
+    n_conv, n_succ = int(st["converged"].sum()), int(st["successful"].sum())
+    scp_iters, ipm_iters = int(st["iterations"].sum()), int(st["ipm_iters"].sum())
+    tot = torch.tensor([float(n_conv), float(n_succ), float(scp_iters), float(ipm_iters)], device=dev,
+                       dtype=torch.float64)
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tot = tot.cpu().numpy()
+    elapsed = float(tmax.item())
+
+    # PCIe-inclusive variant (host buffers in, trajectories out), reported but never the headline value
+    t1 = time.perf_counter()
+    solver.set_problems(x0, glo, ghi, tf)
+    solver.solve(MAX_ITER)
+    solver.traj()
+    pcie_s = time.perf_counter() - t1
+
+    if rank == 0:
+        value = tot[0] * args.steps / elapsed
+        avg_ms = float(np.mean(kernel_ms))
+        alg_bytes = BYTES_PER_KKT * ipm_iters + BYTES_PER_LINEARIZE * scp_iters      # this rank, one launch
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "converged trajectories/sec (batched SCP), freeflyerSE2 N=50",
+            "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "freeflyerSE2 batch=4096 random initial states per GPU, N=50, fp64 "
+                                   "(BASELINE.json configs[1])", "batch_per_gpu": B, "N": N_KNOTS,
+                       "max_iter": MAX_ITER, "sharding": "independent problems per rank, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "gusto::scp_kernel<0>", "avg_launch_ms": avg_ms,
+                         "kkt_solves_per_launch": ipm_iters, "scp_iters_per_launch": scp_iters},
+            "converged": int(tot[0]), "successful": int(tot[1]), "problems": B * world,
+            "mean_scp_iters": tot[2] / (B * world), "mean_ipm_iters": tot[3] / (B * world),
+            "pcie_inclusive_traj_per_s": n_conv / pcie_s,
+        }
+        if not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(P, env, min(args.cpu_sample, B), threads)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

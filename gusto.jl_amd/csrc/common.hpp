@@ -76,7 +76,7 @@ template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
 // LDS layout, offsets in doubles
 struct LdsLayout {
     int Xw, Uw, Xp, Up, dY, rd, pv, cv, rv, qrd, nu, nun, qu, dv;  // N-vectors
-    int sP, sPi, sPG, sT, sHh, sZ, sK, sD, sSinv, sGd, misc;
+    int sP, sPi, sPG, sT, sHh, sZ, sK, sD, sW, sV, sGd, misc;
     int total;
 };
 template <int MODEL> inline LdsLayout make_lds_layout(int N) {
@@ -89,7 +89,7 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     L.dY = take(N * n); L.rd = take(N * n); L.pv = take(N * n); L.cv = take(N * n); L.rv = take(N * n);
     L.qrd = take(N * n); L.nu = take(N * n); L.nun = take(N * n); L.qu = take(N * m); L.dv = take(N * m);
     L.sP = take(n * n); L.sPi = take(n * n); L.sPG = take(2 * n * NZ); L.sT = take(n * NZ); L.sHh = take(NZ * NZ);
-    L.sZ = take(NZ * n); L.sK = take(m * n); L.sD = take(m * n); L.sSinv = take(m * m); L.sGd = take(2 * n * n);
+    L.sZ = take(NZ * n); L.sK = take(m * n); L.sD = take(m * n); L.sW = take(m * n); L.sV = take(m * n); L.sGd = take(2 * n * n);
     L.misc = take(64);
     L.total = o;
     return L;
@@ -193,14 +193,14 @@ template <int n> GD bool inv_gauss_jordan(const double* A, double* Ainv) {
     return ok;
 }
 
-// SPD inverse through Cholesky (same arithmetic order as the reference restatement); S, Sinv row-major m x m
-template <int m> GD bool inv_spd(const double* S, double* Sinv) {
-    double L[m][m], Li[m][m];
+// Cholesky S = L L^T on register arrays: returns Li = L^-1 (lower, row-major m x m); false if not PD
+template <int m> GD bool chol_inv(const double* S, double* Li) {
+    double L[m][m];
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < m; i++)
 #pragma unroll
-        for (int j = 0; j < m; j++) { L[i][j] = 0; Li[i][j] = 0; }
+        for (int j = 0; j < m; j++) { L[i][j] = 0; Li[i * m + j] = 0; }
 #pragma unroll
     for (int j = 0; j < m; j++) {
         double d = S[j * m + j];
@@ -219,24 +219,15 @@ template <int m> GD bool inv_spd(const double* S, double* Sinv) {
     }
 #pragma unroll
     for (int j = 0; j < m; j++) {
-        Li[j][j] = 1.0 / L[j][j];
+        Li[j * m + j] = 1.0 / L[j][j];
 #pragma unroll
         for (int i = j + 1; i < m; i++) {
             double s = 0;
 #pragma unroll
-            for (int l = j; l < i; l++) s -= L[i][l] * Li[l][j];
-            Li[i][j] = s / L[i][i];
+            for (int l = j; l < i; l++) s -= L[i][l] * Li[l * m + j];
+            Li[i * m + j] = s / L[i][i];
         }
     }
-#pragma unroll
-    for (int i = 0; i < m; i++)
-#pragma unroll
-        for (int j = 0; j < m; j++) {
-            double s = 0;
-#pragma unroll
-            for (int l = (i > j ? i : j); l < m; l++) s += Li[l][i] * Li[l][j];
-            Sinv[i * m + j] = s;
-        }
     return ok;
 }
 

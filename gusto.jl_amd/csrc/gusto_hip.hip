@@ -8,50 +8,11 @@
 #include <string>
 #include <vector>
 
-#include "scp.hpp"
+#include "handle.hpp"
 
 using namespace gusto;
 
-struct gusto_handle_s {
-    int model = 0, n = 0, m = 0, N = 0, batch_cap = 0, hist_cap = 0, device = 0, B = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    gusto_scp_params sp{};
-    gusto_model_params mp{};
-    gusto_ipm_opts io{};
-    int n_box = 0, n_sph = 0;
-    double *d_box = nullptr, *d_sph = nullptr;
-    double *d_X = nullptr, *d_U = nullptr, *d_xinit = nullptr, *d_glo = nullptr, *d_ghi = nullptr, *d_tf = nullptr;
-    int* d_sti = nullptr;
-    double* d_std = nullptr;
-    double *d_Jt = nullptr, *d_Jf = nullptr, *d_conv = nullptr, *d_Delta = nullptr, *d_omega = nullptr, *d_rho = nullptr;
-    int *d_acc = nullptr, *d_scp = nullptr, *d_sol = nullptr, *d_tr = nullptr, *d_cvx = nullptr, *d_ipm = nullptr;
-    double* d_ws = nullptr;
-    size_t ws_doubles = 0;
-    double *d_subD = nullptr, *d_subW = nullptr, *d_subT = nullptr, *d_subX = nullptr, *d_subU = nullptr, *d_subObj = nullptr;
-    int *d_subSt = nullptr, *d_subIt = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double last_ms = 0.0;
-    bool have_problems = false;
-    std::string err;
-};
-
-static thread_local std::string g_err;
-
-#define HIPCHK(h, call)                                                                        \
-    do {                                                                                       \
-        hipError_t e_ = (call);                                                                \
-        if (e_ != hipSuccess) {                                                                \
-            std::string msg_ = std::string(#call) + ": " + hipGetErrorString(e_);             \
-            if (h) (h)->err = msg_;                                                            \
-            g_err = msg_;                                                                      \
-            return GUSTO_ERR_HIP;                                                              \
-        }                                                                                      \
-    } while (0)
-
-template <class Tp> static hipError_t dalloc(Tp** p, size_t count) {
-    return hipMalloc(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(Tp));
-}
+thread_local std::string g_err;
 
 extern "C" {
 
@@ -209,82 +170,24 @@ int gusto_set_env(gusto_handle h, int n_box, const double* box, int n_sph, const
 
 }  // extern "C"
 
-// ---- kernel dispatch ---------------------------------------------------------------------------------
-template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B) {
-    using T = MT<MODEL>;
-    memset(&P, 0, sizeof(P));
-    P.N = h->N; P.B = B; P.n_box = h->n_box; P.n_sph = h->n_sph;
-    P.n_obs = T::HAS_OBS ? h->n_box + h->n_sph : 0;
-    P.hist_cap = h->hist_cap;
-    P.sp = h->sp; P.mp = h->mp; P.io = h->io;
-    P.box = h->d_box; P.sph = h->d_sph; P.X = h->d_X; P.U = h->d_U;
-    P.x_init = h->d_xinit; P.goal_lo = h->d_glo; P.goal_hi = h->d_ghi; P.tf = h->d_tf;
-    P.sub_Delta = h->d_subD; P.sub_omega = h->d_subW; P.sub_toggle = h->d_subT; P.sub_X = h->d_subX; P.sub_U = h->d_subU;
-    P.sub_obj = h->d_subObj; P.sub_status = h->d_subSt; P.sub_iters = h->d_subIt;
-    P.st_i = h->d_sti; P.st_d = h->d_std;
-    P.J_true = h->d_Jt; P.J_full = h->d_Jf; P.conv = h->d_conv; P.Delta = h->d_Delta; P.omega = h->d_omega; P.rho = h->d_rho;
-    P.accept = h->d_acc; P.scp_status = h->d_scp; P.solver_status = h->d_sol; P.tr_sat = h->d_tr; P.cvx_sat = h->d_cvx;
-    P.ipm_it = h->d_ipm;
-    P.wl = make_ws_layout<MODEL>(h->N, P.n_obs);
-    P.ll = make_lds_layout<MODEL>(h->N);
-    const size_t need = P.wl.total * (size_t)h->batch_cap;
-    if (need > h->ws_doubles) {
-        if (h->d_ws) hipFree(h->d_ws);
-        h->d_ws = nullptr; h->ws_doubles = 0;
-        HIPCHK(h, dalloc(&h->d_ws, need));
-        h->ws_doubles = need;
+static int do_init(gusto_handle h, bool straight) {
+    switch (h->model) {
+    case 0: return gusto_launch_init_m0(h, straight);
+    case 1: return gusto_launch_init_m1(h, straight);
+    case 2: return gusto_launch_init_m2(h, straight);
+    case 3: return gusto_launch_init_m3(h, straight);
     }
-    P.ws = h->d_ws;
-    return GUSTO_OK;
+    return GUSTO_ERR_ARG;
 }
-
-template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_iter, int force) {
-    KParams P;
-    int rc = fill_params<MODEL>(h, P, h->B);
-    if (rc) return rc;
-    P.mode = mode; P.max_iter = max_iter; P.force = force;
-    const int NT = 64 * ((h->N + 63) / 64);
-    const size_t lds = (size_t)P.ll.total * sizeof(double);
-    if (lds > 160 * 1024) { h->err = "problem does not fit the 160 KiB LDS of a CU"; return GUSTO_ERR_ARG; }
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&scp_kernel<MODEL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(scp_kernel<MODEL>, dim3(h->B), dim3(NT), lds, h->stream, P);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    h->last_ms = ms;
-    return GUSTO_OK;
-}
-
-template <int MODEL> static int launch_init(gusto_handle h, bool straight) {
-    KParams P;
-    int rc = fill_params<MODEL>(h, P, h->B);
-    if (rc) return rc;
-    if (straight) {
-        const int tot = h->B * h->N;
-        hipLaunchKernelGGL(init_straightline_kernel<MODEL>, dim3((tot + 255) / 256), dim3(256), 0, h->stream, P);
-        HIPCHK(h, hipGetLastError());
+static int do_scp(gusto_handle h, int mode, int max_iter, int force) {
+    switch (h->model) {
+    case 0: return gusto_launch_scp_m0(h, mode, max_iter, force);
+    case 1: return gusto_launch_scp_m1(h, mode, max_iter, force);
+    case 2: return gusto_launch_scp_m2(h, mode, max_iter, force);
+    case 3: return gusto_launch_scp_m3(h, mode, max_iter, force);
     }
-    hipLaunchKernelGGL(reset_state_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, P);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return GUSTO_OK;
+    return GUSTO_ERR_ARG;
 }
-
-#define DISPATCH(h, expr)                                                                    \
-    switch ((h)->model) {                                                                    \
-    case GUSTO_FREEFLYER_SE2: { constexpr int MODEL = GUSTO_FREEFLYER_SE2; return expr; }    \
-    case GUSTO_DUBINS_CAR: { constexpr int MODEL = GUSTO_DUBINS_CAR; return expr; }          \
-    case GUSTO_ASTROBEE_SE3: { constexpr int MODEL = GUSTO_ASTROBEE_SE3; return expr; }      \
-    case GUSTO_ASTROBEE_SE3_MANIFOLD: { constexpr int MODEL = GUSTO_ASTROBEE_SE3_MANIFOLD; return expr; } \
-    default: return GUSTO_ERR_ARG;                                                           \
-    }
-
-static int do_init(gusto_handle h, bool straight) { DISPATCH(h, launch_init<MODEL>(h, straight)); }
-static int do_scp(gusto_handle h, int mode, int max_iter, int force) { DISPATCH(h, launch_scp<MODEL>(h, mode, max_iter, force)); }
 
 extern "C" {
 

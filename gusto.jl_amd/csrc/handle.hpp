@@ -1,0 +1,59 @@
+// handle.hpp -- the opaque gusto_handle and the per-model launch entry points (one translation unit per model).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "common.hpp"
+
+struct gusto_handle_s {
+    int model = 0, n = 0, m = 0, N = 0, batch_cap = 0, hist_cap = 0, device = 0, B = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    gusto_scp_params sp{};
+    gusto_model_params mp{};
+    gusto_ipm_opts io{};
+    int n_box = 0, n_sph = 0;
+    double *d_box = nullptr, *d_sph = nullptr;
+    double *d_X = nullptr, *d_U = nullptr, *d_xinit = nullptr, *d_glo = nullptr, *d_ghi = nullptr, *d_tf = nullptr;
+    int* d_sti = nullptr;
+    double* d_std = nullptr;
+    double *d_Jt = nullptr, *d_Jf = nullptr, *d_conv = nullptr, *d_Delta = nullptr, *d_omega = nullptr, *d_rho = nullptr;
+    int *d_acc = nullptr, *d_scp = nullptr, *d_sol = nullptr, *d_tr = nullptr, *d_cvx = nullptr, *d_ipm = nullptr;
+    double* d_ws = nullptr;
+    size_t ws_doubles = 0;
+    double *d_subD = nullptr, *d_subW = nullptr, *d_subT = nullptr, *d_subX = nullptr, *d_subU = nullptr, *d_subObj = nullptr;
+    int *d_subSt = nullptr, *d_subIt = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0;
+    bool have_problems = false;
+    std::string err;
+};
+
+extern thread_local std::string g_err;
+
+#define HIPCHK(h, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            std::string msg_ = std::string(#call) + ": " + hipGetErrorString(e_);             \
+            if (h) (h)->err = msg_;                                                            \
+            g_err = msg_;                                                                      \
+            return GUSTO_ERR_HIP;                                                              \
+        }                                                                                      \
+    } while (0)
+
+template <class Tp> static hipError_t dalloc(Tp** p, size_t count) {
+    return hipMalloc(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(Tp));
+}
+
+
+// defined in model_<id>.hip
+int gusto_launch_init_m0(gusto_handle h, bool straight);
+int gusto_launch_init_m1(gusto_handle h, bool straight);
+int gusto_launch_init_m2(gusto_handle h, bool straight);
+int gusto_launch_init_m3(gusto_handle h, bool straight);
+int gusto_launch_scp_m0(gusto_handle h, int mode, int max_iter, int force);
+int gusto_launch_scp_m1(gusto_handle h, int mode, int max_iter, int force);
+int gusto_launch_scp_m2(gusto_handle h, int mode, int max_iter, int force);
+int gusto_launch_scp_m3(gusto_handle h, int mode, int max_iter, int force);

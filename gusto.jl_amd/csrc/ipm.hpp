@@ -33,7 +33,7 @@ template <int MODEL> struct Blk {
     double dt;
     // LDS
     double *Xw, *Uw, *Xp, *Up, *dY, *rd, *pv, *cv, *rv, *qrd, *nu, *nun, *qu, *dv;
-    double *sP, *sPi, *sPG, *sT, *sHh, *sZ, *sK, *sD, *sSinv, *sGd, *misc;
+    double *sP, *sPi, *sPG, *sT, *sHh, *sZ, *sK, *sD, *sW, *sV, *sGd, *misc;
     // global workspace of this problem
     double *rowstate, *obs_nh, *obs_c0, *PG, *QQ, *Paft, *Piaft, *Kg, *Sinvg, *Dg, *Phicl;
     uint64_t* obs_mask;
@@ -48,7 +48,7 @@ template <int MODEL> struct Blk {
         pv = lds + L.pv; cv = lds + L.cv; rv = lds + L.rv; qrd = lds + L.qrd; nu = lds + L.nu; nun = lds + L.nun;
         qu = lds + L.qu; dv = lds + L.dv;
         sP = lds + L.sP; sPi = lds + L.sPi; sPG = lds + L.sPG; sT = lds + L.sT; sHh = lds + L.sHh; sZ = lds + L.sZ;
-        sK = lds + L.sK; sD = lds + L.sD; sSinv = lds + L.sSinv; sGd = lds + L.sGd; misc = lds + L.misc;
+        sK = lds + L.sK; sD = lds + L.sD; sW = lds + L.sW; sV = lds + L.sV; sGd = lds + L.sGd; misc = lds + L.misc;
         double* w = P.ws + (size_t)b * P.wl.total;
         const WsLayout& W = P.wl;
         rowstate = w + W.rowstate; obs_nh = w + W.obs_nh; obs_c0 = w + W.obs_c0;
@@ -204,45 +204,59 @@ template <int MODEL> GD void factor_sweep(Blk<MODEL>& K, double* fail) {
             }
         }
         __syncthreads();
-        // phase 3: S^-1, K = S^-1 Hyu^T, D = S^-1 Zu
-        if (tid < m * n + m * ng || tid < m * m) {
-            double S[m * m], Si[m * m];
+        // phase 3: block Cholesky of [S Hyu^T; Hyu Hyy]: L = chol(S), W = L^-1 Hyu^T, V = L^-1 Zu,
+        // K = L^-T W, D = L^-T V.  One thread per column; the m x m factor is recomputed by each of them.
+        if (tid < n + ng || tid < m * m) {
+            double S[m * m], Li[m * m];
 #pragma unroll
             for (int i = 0; i < m; i++)
 #pragma unroll
                 for (int j = 0; j < m; j++) S[i * m + j] = K.sHh[(n + i) * NZ + n + j];
-            if (!inv_spd<m>(S, Si)) *fail = 1.0;
-            for (int e = tid; e < m * n + m * ng; e += NT) {
-                if (e < m * n) {
-                    const int i = e / n, j = e % n;
+            if (!chol_inv<m>(S, Li)) *fail = 1.0;
+            for (int c = tid; c < n + ng; c += NT) {
+                double col[m], w[m], kk[m];
+                const bool isK = c < n;
+                const int g = c - n;
+#pragma unroll
+                for (int l = 0; l < m; l++) col[l] = isK ? K.sHh[c * NZ + n + l] : K.sZ[(n + l) * ng + g];
+#pragma unroll
+                for (int i = 0; i < m; i++) {
                     double s = 0;
 #pragma unroll
-                    for (int l = 0; l < m; l++) s += Si[i * m + l] * K.sHh[j * NZ + n + l];
-                    K.sK[e] = s;
-                    K.Kg[(size_t)k * m * n + e] = s;
-                } else {
-                    const int e2 = e - m * n, i = e2 / ng, g = e2 % ng;
+                    for (int l = 0; l <= i; l++) s += Li[i * m + l] * col[l];
+                    w[i] = s;
+                }
+#pragma unroll
+                for (int i = 0; i < m; i++) {
                     double s = 0;
 #pragma unroll
-                    for (int l = 0; l < m; l++) s += Si[i * m + l] * K.sZ[(n + l) * ng + g];
-                    K.sD[e2] = s;
-                    K.Dg[(size_t)k * m * n + e2] = s;
+                    for (int l = i; l < m; l++) s += Li[l * m + i] * w[l];
+                    kk[i] = s;
+                }
+#pragma unroll
+                for (int i = 0; i < m; i++) {
+                    if (isK) { K.sW[i * n + c] = w[i]; K.sK[i * n + c] = kk[i]; K.Kg[(size_t)k * m * n + i * n + c] = kk[i]; }
+                    else { K.sV[i * ng + g] = w[i]; K.sD[i * ng + g] = kk[i]; K.Dg[(size_t)k * m * n + i * ng + g] = kk[i]; }
                 }
             }
-            for (int e = tid; e < m * m; e += NT) K.Sinvg[(size_t)k * m * m + e] = Si[e];
+            for (int e = tid; e < m * m; e += NT) {  // S^-1 = L^-T L^-1 (feed-forward only)
+                const int i = e / m, j = e % m;
+                double s = 0;
+#pragma unroll
+                for (int l = 0; l < m; l++) if (l >= i && l >= j) s += Li[l * m + i] * Li[l * m + j];
+                K.Sinvg[(size_t)k * m * m + e] = s;
+            }
         }
         __syncthreads();
-        // phase 4: P' = Hyy - Hyu K (symmetrised), Pi' = Zy - Hyu D, Phicl = Phi - Gam K, Gd += Zu^T D
+        // phase 4: P' = Hyy - W^T W, Pi' = Zy - W^T V, Phicl = Phi - Gam K, Gd += V^T V.  The Schur complements are
+        // never formed through an explicit S^-1: with barrier weights ~1/mu in Hyy that loses every digit.
         for (int e = tid; e < 2 * n * n + n * ng + ng * ng; e += NT) {
             if (e < n * n) {
                 const int i = e / n, j = e % n;
-                double a = K.sHh[i * NZ + j], c = K.sHh[j * NZ + i];
+                double a = K.sHh[i * NZ + j];
 #pragma unroll
-                for (int l = 0; l < m; l++) {
-                    a -= K.sHh[i * NZ + n + l] * K.sK[l * n + j];
-                    c -= K.sHh[j * NZ + n + l] * K.sK[l * n + i];
-                }
-                K.sP[e] = 0.5 * (a + c);
+                for (int l = 0; l < m; l++) a -= K.sW[l * n + i] * K.sW[l * n + j];
+                K.sP[e] = a;
             } else if (e < 2 * n * n) {
                 const int e2 = e - n * n, i = e2 / n, j = e2 % n;
                 double s = PGs[i * NZ + j];
@@ -253,13 +267,13 @@ template <int MODEL> GD void factor_sweep(Blk<MODEL>& K, double* fail) {
                 const int e2 = e - 2 * n * n, i = e2 / ng, g = e2 % ng;
                 double s = K.sZ[i * ng + g];
 #pragma unroll
-                for (int l = 0; l < m; l++) s -= K.sHh[i * NZ + n + l] * K.sD[l * ng + g];
+                for (int l = 0; l < m; l++) s -= K.sW[l * n + i] * K.sV[l * ng + g];
                 K.sPi[e2] = s;
             } else {
                 const int e2 = e - 2 * n * n - n * ng, g = e2 / ng, h = e2 % ng;
                 double s = 0;
 #pragma unroll
-                for (int l = 0; l < m; l++) s += K.sZ[(n + l) * ng + g] * K.sD[l * ng + h];
+                for (int l = 0; l < m; l++) s += K.sV[l * ng + g] * K.sV[l * ng + h];
                 K.sGd[e2] += s;
             }
         }

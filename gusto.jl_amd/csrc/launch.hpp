@@ -1,0 +1,74 @@
+// launch.hpp -- kernel launch templates, instantiated once per model in model_<id>.hip
+#pragma once
+#include <cstring>
+
+#include "handle.hpp"
+#include "scp.hpp"
+
+using namespace gusto;
+
+// ---- kernel dispatch ---------------------------------------------------------------------------------
+template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B) {
+    using T = MT<MODEL>;
+    memset(&P, 0, sizeof(P));
+    P.N = h->N; P.B = B; P.n_box = h->n_box; P.n_sph = h->n_sph;
+    P.n_obs = T::HAS_OBS ? h->n_box + h->n_sph : 0;
+    P.hist_cap = h->hist_cap;
+    P.sp = h->sp; P.mp = h->mp; P.io = h->io;
+    P.box = h->d_box; P.sph = h->d_sph; P.X = h->d_X; P.U = h->d_U;
+    P.x_init = h->d_xinit; P.goal_lo = h->d_glo; P.goal_hi = h->d_ghi; P.tf = h->d_tf;
+    P.sub_Delta = h->d_subD; P.sub_omega = h->d_subW; P.sub_toggle = h->d_subT; P.sub_X = h->d_subX; P.sub_U = h->d_subU;
+    P.sub_obj = h->d_subObj; P.sub_status = h->d_subSt; P.sub_iters = h->d_subIt;
+    P.st_i = h->d_sti; P.st_d = h->d_std;
+    P.J_true = h->d_Jt; P.J_full = h->d_Jf; P.conv = h->d_conv; P.Delta = h->d_Delta; P.omega = h->d_omega; P.rho = h->d_rho;
+    P.accept = h->d_acc; P.scp_status = h->d_scp; P.solver_status = h->d_sol; P.tr_sat = h->d_tr; P.cvx_sat = h->d_cvx;
+    P.ipm_it = h->d_ipm;
+    P.wl = make_ws_layout<MODEL>(h->N, P.n_obs);
+    P.ll = make_lds_layout<MODEL>(h->N);
+    const size_t need = P.wl.total * (size_t)h->batch_cap;
+    if (need > h->ws_doubles) {
+        if (h->d_ws) hipFree(h->d_ws);
+        h->d_ws = nullptr; h->ws_doubles = 0;
+        HIPCHK(h, dalloc(&h->d_ws, need));
+        h->ws_doubles = need;
+    }
+    P.ws = h->d_ws;
+    return GUSTO_OK;
+}
+
+template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_iter, int force) {
+    KParams P;
+    int rc = fill_params<MODEL>(h, P, h->B);
+    if (rc) return rc;
+    P.mode = mode; P.max_iter = max_iter; P.force = force;
+    const int NT = 64 * ((h->N + 63) / 64);
+    const size_t lds = (size_t)P.ll.total * sizeof(double);
+    if (lds > 160 * 1024) { h->err = "problem does not fit the 160 KiB LDS of a CU"; return GUSTO_ERR_ARG; }
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&scp_kernel<MODEL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(scp_kernel<MODEL>, dim3(h->B), dim3(NT), lds, h->stream, P);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_ms = ms;
+    return GUSTO_OK;
+}
+
+template <int MODEL> static int launch_init(gusto_handle h, bool straight) {
+    KParams P;
+    int rc = fill_params<MODEL>(h, P, h->B);
+    if (rc) return rc;
+    if (straight) {
+        const int tot = h->B * h->N;
+        hipLaunchKernelGGL(init_straightline_kernel<MODEL>, dim3((tot + 255) / 256), dim3(256), 0, h->stream, P);
+        HIPCHK(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(reset_state_kernel<MODEL>, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, P);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GUSTO_OK;
+}
+

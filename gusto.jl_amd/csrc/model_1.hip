@@ -1,0 +1,5 @@
+// model_1.hip -- instantiates the SCP kernels for gusto_model_id 1
+#include "launch.hpp"
+
+int gusto_launch_init_m1(gusto_handle h, bool straight) { return launch_init<1>(h, straight); }
+int gusto_launch_scp_m1(gusto_handle h, int mode, int max_iter, int force) { return launch_scp<1>(h, mode, max_iter, force); }

@@ -229,7 +229,7 @@ template <int MODEL> __global__ void init_straightline_kernel(const KParams P) {
 }
 
 // SCPSolution(SCPP, traj_init) + SCPParam_GuSTO ctor (types.jl:233, scp_gusto.jl:21-23)
-__global__ void reset_state_kernel(const KParams P) {
+template <int MODEL> __global__ void reset_state_kernel(const KParams P) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
     int* sti = P.st_i + (size_t)b * ST_NI;

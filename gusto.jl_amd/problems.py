@@ -96,3 +96,77 @@ def dubins_batch(B, first=0):
         X[i] = [-3 + 6 * next(g), -3 + 6 * next(g), -np.pi + 2 * np.pi * next(g)]
     goal = np.zeros((B, 3))
     return X, goal.copy(), goal.copy(), np.full(B, 10.0)
+
+
+# ---- ISS corner (src/environment/iss_corner.jl + iss_corner.mat, converted by tools/convert_iss_corner.py) ----
+def _iss():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "iss_corner.npz"))
+
+
+def iss_corner_env(with_obstacles=True):
+    """ISSCorner() keep-out AABBs (26), then add_obstacles! (4 boxes, 2 spheres): returns (boxes, spheres)."""
+    d = _iss()
+    if with_obstacles:
+        return np.vstack([d["keepout"], d["rectangles"]]), d["spheres"].copy()
+    return d["keepout"].copy(), np.zeros((0, 4))
+
+
+ASTROBEE_RADIUS = np.sqrt(3.0) * 0.5 * 0.305
+
+
+def _sdf_box3(p, lo, hi):
+    e = np.maximum(np.maximum(lo - p, 0.0), p - hi)
+    if (e > 0).any():
+        return float(np.linalg.norm(e))
+    return -float(min((p - lo).min(), (hi - p).min()))
+
+
+def _astrobee_free_points(count, seed, with_obstacles=True, margin=0.1):
+    """Points uniform in keep-in boxes #4,#5,#8 (the corner module) shrunk by r+margin, rejected if the sphere
+    touches any keep-out component."""
+    d = _iss()
+    boxes, sph = iss_corner_env(with_obstacles)
+    zones = d["keepin"][[3, 4, 7]]
+    g = splitmix64(seed)
+    pts = []
+    while len(pts) < count:
+        z = zones[int(next(g) * 3) % 3]
+        lo, hi = z[:3] + ASTROBEE_RADIUS + margin, z[3:] - ASTROBEE_RADIUS - margin
+        p = lo + (hi - lo) * np.array([next(g), next(g), next(g)])
+        ok = all(_sdf_box3(p, b[:3], b[3:]) - ASTROBEE_RADIUS > margin for b in boxes)
+        ok = ok and all(np.linalg.norm(p - s[:3]) - s[3] - ASTROBEE_RADIUS > margin for s in sph)
+        if ok:
+            pts.append(p)
+    return np.array(pts)
+
+
+def astrobee_se3_batch(B, first=0, tf=70.0):
+    """Config 4: start/goal positions in the corner module, MRP p=0 start, goal MRP uniform |p| <= 0.4, rest to rest."""
+    x0, xg = np.zeros((B, 12)), np.zeros((B, 12))
+    for i in range(B):
+        pts = _astrobee_free_points(2, 0x9E3779B97F4A7C15 + first + i)
+        x0[i, :3], xg[i, :3] = pts[0], pts[1]
+        g = splitmix64(0xD1B54A32D192ED03 + first + i)
+        while True:
+            p = 0.8 * np.array([next(g), next(g), next(g)]) - 0.4
+            if np.linalg.norm(p) <= 0.4:
+                break
+        xg[i, 6:9] = p
+    return x0, xg.copy(), xg.copy(), np.full(B, tf)
+
+
+def astrobee_manifold_batch(B, first=0, tf=40.0, eps=1e-4):
+    """Config 5: q_init = (1,0,0,0), q_goal = normalise((1,a,b,c)), a,b,c ~ U(-0.5,0.5); point goals on r,v,w and
+    a +-eps box on q as in examples/astrobeeSE3manifold.ipynb cell 1."""
+    x0, glo, ghi = np.zeros((B, 13)), np.zeros((B, 13)), np.zeros((B, 13))
+    for i in range(B):
+        pts = _astrobee_free_points(2, 0x9E3779B97F4A7C15 + first + i)
+        x0[i, :3] = pts[0]
+        x0[i, 6] = 1.0
+        g = splitmix64(0xD1B54A32D192ED03 + first + i)
+        q = np.array([1.0, next(g) - 0.5, next(g) - 0.5, next(g) - 0.5])
+        q /= np.linalg.norm(q)
+        glo[i, :3] = ghi[i, :3] = pts[1]
+        glo[i, 6:10], ghi[i, 6:10] = q - eps, q + eps
+    return x0, glo, ghi, np.full(B, tf)

@@ -131,9 +131,9 @@ static int inv_gj(double* Ainv, const double* A, int n) {
         for (int j = 0; j < n; j++) Ainv[i * n + j] = W[i * w + n + j];
     return 0;
 }
-/* SPD inverse through Cholesky; returns 0 ok, -1 not positive definite */
-static int inv_spd(double* Sinv, const double* S, int n) {
-    double L[NX * NX], Li[NX * NX];
+/* Cholesky S = L L^T; returns Li = L^{-1} (lower) and Sinv = Li^T Li; 0 ok, -1 not positive definite */
+static int chol_inv(double* Sinv, double* Li, const double* S, int n) {
+    double L[NX * NX];
     memset(L, 0, sizeof(L));
     for (int j = 0; j < n; j++) {
         double d = S[j * n + j];
@@ -147,8 +147,7 @@ static int inv_spd(double* Sinv, const double* S, int n) {
             L[i * n + j] = s / d;
         }
     }
-    /* Li = L^{-1} (lower) */
-    memset(Li, 0, sizeof(Li));
+    for (int i = 0; i < n * n; i++) Li[i] = 0;
     for (int j = 0; j < n; j++) {
         Li[j * n + j] = 1.0 / L[j * n + j];
         for (int i = j + 1; i < n; i++) {
@@ -165,6 +164,10 @@ static int inv_spd(double* Sinv, const double* S, int n) {
             Sinv[i * n + j] = s;
         }
     return 0;
+}
+static int inv_spd(double* Sinv, const double* S, int n) {
+    double Li[NX * NX];
+    return chol_inv(Sinv, Li, S, n);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -626,46 +629,62 @@ static int riccati_factor(go_problem* p, int ng, const int* gidx) {
         for (int i = 0; i < m; i++)
             for (int j = 0; j < m; j++) S[i * m + j] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]);
         double* Sinv = p->Sinv + k * m * m;
-        if (inv_spd(Sinv, S, m)) return -1;
-        /* K = Sinv Hyu^T (m x n), D = Sinv Zu (m x ng) */
+        double Li[NU * NU], Wm[NU * NX], Vm[NU * NX];
+        if (chol_inv(Sinv, Li, S, m)) {
+            if (getenv("GO_DEBUG")) fprintf(stderr, "gusto_oracle: S not PD at k=%d\n", k);
+            return -1;
+        }
+        /* block Cholesky of [S Hyu^T; Hyu Hyy]: W = L^-1 Hyu^T, V = L^-1 Zu; K = L^-T W, D = L^-T V.
+         * The Schur complements are formed as Hyy - W^T W (never through an explicit S^-1): with barrier
+         * weights ~1/mu in Hyy the explicit form loses all digits. */
+        for (int i = 0; i < m; i++) {
+            for (int j = 0; j < n; j++) {
+                double s = 0;
+                for (int l = 0; l <= i; l++) s += Li[i * m + l] * Hh[j * nz + n + l];
+                Wm[i * n + j] = s;
+            }
+            for (int j = 0; j < ng; j++) {
+                double s = 0;
+                for (int l = 0; l <= i; l++) s += Li[i * m + l] * Z[(n + l) * ng + j];
+                Vm[i * ng + j] = s;
+            }
+        }
         double* K = p->Ks + k * m * n, *D = p->Ds + k * m * ng;
         for (int i = 0; i < m; i++) {
             for (int j = 0; j < n; j++) {
                 double s = 0;
-                for (int l = 0; l < m; l++) s += Sinv[i * m + l] * Hh[j * nz + n + l];
+                for (int l = i; l < m; l++) s += Li[l * m + i] * Wm[l * n + j];
                 K[i * n + j] = s;
             }
             for (int j = 0; j < ng; j++) {
                 double s = 0;
-                for (int l = 0; l < m; l++) s += Sinv[i * m + l] * Z[(n + l) * ng + j];
+                for (int l = i; l < m; l++) s += Li[l * m + i] * Vm[l * ng + j];
                 D[i * ng + j] = s;
             }
         }
-        /* Gd += Zu^T D ; P' = Hyy - Hyu K ; Pi' = Zy - Hyu D */
+        /* Gd += V^T V ; P' = Hyy - W^T W ; Pi' = Zy - W^T V */
         for (int i = 0; i < ng; i++)
             for (int j = 0; j < ng; j++) {
                 double s = 0;
-                for (int l = 0; l < m; l++) s += Z[(n + l) * ng + i] * D[l * ng + j];
+                for (int l = 0; l < m; l++) s += Vm[l * ng + i] * Vm[l * ng + j];
                 p->Gd[i * ng + j] += s;
             }
         for (int i = 0; i < n; i++) {
             for (int j = 0; j < n; j++) {
-                double s = Hh[i * nz + j];
-                for (int l = 0; l < m; l++) s -= Hh[i * nz + n + l] * K[l * n + j];
-                tmp[i * n + j] = s;
+                double s = 0.5 * (Hh[i * nz + j] + Hh[j * nz + i]);
+                for (int l = 0; l < m; l++) s -= Wm[l * n + i] * Wm[l * n + j];
+                P[i * n + j] = s;
             }
             for (int j = 0; j < ng; j++) {
                 double s = Z[i * ng + j];
-                for (int l = 0; l < m; l++) s -= Hh[i * nz + n + l] * D[l * ng + j];
+                for (int l = 0; l < m; l++) s -= Wm[l * n + i] * Vm[l * ng + j];
                 Pi[i * ng + j] = s;
             }
         }
-        for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) P[i * n + j] = 0.5 * (tmp[i * n + j] + tmp[j * n + i]);
     }
     if (ng > 0) {
         double Gi[NX * NX];
-        if (inv_spd(Gi, p->Gd, ng)) return -2;
+        if (inv_spd(Gi, p->Gd, ng)) { if (getenv("GO_DEBUG")) { fprintf(stderr,"Gd not PD:"); for(int i=0;i<ng*ng;i++) fprintf(stderr," %g",p->Gd[i]); fprintf(stderr,"\n"); } return -2; }
         memcpy(p->Gd, Gi, sizeof(double) * ng * ng); /* Gd now holds its inverse */
     }
     return 0;
