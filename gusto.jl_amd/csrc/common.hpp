@@ -73,25 +73,25 @@ template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     return L;
 }
 
-// LDS layout, offsets in doubles
+// LDS layout, offsets in doubles.  The cooperative working set of the sweeps sits first at compile-time offsets
+// (so its addresses are instruction immediates, not SGPRs); the per-knot vectors follow, `vec(i)` = i-th vector.
+template <int MODEL> struct LdsC {
+    using T = MT<MODEL>;
+    static constexpr int n = T::n, m = T::m, NZ = n + m;
+    static constexpr int sP = 0, sPi = sP + n * n, sPG = sPi + n * n, sT = sPG + 2 * n * NZ, sHh = sT + n * NZ,
+                         sZ = sHh + NZ * NZ, sK = sZ + NZ * n, sD = sK + m * n, sW = sD + m * n, sV = sW + m * n,
+                         sGd = sV + m * n, misc = sGd + 2 * n * n, lut = misc + 64,
+                         vecs = lut + (NZ * (NZ + 1) / 2 + 1) / 2 + 1;
+    // per-knot vectors: n-vectors first (Xw Xp dY rd pv cv rv qrd nu nun dXs), then m-vectors (Uw Up qu dv dUs)
+    static constexpr int NVN = 11, NVM = 5;
+};
 struct LdsLayout {
-    int Xw, Uw, Xp, Up, dY, rd, pv, cv, rv, qrd, nu, nun, qu, dv;  // N-vectors
-    int sP, sPi, sPG, sT, sHh, sZ, sK, sD, sW, sV, sGd, misc;
     int total;
 };
 template <int MODEL> inline LdsLayout make_lds_layout(int N) {
-    using T = MT<MODEL>;
-    constexpr int n = T::n, m = T::m, NZ = n + m;
+    using C = LdsC<MODEL>;
     LdsLayout L;
-    int o = 0;
-    auto take = [&](int c) { int r = o; o += c; return r; };
-    L.Xw = take(N * n); L.Uw = take(N * m); L.Xp = take(N * n); L.Up = take(N * m);
-    L.dY = take(N * n); L.rd = take(N * n); L.pv = take(N * n); L.cv = take(N * n); L.rv = take(N * n);
-    L.qrd = take(N * n); L.nu = take(N * n); L.nun = take(N * n); L.qu = take(N * m); L.dv = take(N * m);
-    L.sP = take(n * n); L.sPi = take(n * n); L.sPG = take(2 * n * NZ); L.sT = take(n * NZ); L.sHh = take(NZ * NZ);
-    L.sZ = take(NZ * n); L.sK = take(m * n); L.sD = take(m * n); L.sW = take(m * n); L.sV = take(m * n); L.sGd = take(2 * n * n);
-    L.misc = take(64);
-    L.total = o;
+    L.total = C::vecs + N * (C::NVN * C::n + C::NVM * C::m);
     return L;
 }
 
@@ -116,11 +116,27 @@ struct KParams {
     double *J_true, *J_full, *conv, *Delta, *omega, *rho;                       // [B][hist_cap]
     int *accept, *scp_status, *solver_status, *tr_sat, *cvx_sat, *ipm_it;      // [B][hist_cap]
     double* ws;
+    long long* prof;  // [B][PROF_N] phase cycle counters (GUSTO_PROFILE builds only)
     WsLayout wl;
     LdsLayout ll;
 };
 constexpr int ST_ITER = 0, ST_CONV = 1, ST_SUCC = 2, ST_STOP = 3, ST_IPM = 4, ST_NHIST = 5, ST_NJ = 6, ST_NRHO = 7, ST_NI = 8;
 constexpr int SD_TOGGLE = 0, SD_DUAL = 2, SD_ND = 2 + GUSTO_MAXN;
+
+// ---- optional phase timers (compile with -DGUSTO_PROFILE) ---------------------------------------------
+constexpr int PROF_N = 16;
+enum { PF_RESID = 0, PF_BUILD, PF_FACTOR, PF_POSTF, PF_RHS, PF_BACK, PF_MID, PF_FWD, PF_STEP, PF_UPDATE, PF_LIN, PF_SCP, PF_INIT };
+struct Prof {
+#ifdef GUSTO_PROFILE
+    long long t0, acc[PROF_N];
+    GD Prof() { for (int i = 0; i < PROF_N; i++) acc[i] = 0; t0 = clock64(); }
+    GD void tick(int id) { const long long t = clock64(); acc[id] += t - t0; t0 = t; }
+    GD void flush(long long* out) { if (out && threadIdx.x == 0) for (int i = 0; i < PROF_N; i++) out[(size_t)blockIdx.x * PROF_N + i] = acc[i]; }
+#else
+    GD void tick(int) {}
+    GD void flush(long long*) {}
+#endif
+};
 
 // ---- block-wide reductions (every thread of the block must call) -----------------------------------
 struct OpMax { GD double operator()(double a, double b) const { return fmax(a, b); } };
@@ -193,9 +209,10 @@ template <int n> GD bool inv_gauss_jordan(const double* A, double* Ainv) {
     return ok;
 }
 
-// Cholesky S = L L^T on register arrays: returns Li = L^-1 (lower, row-major m x m); false if not PD
+// Cholesky S = L L^T on register arrays: returns Li = L^-1 (lower, row-major m x m); false if not PD.
+// One sqrt and one division per column (r = 1/sqrt(d); L_jj = d r).
 template <int m> GD bool chol_inv(const double* S, double* Li) {
-    double L[m][m];
+    double L[m][m], r[m];
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < m; i++)
@@ -207,25 +224,25 @@ template <int m> GD bool chol_inv(const double* S, double* Li) {
 #pragma unroll
         for (int l = 0; l < j; l++) d -= L[j][l] * L[j][l];
         if (!(d > 0.0)) ok = false;
-        d = sqrt(d);
-        L[j][j] = d;
+        r[j] = 1.0 / sqrt(d);
+        L[j][j] = d * r[j];
 #pragma unroll
         for (int i = j + 1; i < m; i++) {
             double s = S[i * m + j];
 #pragma unroll
             for (int l = 0; l < j; l++) s -= L[i][l] * L[j][l];
-            L[i][j] = s / d;
+            L[i][j] = s * r[j];
         }
     }
 #pragma unroll
     for (int j = 0; j < m; j++) {
-        Li[j * m + j] = 1.0 / L[j][j];
+        Li[j * m + j] = r[j];
 #pragma unroll
         for (int i = j + 1; i < m; i++) {
             double s = 0;
 #pragma unroll
             for (int l = j; l < i; l++) s -= L[i][l] * Li[l * m + j];
-            Li[i * m + j] = s / L[i][i];
+            Li[i * m + j] = s * r[i];
         }
     }
     return ok;

@@ -127,7 +127,7 @@ int gusto_destroy(gusto_handle h) {
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_X, h->d_U, h->d_xinit, h->d_glo, h->d_ghi, h->d_tf, h->d_sti, h->d_std, h->d_Jt, h->d_Jf, h->d_conv,
                     h->d_Delta, h->d_omega, h->d_rho, h->d_acc, h->d_scp, h->d_sol, h->d_tr, h->d_cvx, h->d_ipm, h->d_ws,
-                    h->d_subD, h->d_subW, h->d_subT, h->d_subX, h->d_subU, h->d_subObj, h->d_subSt, h->d_subIt, h->d_box, h->d_sph};
+                    h->d_prof, h->d_subD, h->d_subW, h->d_subT, h->d_subX, h->d_subU, h->d_subObj, h->d_subSt, h->d_subIt, h->d_box, h->d_sph};
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -228,6 +228,13 @@ int gusto_solve(gusto_handle h, int max_iter, int force) {
     if (!h->have_problems) { h->err = "gusto_solve: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     return do_scp(h, 0, max_iter, force ? 1 : 0);
+}
+
+// development hook (GUSTO_PROFILE builds): per-problem phase cycle counters [B][16]; not part of gusto_hip.h
+int gusto_dev_get_prof(gusto_handle h, long long* out) {
+    if (!h || !h->d_prof) return GUSTO_ERR_STATE;
+    HIPCHK(h, hipMemcpy(out, h->d_prof, sizeof(long long) * (size_t)h->B * PROF_N, hipMemcpyDeviceToHost));
+    return GUSTO_OK;
 }
 
 int gusto_last_solve_ms(gusto_handle h, double* ms) {

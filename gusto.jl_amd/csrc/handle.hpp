@@ -21,6 +21,7 @@ struct gusto_handle_s {
     double *d_Jt = nullptr, *d_Jf = nullptr, *d_conv = nullptr, *d_Delta = nullptr, *d_omega = nullptr, *d_rho = nullptr;
     int *d_acc = nullptr, *d_scp = nullptr, *d_sol = nullptr, *d_tr = nullptr, *d_cvx = nullptr, *d_ipm = nullptr;
     double* d_ws = nullptr;
+    long long* d_prof = nullptr;
     size_t ws_doubles = 0;
     double *d_subD = nullptr, *d_subW = nullptr, *d_subT = nullptr, *d_subX = nullptr, *d_subU = nullptr, *d_subObj = nullptr;
     int *d_subSt = nullptr, *d_subIt = nullptr;

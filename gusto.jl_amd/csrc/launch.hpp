@@ -33,6 +33,10 @@ template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B) {
         h->ws_doubles = need;
     }
     P.ws = h->d_ws;
+#ifdef GUSTO_PROFILE
+    if (!h->d_prof) HIPCHK(h, dalloc(&h->d_prof, (size_t)h->batch_cap * PROF_N));
+#endif
+    P.prof = h->d_prof;
     return GUSTO_OK;
 }
 
@@ -44,10 +48,11 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     const int NT = 64 * ((h->N + 63) / 64);
     const size_t lds = (size_t)P.ll.total * sizeof(double);
     if (lds > 160 * 1024) { h->err = "problem does not fit the 160 KiB LDS of a CU"; return GUSTO_ERR_ARG; }
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&scp_kernel<MODEL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // a problem with N <= 64 knots runs as one wave per workgroup (no barriers at all)
+    auto kern = (NT == 64) ? &scp_kernel<MODEL, true> : &scp_kernel<MODEL, false>;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(scp_kernel<MODEL>, dim3(h->B), dim3(NT), lds, h->stream, P);
+    hipLaunchKernelGGL(kern, dim3(h->B), dim3(NT), lds, h->stream, P);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

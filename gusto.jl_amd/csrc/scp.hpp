@@ -7,8 +7,8 @@
 namespace gusto {
 
 // cost_true: trapezoid control effort (freeflyer_se2.jl:66-76)
-template <int MODEL> GD double cost_true(Blk<MODEL>& K, const double* U) {
-    constexpr int m = Blk<MODEL>::m;
+template <class BLK> GD double cost_true(BLK& K, const double* U) {
+    constexpr int m = BLK::m;
     const int k = K.tid;
     double l = 0;
     if (k >= 1 && k < K.N) {
@@ -19,7 +19,7 @@ template <int MODEL> GD double cost_true(Blk<MODEL>& K, const double* U) {
 }
 
 // trust_region_ratio_gusto (freeflyer_se2.jl:392-427 etc.); the "linearised" dynamics deliberately lack B*du
-template <int MODEL> GD double trust_region_ratio(Blk<MODEL>& K, const double* X, const double* U, const double* Xp, const double* Up) {
+template <int MODEL, class BLK> GD double trust_region_ratio(BLK& K, const double* X, const double* U, const double* Xp, const double* Up) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m;
     const int k = K.tid, N = K.N;
@@ -65,29 +65,32 @@ template <int MODEL> GD double trust_region_ratio(Blk<MODEL>& K, const double* X
     return num / den;
 }
 
-template <int MODEL> GD void store_traj(Blk<MODEL>& K, const double* Xs, const double* Us, double* Xg, double* Ug) {
-    constexpr int n = Blk<MODEL>::n, m = Blk<MODEL>::m;
-    for (int e = K.tid; e < K.N * n; e += K.NT) Xg[e] = Xs[e];
-    for (int e = K.tid; e < K.N * m; e += K.NT) Ug[e] = Us[e];
+template <class BLK> GD void store_traj(BLK& K, const double* Xs, const double* Us, double* Xg, double* Ug) {
+    constexpr int n = BLK::n, m = BLK::m;
+    for (int e = K.tid; e < K.N * n; e += K.nt()) Xg[e] = Xs[e];
+    for (int e = K.tid; e < K.N * m; e += K.nt()) Ug[e] = Us[e];
 }
 
-template <int MODEL> __global__ void __launch_bounds__(256) scp_kernel(const KParams P) {
+template <int MODEL, bool ONEWAVE> __global__ void __launch_bounds__(ONEWAVE ? 64 : 256)
+__attribute__((amdgpu_waves_per_eu(1, 1))) scp_kernel(const KParams P) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m;
     extern __shared__ double lds[];
-    Blk<MODEL> K(P, lds);
+    Blk<MODEL, ONEWAVE> K(P, lds);
+    Prof pf;
     const int b = K.b, tid = K.tid, N = K.N, k = tid;
     double* Xg = P.X + (size_t)b * N * n;
     double* Ug = P.U + (size_t)b * N * m;
 
     if (P.mode == 1) {  // one convex subproblem around the stored (Xp,Up): parity hook
-        for (int e = tid; e < N * n; e += K.NT) K.Xp[e] = Xg[e];
-        for (int e = tid; e < N * m; e += K.NT) K.Up[e] = Ug[e];
-        __syncthreads();
+        for (int e = tid; e < N * n; e += K.nt()) K.Xp[e] = Xg[e];
+        for (int e = tid; e < N * m; e += K.nt()) K.Up[e] = Ug[e];
+        K.sync();
         linearize<MODEL>(K, P.sub_toggle[b]);
         IpmOut io;
-        ipm_solve<MODEL>(K, P.sub_Delta[b], P.sub_omega[b], io);
-        store_traj<MODEL>(K, K.Xw, K.Uw, P.sub_X + (size_t)b * N * n, P.sub_U + (size_t)b * N * m);
+        ipm_solve<MODEL>(K, P.sub_Delta[b], P.sub_omega[b], io, pf);
+        pf.flush(P.prof);
+        store_traj(K, K.Xw, K.Uw, P.sub_X + (size_t)b * N * n, P.sub_U + (size_t)b * N * m);
         if (tid == 0) {
             P.sub_obj[b] = io.obj; P.sub_status[b] = io.status; P.sub_iters[b] = io.iters;
             for (int i = 0; i < n; i++) P.st_d[(size_t)b * SD_ND + SD_DUAL + i] = K.nu[i] * fmax(1.0, P.sub_omega[b]);
@@ -103,12 +106,12 @@ template <int MODEL> __global__ void __launch_bounds__(256) scp_kernel(const KPa
     int total_ipm = sti[ST_IPM], n_hist = sti[ST_NHIST], nJ = sti[ST_NJ], n_rho = sti[ST_NRHO];
     const int iter_cap = iterations + P.max_iter;  // scp_gusto.jl:67
 
-    for (int e = tid; e < N * n; e += K.NT) K.Xp[e] = Xg[e];
-    for (int e = tid; e < N * m; e += K.NT) K.Up[e] = Ug[e];
-    __syncthreads();
+    for (int e = tid; e < N * n; e += K.nt()) K.Xp[e] = Xg[e];
+    for (int e = tid; e < N * m; e += K.nt()) K.Up[e] = Ug[e];
+    K.sync();
 
     // scp_gusto.jl:73-76
-    double Jt = cost_true<MODEL>(K, K.Up);
+    double Jt = cost_true(K, K.Up);
     double rho0v = trust_region_ratio<MODEL>(K, K.Xp, K.Up, K.Xp, K.Up);
     double Delta = P.Delta[hb + n_hist - 1], omega = P.omega[hb + n_hist - 1];
     if (tid == 0 && nJ < P.hist_cap) { P.J_true[hb + nJ] = Jt; P.J_full[hb + nJ] = Jt; }
@@ -118,9 +121,11 @@ template <int MODEL> __global__ void __launch_bounds__(256) scp_kernel(const KPa
     double conv_prev = (n_hist >= 1) ? P.conv[hb + n_hist - 1] : 0.0;
 
     while (iterations < iter_cap && n_hist < P.hist_cap && nJ < P.hist_cap && n_rho < P.hist_cap) {
+        pf.tick(PF_SCP);
         linearize<MODEL>(K, toggle);                       // :95  update_model_params!
+        pf.tick(PF_LIN);
         IpmOut io;
-        ipm_solve<MODEL>(K, Delta, omega, io);             // :96-104
+        ipm_solve<MODEL>(K, Delta, omega, io, pf);         // :96-104
         total_ipm += io.iters;
         const int h = n_hist;
         if (tid == 0) { P.solver_status[hb + h] = io.status; P.ipm_it[hb + h] = io.iters; }
@@ -174,11 +179,11 @@ template <int MODEL> __global__ void __launch_bounds__(256) scp_kernel(const KPa
             status = GUSTO_SCP_TRUST_REGION_VIOLATED; accept = 0; Delta_n = Delta; omega_n = sp.gamma_fail * omega;
         }
         if (accept) {                                       // :149-154
-            Jt = cost_true<MODEL>(K, K.Uw);
-            __syncthreads();
-            for (int e = tid; e < N * n; e += K.NT) K.Xp[e] = K.Xw[e];
-            for (int e = tid; e < N * m; e += K.NT) K.Up[e] = K.Uw[e];
-            __syncthreads();
+            Jt = cost_true(K, K.Uw);
+            K.sync();
+            for (int e = tid; e < N * n; e += K.nt()) K.Xp[e] = K.Xw[e];
+            for (int e = tid; e < N * m; e += K.nt()) K.Up[e] = K.Uw[e];
+            K.sync();
         }
         if (tid == 0)
             for (int i = 0; i < n; i++) std_[SD_DUAL + i] = K.nu[i] * fmax(1.0, omega);  // :117 get_dual_jump
@@ -202,7 +207,9 @@ template <int MODEL> __global__ void __launch_bounds__(256) scp_kernel(const KPa
             if (!P.force) { stop = GUSTO_STOP_CONVERGED; break; }
         }
     }
-    store_traj<MODEL>(K, K.Xp, K.Up, Xg, Ug);
+    pf.tick(PF_SCP);
+    pf.flush(P.prof);
+    store_traj(K, K.Xp, K.Up, Xg, Ug);
     if (tid == 0) {
         sti[ST_ITER] = iterations; sti[ST_CONV] = converged; sti[ST_SUCC] = successful; sti[ST_STOP] = stop;
         sti[ST_IPM] = total_ipm; sti[ST_NHIST] = n_hist; sti[ST_NJ] = nJ; sti[ST_NRHO] = n_rho;

@@ -1,0 +1,23 @@
+"""Phase-cycle breakdown of the SCP kernel (needs a -DGUSTO_PROFILE build)."""
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import gusto_jl_amd as g
+P = g.problems
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+x0, glo, ghi, tf = P.freeflyer_batch(B)
+s = g.BatchSolver(g.FREEFLYER_SE2, 50, B, hist_cap=64, boxes=P.freeflyer_env())
+for rep in range(2):
+    s.set_problems(x0, glo, ghi, tf); s.solve(30)
+st = s.status()
+print(f"B={B} kernel {s.last_solve_ms():.1f} ms conv {st['converged'].sum()} traj/s {st['converged'].sum()/(s.last_solve_ms()/1e3):.0f} ipm total {st['ipm_iters'].sum()}")
+prof = np.zeros((B, 16), dtype=np.int64)
+s.L.gusto_dev_get_prof.argtypes = [C.c_void_p, C.c_void_p]
+rc = s.L.gusto_dev_get_prof(s.h, prof.ctypes.data)
+names = ["RESID","BUILD","FACTOR","POSTF","RHS","BACK","MID","FWD","STEP","UPDATE","LIN","SCP","INIT"]
+tot = prof.sum(axis=0).astype(float)
+ipm = st["ipm_iters"].sum()
+print("phase: share, cycles per IPM iteration")
+for i, nm in enumerate(names):
+    print(f"  {nm:7s} {100*tot[i]/tot.sum():5.1f}%  {tot[i]/ipm:9.0f}")
+print("total cycles/ipm-iter", tot.sum()/ipm, " mean cycles per problem", tot.sum()/B)
