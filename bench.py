@@ -32,6 +32,18 @@ BYTES_PER_LINEARIZE = 8 * N_KNOTS * (2 * 9 + 6 + 36)                     # 24 00
 HBM_PEAK_GBS = 8000.0
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(problems, env, n_sample, threads):
     """The oracle (a C port, NOT the Julia reference) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -52,7 +64,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="0 = 384 problems per usable host core (about 10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -148,8 +160,9 @@ def main():
             "pcie_inclusive_traj_per_s": n_conv / pcie_s,
         }
         if not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(P, env, min(args.cpu_sample, B), threads)
+            threads = usable_cores()
+            n_sample = args.cpu_sample or max(1024, 384 * threads)
+            out["cpu_baseline"] = cpu_baseline(P, env, n_sample, threads)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
