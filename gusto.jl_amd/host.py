@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference's driver interface for the GuSTO path.
+
+The reference is Julia (no Julia toolchain in this image), so the host layer above the C ABI is written in Python
+with the reference's names and argument meaning; julia/GuSTOHIP.jl holds the same logic as `ccall`s for a Julia
+host.  What is mirrored (reference file:line):
+
+  Goal / PointGoal / BoxGoal / GoalSet / add_goal!        src/goals.jl:1-48, src/types.jl:26-30
+  ProblemDefinition, Trajectory                           src/types.jl:32-46,235
+  TrajectoryOptimizationProblem / ...Solution             src/types.jl:48-61,196-202,228
+  SCPProblem, SCPSolution (+ SCPParam_GuSTO histories)    src/types.jl:78-86,150-173,233,256-259; scp_gusto.jl:4-24
+  solve_SCP!(TOS, TOP, solve_method!, init, solver; ...)  src/traj_opt.jl:47-72
+  solve_gusto_jump! -> solve_gusto_hip!                   src/scp/scp_gusto.jl:49   (the plug-in seam)
+
+plus `solve_SCP_batch!`, which the reference does not have (it solves one problem at a time), and the rank
+sharding used for multi-GPU runs (independent problems, no data-path collective).
+"""
+import numpy as np
+
+from . import _capi
+from ._capi import (ASTROBEE_SE3, ASTROBEE_SE3_MANIFOLD, DUBINS_CAR, FREEFLYER_SE2, MODEL_DIMS, SCP_STATUS,
+                    SOLVER_STATUS, BatchSolver)
+
+
+# ---- models / robots / environments: parameter holders (src/dynamics/*.jl, src/robot/*.jl, src/environment/*.jl) ----
+class _Model:
+    model_id = None
+
+    def __init__(self):
+        self.x_dim, self.u_dim = MODEL_DIMS[self.model_id]
+
+
+class FreeflyerSE2(_Model):
+    model_id = FREEFLYER_SE2
+
+
+class DubinsCar(_Model):
+    model_id = DUBINS_CAR
+
+
+class AstrobeeSE3(_Model):
+    model_id = ASTROBEE_SE3
+
+
+class AstrobeeSE3Manifold(_Model):
+    model_id = ASTROBEE_SE3_MANIFOLD
+
+
+class Robot:
+    """Freeflyer() / Astrobee3D() / Car(): the constants live in gusto_model_params (gusto_default_params)."""
+
+
+class Environment:
+    """keepout_zones + obstacle_set as AABBs [min xyz | max xyz] and spheres [c xyz | r]  (types.jl:12-24)."""
+
+    def __init__(self, boxes=None, spheres=None):
+        self.boxes = np.zeros((0, 6)) if boxes is None else np.asarray(boxes, float).reshape(-1, 6)
+        self.spheres = np.zeros((0, 4)) if spheres is None else np.asarray(spheres, float).reshape(-1, 4)
+
+
+def Table(room="stanford"):
+    from . import problems
+    if room != "stanford":
+        raise NotImplementedError("only Table(:stanford) is tabulated")
+    return Environment(problems.table_stanford_boxes())
+
+
+def ISSCorner(with_obstacles=False):
+    from . import problems
+    b, s = problems.iss_corner_env(with_obstacles)
+    return Environment(b, s)
+
+
+def BlankEnv():
+    return Environment()
+
+
+# ---- goals (src/goals.jl) ---------------------------------------------------------------------------
+class PointGoal:
+    def __init__(self, point):
+        self.point = np.asarray(point, float)
+
+
+class BoxGoal:
+    def __init__(self, lower_bound, upper_bound):
+        self.lower_bound, self.upper_bound = np.asarray(lower_bound, float), np.asarray(upper_bound, float)
+
+
+class Goal:
+    def __init__(self, params, t_guess, ind_coordinates):
+        """ind_coordinates: a model (all coordinates) or 0-based indices (the reference is 1-based)."""
+        self.params, self.t_guess = params, float(t_guess)
+        if isinstance(ind_coordinates, _Model):
+            ind_coordinates = range(ind_coordinates.x_dim)
+        self.ind_coordinates = np.asarray(list(ind_coordinates), int)
+
+
+class GoalSet:
+    def __init__(self):
+        self.goals = []
+
+
+def add_goal(goal_set, goal):
+    goal_set.goals.append(goal)
+    goal_set.goals.sort(key=lambda g: g.t_guess)
+
+
+def _goal_bounds(goal_set, x_dim, tf_guess):
+    """Flatten the goals active at tf_guess into (lo, hi): lo == hi -> hard equality row (csbce_goal_constraints),
+    lo < hi -> hard box rows (csbci_goal_constraints), +-inf -> no goal on that coordinate (dynamics.jl:30-42)."""
+    lo, hi = np.full(x_dim, -np.inf), np.full(x_dim, np.inf)
+    for g in goal_set.goals:
+        if g.t_guess != tf_guess:
+            continue   # every row function of the reference hard-codes knot N (dynamics.jl:33,40)
+        if isinstance(g.params, PointGoal):
+            lo[g.ind_coordinates] = hi[g.ind_coordinates] = g.params.point
+        elif isinstance(g.params, BoxGoal):
+            lo[g.ind_coordinates], hi[g.ind_coordinates] = g.params.lower_bound, g.params.upper_bound
+        else:
+            raise NotImplementedError("BallGoal has no row function in the reference either")
+    return lo, hi
+
+
+# ---- problem / solution containers (src/types.jl) ---------------------------------------------------
+class ProblemDefinition:
+    def __init__(self, robot, model, env, x_init, goal_set):
+        self.robot, self.model, self.env = robot, model, env
+        self.x_init, self.goal_set = np.asarray(x_init, float), goal_set
+
+
+class Trajectory:
+    def __init__(self, X, U, Tf):
+        self.X, self.U, self.Tf = X, U, float(Tf)        # X is x_dim x N as in the reference
+        self.dt = self.Tf / (self.X.shape[1] - 1)         # types.jl:235
+
+
+class TrajectoryOptimizationProblem:
+    def __init__(self, PD, N, tf_guess, fixed_final_time=False):
+        if not fixed_final_time:
+            raise NotImplementedError("free final time: the reference's dynamics use traj_prev.dt, i.e. Tf never "
+                                      "enters the subproblem (freeflyer_se2.jl:170); only fixed_final_time is mirrored")
+        self.PD, self.N, self.tf_guess, self.fixed_final_time = PD, int(N), float(tf_guess), True
+
+
+class SCPProblem:
+    def __init__(self, TOP):
+        self.PD, self.N, self.tf_guess = TOP.PD, TOP.N, TOP.tf_guess
+        self.scp_params, self.model_params = _capi.default_params(TOP.PD.model.model_id)   # SCPParam + SCPParam_GuSTO
+        self.Delta_vec, self.omega_vec, self.rho_vec = [], [], []
+        self.trust_region_satisfied_vec, self.convex_ineq_satisfied_vec = [], []
+
+
+class SCPSolution:
+    def __init__(self, SCPP, traj_init):
+        self.traj, self.SCPP = traj_init, SCPP
+        self.dual = np.zeros(SCPP.PD.model.x_dim)
+        self.J_true, self.J_full = [], []
+        self.solver_status, self.scp_status = ["NA"], ["NA"]
+        self.accept_solution, self.convergence_measure = [True], [0.0]
+        self.successful = self.converged = False
+        self.iterations, self.iter_elapsed_times, self.total_time = 0, [0.0], 0.0
+        self._solver = None     # the gusto_handle that owns the device-side state of this solution (resume)
+
+
+class TrajectoryOptimizationSolution:
+    def __init__(self, TOP):
+        n, m = TOP.PD.model.x_dim, TOP.PD.model.u_dim
+        self.traj = Trajectory(np.zeros((n, TOP.N)), np.zeros((m, TOP.N)), TOP.tf_guess)
+        self.SCPS = None
+        self.total_time = 0.0
+
+
+def init_traj_straightline(TOP):
+    """freeflyer_se2.jl:97-111: linear interpolation x_init -> centre of the goals at the final time, U = 0."""
+    n, m, N = TOP.PD.model.x_dim, TOP.PD.model.u_dim, TOP.N
+    lo, hi = _goal_bounds(TOP.PD.goal_set, n, TOP.tf_guess)
+    xg = np.where(np.isfinite(lo) & np.isfinite(hi), 0.5 * (lo + hi), 0.0)
+    t = np.arange(N) / (N - 1)
+    X = (1 - t)[None, :] * TOP.PD.x_init[:, None] + t[None, :] * xg[:, None]
+    return Trajectory(X, np.zeros((m, N)), TOP.tf_guess)
+
+
+# ---- the plug-in: solve_method!(SCPS, SCPP, solver, max_iter, force; kw...) ---------------------------------------
+def _fill_solution(SCPS, SCPP, bs, b, elapsed):
+    X, U = bs.traj()
+    st, h = bs.status(), bs.history()
+    SCPS.traj.X, SCPS.traj.U = X[b].T.copy(), U[b].T.copy()
+    nh, nJ, nr = h["n_hist"][b], h["nJ"][b], h["n_rho"][b]
+    SCPS.J_true, SCPS.J_full = list(h["J_true"][b, :nJ]), list(h["J_full"][b, :nJ])
+    SCPS.solver_status = [SOLVER_STATUS[int(v)] for v in h["solver_status"][b, :nh]]
+    SCPS.scp_status = [SCP_STATUS[int(v)] for v in h["scp_status"][b, :nh]]
+    SCPS.accept_solution = [bool(v) for v in h["accept_solution"][b, :nh]]
+    SCPS.convergence_measure = list(h["convergence_measure"][b, :nh])
+    SCPS.iterations = int(st["iterations"][b])
+    SCPS.converged, SCPS.successful = bool(st["converged"][b]), bool(st["successful"][b])
+    SCPS.dual = bs.dual()[b]
+    SCPS.total_time += elapsed
+    SCPS.iter_elapsed_times = [0.0] + [SCPS.total_time / max(1, SCPS.iterations)] * SCPS.iterations
+    SCPP.Delta_vec, SCPP.omega_vec = list(h["Delta"][b, :nh]), list(h["omega"][b, :nh])
+    SCPP.rho_vec = list(h["rho"][b, :nr])
+    SCPP.trust_region_satisfied_vec = [bool(v) for v in h["trust_region_satisfied"][b, :nh]]
+    SCPP.convex_ineq_satisfied_vec = [bool(v) for v in h["convex_ineq_satisfied"][b, :nh]]
+    SCPP.obstacle_toggle_distance = SCPP.Delta_vec[-1] / 8 + SCPP.model_params.clearance
+
+
+def solve_gusto_hip(SCPS, SCPP, solver="hip", max_iter=30, force=False, device=0, **kwarg):
+    """Same positional signature as solve_gusto_jump! (scp_gusto.jl:49).  Mutates SCPS / SCPP in place; a second
+    call resumes from SCPS (iter_cap = iterations + max_iter, scp_gusto.jl:67)."""
+    model = SCPP.PD.model
+    n, N = model.x_dim, SCPP.N
+    bs = SCPS._solver
+    if bs is None:
+        env = SCPP.PD.env
+        bs = BatchSolver(model.model_id, N, 1, hist_cap=max(64, 2 * max_iter + 8), device=device, boxes=env.boxes,
+                         spheres=env.spheres, scp_params=SCPP.scp_params, model_params=SCPP.model_params)
+        lo, hi = _goal_bounds(SCPP.PD.goal_set, n, SCPP.tf_guess)
+        bs.set_problems(SCPP.PD.x_init[None], lo[None], hi[None], [SCPP.tf_guess],
+                        SCPS.traj.X.T[None].copy(), SCPS.traj.U.T[None].copy())
+        SCPS._solver = bs
+    bs.solve(max_iter, force)
+    _fill_solution(SCPS, SCPP, bs, 0, bs.last_solve_ms() * 1e-3)
+
+
+def solve_SCP(TOS, TOP, solve_method, init_method, solver="hip", max_iter=30, force=False, **kwarg):
+    """traj_opt.jl:47-72 (both overloads: `init_method` may be a function of TOP or a Trajectory)."""
+    SCPP = SCPProblem(TOP)
+    traj_init = init_method(TOP) if callable(init_method) else init_method
+    SCPS = SCPSolution(SCPP, traj_init)
+    TOS.traj, TOS.SCPS = SCPS.traj, SCPS          # aliasing as in traj_opt.jl:58
+    solve_method(SCPS, SCPP, solver, max_iter, force, **kwarg)
+    return SCPS
+
+
+# ---- batch API (new: the reference has no batch mode) --------------------------------------------------------------
+def shard_bounds(B, world_size, rank):
+    """Contiguous block of ceil(B/G) problems per rank; the tail rank may get fewer."""
+    per = -(-B // world_size)
+    lo = min(B, rank * per)
+    return lo, min(B, lo + per)
+
+
+def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straightline, solver="hip", max_iter=30,
+                    force=False, device=0):
+    """All TOPs must share model, N and environment; one gusto_solve covers the whole list."""
+    TOP0 = TOPs[0]
+    model, N = TOP0.PD.model, TOP0.N
+    n = model.x_dim
+    B = len(TOPs)
+    sp, mp = _capi.default_params(model.model_id)
+    bs = BatchSolver(model.model_id, N, B, hist_cap=max(64, 2 * max_iter + 8), device=device, boxes=TOP0.PD.env.boxes,
+                     spheres=TOP0.PD.env.spheres, scp_params=sp, model_params=mp)
+    x0 = np.stack([t.PD.x_init for t in TOPs])
+    bounds = [_goal_bounds(t.PD.goal_set, n, t.tf_guess) for t in TOPs]
+    lo, hi = np.stack([b[0] for b in bounds]), np.stack([b[1] for b in bounds])
+    tf = np.array([t.tf_guess for t in TOPs])
+    inits = [init_method(t) if callable(init_method) else init_method for t in TOPs]
+    X0 = np.stack([t.X.T for t in inits])
+    U0 = np.stack([t.U.T for t in inits])
+    bs.set_problems(x0, lo, hi, tf, X0, U0)
+    bs.solve(max_iter, force)
+    out = []
+    for b, (TOS, TOP) in enumerate(zip(TOSs, TOPs)):
+        SCPP = SCPProblem(TOP)
+        SCPS = SCPSolution(SCPP, inits[b])
+        _fill_solution(SCPS, SCPP, bs, b, bs.last_solve_ms() * 1e-3 / B)
+        TOS.traj, TOS.SCPS = SCPS.traj, SCPS
+        out.append(SCPS)
+    return out
+
+
+def gather_batch_results(local, world_size, rank, group=None):
+    """Final gather of per-rank results to rank 0: the only communication of a multi-GPU run.
+    `local` is a dict of numpy arrays with the problem index leading.  Uses torch.distributed (RCCL when the
+    tensors live on GPUs under the nccl backend, gloo on CPU); returns the concatenated dict on rank 0."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1:
+        return local
+    out = {}
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    for k, v in local.items():
+        t = torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world_size)]
+        dist.all_gather(sizes, torch.tensor([t.shape[0]], dtype=torch.int64, device=dev), group=group)
+        sizes = [int(s.item()) for s in sizes]
+        mx = max(sizes)
+        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        pad[:t.shape[0]] = t
+        bufs = [torch.zeros_like(pad) for _ in range(world_size)] if rank == 0 else None
+        dist.gather(pad, bufs, dst=0, group=group)
+        if rank == 0:
+            out[k] = np.concatenate([b[:s].cpu().numpy() for b, s in zip(bufs, sizes)], axis=0)
+    return out if rank == 0 else None

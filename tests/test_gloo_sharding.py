@@ -1,0 +1,63 @@
+"""Multi-process path on CPU (gloo, world_size 2): the batch is sharded into contiguous blocks, every rank works
+on its own block with NO data-path collective, and the only communication is the final gather to rank 0
+(SURVEY.md 8(e)).  The per-rank 'solve' here is a deterministic stand-in computed from the inputs, so the test
+checks exactly the sharding / gather plumbing that bench.py and solve_SCP_batch use on GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, B, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import gusto_jl_amd as g
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x0, glo, ghi, tf = g.problems.freeflyer_batch(B)           # every rank can regenerate the seeded inputs
+    lo, hi = g.host.shard_bounds(B, world, rank)
+    # stand-in for the per-rank solve: something only the owner of a problem can produce
+    local = {"X": (x0[lo:hi] * (1 + np.arange(lo, hi))[:, None]), "owner": np.full(hi - lo, rank, dtype=np.int64),
+             "index": np.arange(lo, hi, dtype=np.int64)}
+    out = g.host.gather_batch_results(local, world, rank)
+    import torch
+    cnt = torch.tensor([hi - lo], dtype=torch.int64)
+    dist.all_reduce(cnt)                                       # the metric reduction bench.py performs
+    if rank == 0:
+        q.put((out["X"], out["owner"], out["index"], int(cnt.item())))
+    else:
+        assert out is None
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_gather():
+    B, world = 37, 2                       # ragged: 19 + 18
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    X, owner, index, total = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    import gusto_jl_amd as g
+    x0, _, _, _ = g.problems.freeflyer_batch(B)
+    assert total == B
+    np.testing.assert_array_equal(index, np.arange(B))
+    np.testing.assert_array_equal(owner, np.array([0] * 19 + [1] * 18))
+    np.testing.assert_array_equal(X, x0 * (1 + np.arange(B))[:, None])

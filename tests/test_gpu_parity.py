@@ -263,3 +263,68 @@ def test_single_problem_plumbing():
     # clearance >= 0.05 - eps at every knot but the (fixed) first one
     d = min(o.signed_distance(0, X[0, k, :2], i)[0] for k in range(1, 50) for i in range(len(env)))
     assert d >= 0.05 - 1e-2
+
+
+GOLDEN = ["freeflyer_se2_n50", "freeflyer_se2_n200_notebook", "dubins_car_n30", "astrobee_se3_n50",
+          "astrobee_se3_manifold_n50"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_gpu_matches_golden_vectors(name):
+    """Committed fixtures (tests/golden, generated by the oracle): no oracle needed at run time.  The N=200 case
+    runs the multi-wave (4 waves per problem, real barriers) variant of the kernel."""
+    import os
+    g, _ = _mods()
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    model, N, B = int(d["model"]), int(d["N"]), len(d["x_init"])
+    s = g.BatchSolver(model, N, B, hist_cap=int(d["max_iter"]) + 8, boxes=d["boxes"], spheres=d["spheres"])
+    s.set_problems(d["x_init"], d["goal_lo"], d["goal_hi"], d["tf"])
+    X0, U0 = s.traj()
+    sp, mp = g.default_params(model)
+    sub = s.subproblem(X0, U0, sp.Delta0, 1.0, sp.Delta0 / 8 + mp.clearance)
+    for b in range(B):
+        if d["sub_iters"][b] >= 60 or not np.isfinite(d["sub_obj"][b]):
+            continue
+        assert np.abs(sub["X"][b] - d["sub_X"][b]).max() < SUB_ATOL and np.abs(sub["U"][b] - d["sub_U"][b]).max() < SUB_ATOL
+        assert abs(sub["obj"][b] - d["sub_obj"][b]) <= 1e-8 * max(1.0, abs(d["sub_obj"][b]))
+    s.set_problems(d["x_init"], d["goal_lo"], d["goal_hi"], d["tf"])
+    s.solve(int(d["max_iter"]))
+    X, U = s.traj()
+    st = s.status()
+    for b in range(B):
+        om = d["omega"][b][~np.isnan(d["omega"][b])]
+        if om.max() > 1e3:
+            continue
+        assert bool(st["converged"][b]) == bool(d["converged"][b]) and int(st["iterations"][b]) == int(d["iterations"][b])
+        assert int(st["stop_reason"][b]) == int(d["stop_reason"][b])
+        assert np.abs(X[b] - d["X"][b]).max() < TRAJ_ATOL and np.abs(U[b] - d["U"][b]).max() < TRAJ_ATOL
+
+
+def test_host_mirror_solve_SCP_through_the_seam():
+    """solve_SCP!(TOS, TOP, solve_gusto_hip!, init_traj_straightline, "hip") on the notebook's problem (N=50)."""
+    g, go = _mods()
+    H, P = g.host, g.problems
+    env = H.Environment(P.freeflyer_env())
+    model = H.FreeflyerSE2()
+    gs = H.GoalSet()
+    H.add_goal(gs, H.Goal(H.PointGoal(P.FREEFLYER_X_GOAL), 200.0, model))
+    PD = H.ProblemDefinition(H.Robot(), model, env, P.FREEFLYER_X_INIT, gs)
+    TOP = H.TrajectoryOptimizationProblem(PD, 50, 200.0, fixed_final_time=True)
+    TOS = H.TrajectoryOptimizationSolution(TOP)
+    SCPS = H.solve_SCP(TOS, TOP, H.solve_gusto_hip, H.init_traj_straightline, "hip", max_iter=4)
+    assert TOS.traj is SCPS.traj and SCPS.iterations == 4 and not SCPS.converged
+    H.solve_gusto_hip(SCPS, SCPS.SCPP, "hip", 26)                    # resume (scp_gusto.jl:67)
+    assert SCPS.converged and SCPS.successful
+    o = go.Oracle(go.FREEFLYER_SE2, 50, boxes=P.freeflyer_env())
+    o.set_problem(P.FREEFLYER_X_INIT, P.FREEFLYER_X_GOAL, P.FREEFLYER_X_GOAL, 200.0)
+    r = o.solve(30)
+    assert SCPS.iterations == r["iterations"]
+    assert np.abs(SCPS.traj.X.T - r["X"]).max() < TRAJ_ATOL
+    assert SCPS.scp_status == [go.SCP_STATUS[v] for v in r["scp_status"]]
+    assert len(SCPS.J_true) == len(r["J_true"]) + 1 and SCPS.SCPP.omega_vec == list(r["omega"])
+    # batch seam: three copies of the problem through solve_SCP_batch! give the same trajectory
+    TOSs = [H.TrajectoryOptimizationSolution(TOP) for _ in range(3)]
+    outs = H.solve_SCP_batch(TOSs, [TOP] * 3, H.solve_gusto_hip, H.init_traj_straightline, "hip", max_iter=30)
+    for S in outs:
+        assert S.converged and np.array_equal(S.traj.X, outs[0].traj.X)
+    assert np.abs(outs[0].traj.X.T - r["X"]).max() < TRAJ_ATOL
