@@ -29,7 +29,7 @@ def run(name, model, N, boxes, spheres, x0, glo, ghi, tf, max_iter=30):
         sub = o.subproblem(Xi, Ui, D0, 1.0, D0 / 8 + clr)
         o.set_problem(x0[b], glo[b], ghi[b], tf[b])
         r = o.solve(max_iter)
-        r["sub_X"], r["sub_U"], r["sub_obj"], r["sub_iters"] = sub["X"], sub["U"], sub["obj"], sub["iters"]
+        r["sub_X"], r["sub_U"], r["sub_obj"], r["sub_iters"], r["sub_status"] = sub["X"], sub["U"], sub["obj"], sub["iters"], sub["status"]
         res.append(r)
     keys = ["X", "U", "sub_X", "sub_U"]
     d = dict(model=model, N=N, boxes=np.zeros((0, 6)) if boxes is None else boxes,
@@ -37,7 +37,7 @@ def run(name, model, N, boxes, spheres, x0, glo, ghi, tf, max_iter=30):
              max_iter=max_iter)
     for k in keys:
         d[k] = np.stack([r[k] for r in res])
-    for k in ("iterations", "converged", "successful", "stop_reason", "sub_obj", "sub_iters"):
+    for k in ("iterations", "converged", "successful", "stop_reason", "sub_obj", "sub_iters", "sub_status"):
         d[k] = np.array([r[k] for r in res])
     H = max(len(r["omega"]) for r in res) + 2
     for k in ("J_true", "J_full", "conv", "Delta", "omega", "rho", "accept", "scp_status"):

@@ -2,8 +2,9 @@
 seeded problems, plus size-independent properties at BASELINE.json's full batch sizes.
 
 Tolerances (fp64, BASELINE.json "stated fp64 tolerance"):
-  subproblem level  : X, U within 1e-6*max(1, omega/5) abs of the oracle (both sides stop at a 1e-8 residual
-                      of the problem scaled by 1/max(1,omega)), objective within 1e-8 rel
+  subproblem level  : X, U within 1e-6*max(1, omega) abs of the oracle (both sides stop at a 1e-8 residual of
+                      the problem scaled by 1/max(1,omega); the horizon amplifies a control error by ~tf^2/2m),
+                      objective within 1e-8 rel
   trajectory level  : same `converged` flag, final X within 1e-3 abs, J_true within 1e-4 rel
 Both sides run the same interior point algorithm, so typical differences are 1e-10..1e-13; the stated
 tolerances are what the suite gates on.  Problems whose penalty weight omega climbed above 1e3 are compared
@@ -40,7 +41,7 @@ def _sub_parity(model, N, env, spheres, x0, glo, ghi, tf, Delta, omega, toggle, 
             continue
         dx, du = np.abs(r["X"][b] - ro["X"]).max(), np.abs(r["U"][b] - ro["U"]).max()
         worst = max(worst, dx, du)
-        tol_b = atol * max(1.0, omega / 5.0)
+        tol_b = atol * max(1.0, omega)
         assert dx < tol_b and du < tol_b, (b, dx, du)
         assert abs(r["obj"][b] - ro["obj"]) <= 1e-8 * max(1.0, abs(ro["obj"])), (b, r["obj"][b], ro["obj"])
         assert abs(int(r["iters"][b]) - ro["iters"]) <= 1
@@ -283,7 +284,8 @@ def test_gpu_matches_golden_vectors(name):
     sp, mp = g.default_params(model)
     sub = s.subproblem(X0, U0, sp.Delta0, 1.0, sp.Delta0 / 8 + mp.clearance)
     for b in range(B):
-        if d["sub_iters"][b] >= 60 or not np.isfinite(d["sub_obj"][b]):
+        assert int(sub["status"][b]) == int(d["sub_status"][b])
+        if int(d["sub_status"][b]) != 1:
             continue
         assert np.abs(sub["X"][b] - d["sub_X"][b]).max() < SUB_ATOL and np.abs(sub["U"][b] - d["sub_U"][b]).max() < SUB_ATOL
         assert abs(sub["obj"][b] - d["sub_obj"][b]) <= 1e-8 * max(1.0, abs(d["sub_obj"][b]))
