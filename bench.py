@@ -143,6 +143,15 @@ def main():
         avg_ms = float(np.mean(kernel_ms))
         alg_bytes = BYTES_PER_KKT * ipm_iters + BYTES_PER_LINEARIZE * scp_iters      # this rank, one launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # HBM traffic of one launch from the latest committed PMC pass (separate rocprofv3 --pmc runs, profiles/)
+        traffic = None
+        try:
+            import glob
+            pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+            if pmc and B == BATCH:
+                traffic = json.load(open(pmc[-1]))["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "converged trajectories/sec (batched SCP), freeflyerSE2 N=50",
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -152,7 +161,7 @@ def main():
                                    "(BASELINE.json configs[1])", "batch_per_gpu": B, "N": N_KNOTS,
                        "max_iter": MAX_ITER, "sharding": "independent problems per rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "gusto::scp_kernel<0>", "avg_launch_ms": avg_ms,
                          "kkt_solves_per_launch": ipm_iters, "scp_iters_per_launch": scp_iters},
             "converged": int(tot[0]), "successful": int(tot[1]), "problems": B * world,
