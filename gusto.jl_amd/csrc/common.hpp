@@ -78,7 +78,7 @@ template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
 template <int MODEL> struct LdsC {
     using T = MT<MODEL>;
     static constexpr int n = T::n, m = T::m, NZ = n + m;
-    static constexpr int sP = 0, sPi = sP + n * n, sPG = sPi + n * n, sT = sPG + 2 * n * NZ, sHh = sT + n * NZ,
+    static constexpr int sP = 0, sPi = sP + n * n, sPG = sPi + n * n, sT = sPG + 3 * n * NZ, sHh = sT + n * NZ,
                          sZ = sHh + NZ * NZ, sK = sZ + NZ * n, sD = sK + m * n, sW = sD + m * n, sV = sW + m * n,
                          sGd = sV + m * n, misc = sGd + 2 * n * n, lut = misc + 64,
                          vecs = lut + (NZ * (NZ + 1) / 2 + 1) / 2 + 1;

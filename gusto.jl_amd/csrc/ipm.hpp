@@ -169,7 +169,7 @@ template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
 // ---- Riccati factorisation of the condensed KKT system (cooperative, sequential in k) ---------------
 // All goal-multiplier blocks (Pi, Z, V, D, Gd) have n columns in state-index space; column i is identically
 // zero when coordinate i has no point goal.
-template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail) {
+template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ;
     constexpr int QPT = (NQ + 63) / 64, PPT = (NPG + 63) / 64;
@@ -349,7 +349,8 @@ template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail) {
 }
 
 // p_{k-1} = Phicl_k^T (p_k + r_k) + qt_k, k = N-1..1; pv[k] holds qt_k on entry and p_k on exit
-template <class BLK> GD void backward_sweep(BLK& K) {
+template <class BLK> GD void backward_sweep_mw(BLK& K) {
+    // pt_{k-1} = Phicl_k^T pt_k + qq_k (pt = p + r, qq_k = qt_k + r_{k-1}); pv[k]: qq_k on entry, pt_k on exit
     constexpr int n = BLK::n;
     const int tid = K.tid, N = K.N;
     double p = 0.0, col[n], coln[n];
@@ -358,6 +359,7 @@ template <class BLK> GD void backward_sweep(BLK& K) {
     if (tid < n) {
 #pragma unroll
         for (int l = 0; l < n; l++) col[l] = K.Phicl[(size_t)(N - 1) * n * n + l * n + tid];
+        p = K.rv[(N - 1) * n + tid];
     }
     for (int k = N - 1; k >= 1; k--) {
         double* buf = K.sT + (k & 1) * n;
@@ -366,7 +368,7 @@ template <class BLK> GD void backward_sweep(BLK& K) {
 #pragma unroll
                 for (int l = 0; l < n; l++) coln[l] = K.Phicl[(size_t)(k - 1) * n * n + l * n + tid];
             }
-            buf[tid] = p + K.rv[k * n + tid];
+            buf[tid] = p;
         }
         K.sync();
         if (tid < n) {
@@ -387,7 +389,7 @@ template <class BLK> GD void backward_sweep(BLK& K) {
 }
 
 // dy_k = Phicl_k dy_{k-1} + ct_k, k = 0..N-1; dY[k] holds ct_k on entry and dy_k on exit
-template <class BLK> GD void forward_sweep(BLK& K) {
+template <class BLK> GD void forward_sweep_mw(BLK& K) {
     constexpr int n = BLK::n;
     const int tid = K.tid, N = K.N;
     double y = 0.0, row[n], rown[n];
@@ -421,6 +423,309 @@ template <class BLK> GD void forward_sweep(BLK& K) {
         }
     }
     K.sync();
+}
+
+
+// ---- one-wave variants: every lane's role and LDS addresses are fixed before the knot loop ---------------
+GD double readlane_f64(double v, int lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), lane);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// LDS buffer holding [Phi Gam] of knot k: knot 0 has its own ([0 | b_0], x_1 is pinned), LTI models one more,
+// time-varying models double-buffer.
+template <int MODEL, class BLK> GD double* pg_buf(BLK& K, int k) {
+    using T = MT<MODEL>;
+    constexpr int NPG = T::n * (T::n + T::m);
+    return K.sPG + (k == 0 ? 2 * NPG : (T::LTI ? 0 : (k & 1) * NPG));
+}
+
+template <int MODEL, class BLK> GD void factor_sweep_1w(BLK& K, double* fail) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n;
+    constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64;
+    const int tid = K.tid, N = K.N;
+    // fixed roles: T/Z entries (phase 1), packed H entries (phase 2), n x n entries (phase 4)
+    int tI[RT], tJ[RT], zJ[RT], zG[RT], hI[RQ], hJ[RQ], nI[RN], nJ[RN];
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+        const int e = tid + 64 * r;
+        tI[r] = (e < NPG) ? e / NZ : 0; tJ[r] = (e < NPG) ? e % NZ : 0;
+        zJ[r] = (e < NPG) ? e / n : 0; zG[r] = (e < NPG) ? e % n : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < RQ; r++) {
+        const int e = tid + 64 * r, ij = (e < NQ) ? K.lut[e] : 0;
+        hI[r] = ij >> 8; hJ[r] = ij & 255;
+    }
+#pragma unroll
+    for (int r = 0; r < RN; r++) {
+        const int e = tid + 64 * r;
+        nI[r] = (e < NN) ? e / n : 0; nJ[r] = (e < NN) ? e % n : 0;
+    }
+    // knot-0 operands [0 | b_0] and, for LTI models, the one [Phi Gam] block
+    {
+        double B[n * m];
+        Dyn<MODEL>::B(K.P.mp, B);
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const int e = tid + 64 * r;
+            if (e < NPG) {
+                const int i = e / NZ, j = e % NZ;
+                double v = 0.0;
+#pragma unroll
+                for (int q = 0; q < n * m; q++) if (j >= n && q == i * m + (j - n)) v = 0.5 * K.dt * B[q];
+                K.sPG[2 * NPG + e] = v;
+                K.sPG[((T::LTI ? 0 : (N - 1)) & 1) * NPG + e] = K.PGk(N - 1)[e];
+            }
+        }
+    }
+    double qq[RQ], pgn[RT];
+#pragma unroll
+    for (int r = 0; r < RQ; r++) { const int e = tid + 64 * r; qq[r] = (e < NQ) ? K.QQ[(size_t)(N - 1) * NQ + e] : 0.0; }
+#pragma unroll
+    for (int r = 0; r < RT; r++) pgn[r] = 0.0;
+#pragma unroll
+    for (int r = 0; r < RN; r++) {
+        const int e = tid + 64 * r;
+        if (e < NN) {
+            K.sP[e] = 0; K.sPi[e] = 0; K.sGd[e] = 0;
+            K.Paft[(size_t)(N - 1) * NN + e] = 0.0;   // value function after the last knot
+            K.Piaft[(size_t)(N - 1) * NN + e] = 0.0;
+        }
+    }
+    K.sync();
+    for (int k = N - 1; k >= 0; k--) {
+        const double* PGs = pg_buf<MODEL>(K, k);
+        // prefetch the operands of knot k-1
+        double qqn[RQ];
+#pragma unroll
+        for (int r = 0; r < RQ; r++) {
+            const int e = tid + 64 * r;
+            qqn[r] = (k > 0 && e < NQ) ? K.QQ[(size_t)(k - 1) * NQ + e] : 0.0;
+        }
+        if (!T::LTI && k > 1) {
+            const double* pg = K.PGk(k - 1);
+#pragma unroll
+            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = (e < NPG) ? pg[e] : 0.0; }
+        }
+        // phase 1a: T = P [Phi Gam]
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            if (tid + 64 * r < NPG) {
+                double a[n], bb[n];
+#pragma unroll
+                for (int l = 0; l < n; l++) { a[l] = K.sP[tI[r] * n + l]; bb[l] = PGs[l * NZ + tJ[r]]; }
+                __builtin_amdgcn_sched_barrier(0);
+                double s = 0;
+#pragma unroll
+                for (int l = 0; l < n; l++) s += a[l] * bb[l];
+                K.sT[tid + 64 * r] = s;
+            }
+        }
+        // phase 1b: Z = [Phi Gam]^T Pi (+ E at the last knot; E = [M^T C^T; b^T M^T C^T], M = (Phi+I)/2, M b = Gam/2)
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            if (tid + 64 * r < NPG) {
+                double a[n], bb[n];
+#pragma unroll
+                for (int l = 0; l < n; l++) { a[l] = PGs[l * NZ + zJ[r]]; bb[l] = K.sPi[l * n + zG[r]]; }
+                __builtin_amdgcn_sched_barrier(0);
+                double s = 0;
+#pragma unroll
+                for (int l = 0; l < n; l++) s += a[l] * bb[l];
+                if (k == N - 1 && K.is_goal(zG[r])) s += 0.5 * (PGs[zG[r] * NZ + zJ[r]] + ((zJ[r] == zG[r]) ? 1.0 : 0.0));
+                K.sZ[tid + 64 * r] = s;
+            }
+        }
+        K.sync();
+        // phase 2: Hh = QQ + [Phi Gam]^T T (one triangle, mirrored)
+#pragma unroll
+        for (int r = 0; r < RQ; r++) {
+            if (tid + 64 * r < NQ) {
+                double a[n], bb[n];
+#pragma unroll
+                for (int l = 0; l < n; l++) { a[l] = PGs[l * NZ + hI[r]]; bb[l] = K.sT[l * NZ + hJ[r]]; }
+                __builtin_amdgcn_sched_barrier(0);
+                double s = qq[r];
+#pragma unroll
+                for (int l = 0; l < n; l++) s += a[l] * bb[l];
+                K.sHh[hI[r] * NZ + hJ[r]] = s;
+                K.sHh[hJ[r] * NZ + hI[r]] = s;
+            }
+        }
+        K.sync();
+        // phase 3: block Cholesky of [S Hyu^T; Hyu Hyy]: L = chol(S), W = L^-1 Hyu^T, V = L^-1 Zu, K = L^-T W,
+        // D = L^-T V; one lane per column, each recomputes the m x m factor
+        if (tid < 2 * n || tid < m * m) {
+            double S[m * m], Li[m * m];
+#pragma unroll
+            for (int i = 0; i < m; i++)
+#pragma unroll
+                for (int j = 0; j < m; j++) S[i * m + j] = K.sHh[(n + i) * NZ + n + j];
+            const bool isK = tid < n;
+            const int g = isK ? tid : tid - n;
+            double col[m], w[m], kk[m];
+#pragma unroll
+            for (int l = 0; l < m; l++) col[l] = (tid < 2 * n) ? (isK ? K.sHh[g * NZ + n + l] : K.sZ[(n + l) * n + g]) : 0.0;
+            if (!chol_inv<m>(S, Li)) *fail = 1.0;
+#pragma unroll
+            for (int i = 0; i < m; i++) {
+                double s = 0;
+#pragma unroll
+                for (int l = 0; l <= i; l++) s += Li[i * m + l] * col[l];
+                w[i] = s;
+            }
+#pragma unroll
+            for (int i = 0; i < m; i++) {
+                double s = 0;
+#pragma unroll
+                for (int l = i; l < m; l++) s += Li[l * m + i] * w[l];
+                kk[i] = s;
+            }
+            if (tid < 2 * n) {
+                double* sw = isK ? K.sW : K.sV;
+                double* sk = isK ? K.sK : K.sD;
+                double* gk = (isK ? K.Kg : K.Dg) + (size_t)k * m * n;
+#pragma unroll
+                for (int i = 0; i < m; i++) { sw[i * n + g] = w[i]; sk[i * n + g] = kk[i]; gk[i * n + g] = kk[i]; }
+            }
+            if (tid < m * m) {  // S^-1 = L^-T L^-1 (feed-forward only)
+                const int i = tid / m, j = tid % m;
+                double s = 0;
+#pragma unroll
+                for (int l = 0; l < m; l++) if (l >= i && l >= j) s += Li[l * m + i] * Li[l * m + j];
+                K.Sinvg[(size_t)k * m * m + tid] = s;
+            }
+        }
+        K.sync();
+        // phase 4: P' = Hyy - W^T W, Pi' = Zy - W^T V, Phicl = Phi - Gam K, Gd += V^T V (never through S^-1:
+        // with barrier weights ~1/mu in Hyy the explicit form loses every digit).  P', Pi' are the value function
+        // after knot k-1 and are stored as such.
+#pragma unroll
+        for (int r = 0; r < RN; r++) {
+            const int e2 = tid + 64 * r;
+            if (e2 < NN) {
+                const int i = nI[r], j = nJ[r];
+                double wi[m], wj[m], vj[m], vi[m], gi[m], kj[m];
+#pragma unroll
+                for (int l = 0; l < m; l++) {
+                    wi[l] = K.sW[l * n + i]; wj[l] = K.sW[l * n + j]; vj[l] = K.sV[l * n + j]; vi[l] = K.sV[l * n + i];
+                    gi[l] = PGs[i * NZ + n + l]; kj[l] = K.sK[l * n + j];
+                }
+                double pn = K.sHh[i * NZ + j], ph = PGs[i * NZ + j], pin = K.sZ[i * n + j], gd = K.sGd[e2];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int l = 0; l < m; l++) { pn -= wi[l] * wj[l]; ph -= gi[l] * kj[l]; pin -= wi[l] * vj[l]; gd += vi[l] * vj[l]; }
+                K.sP[e2] = pn; K.sPi[e2] = pin; K.sGd[e2] = gd;
+                K.Phicl[(size_t)k * NN + e2] = ph;
+                if (k > 0) { K.Paft[(size_t)(k - 1) * NN + e2] = pn; K.Piaft[(size_t)(k - 1) * NN + e2] = pin; }
+            }
+        }
+        if (!T::LTI && k > 1) {
+#pragma unroll
+            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; if (e < NPG) K.sPG[((k - 1) & 1) * NPG + e] = pgn[r]; }
+        }
+#pragma unroll
+        for (int r = 0; r < RQ; r++) qq[r] = qqn[r];
+        K.sync();
+    }
+}
+
+// Affine vector recurrences of the one-wave path.  The wave is split into C = 64/n groups of n lanes; group g
+// holds the operands of knot (k0 -+ g) of the current chunk of C knots, so ONE batch of global loads feeds C knots
+// of the dependency chain (the recurrences are memory-latency bound otherwise), and the next chunk is fetched
+// while the current one computes.  The n-vector travels between groups with v_readlane (no LDS on the chain).
+//
+// backward: pt_{k-1} = Phicl_k^T pt_k + qq_k, k = N-1..1, pt := p + r (so qq_k = qt_k + r_{k-1}), pt_{N-1} = r_{N-1}.
+//           pv[k] holds qq_k on entry and pt_k on exit.
+template <class BLK> GD void backward_sweep_1w(BLK& K) {
+    constexpr int n = BLK::n, C = 64 / n;
+    const int tid = K.tid, N = K.N;
+    const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
+    double col[n], coln[n], qv, qvn = 0, pval;
+    auto fetch = [&](int k0, double* c, double& q) {
+        const int kk = k0 - g;
+        const bool ok = kk >= 1;
+#pragma unroll
+        for (int l = 0; l < n; l++) c[l] = ok ? K.Phicl[(size_t)kk * n * n + l * n + i] : 0.0;
+        q = ok ? K.pv[kk * n + i] : 0.0;
+    };
+    fetch(N - 1, col, qv);
+    pval = K.rv[(N - 1) * n + i];       // every group starts from pt_{N-1}; only group C-1 is read at step 0
+    K.sync();
+    if (tid < n) K.pv[(N - 1) * n + tid] = pval;
+    for (int k0 = N - 1; k0 >= 1; k0 -= C) {
+        if (k0 - C >= 1) fetch(k0 - C, coln, qvn);
+#pragma unroll
+        for (int gs = 0; gs < C; gs++) {
+            if (k0 - gs >= 1) {
+                const int sg = (gs == 0) ? C - 1 : gs - 1;
+                double s = qv;
+#pragma unroll
+                for (int l = 0; l < n; l++) s += col[l] * readlane_f64(pval, sg * n + l);
+                pval = (g == gs) ? s : pval;
+            }
+        }
+        {   // group g produced pt_{kk-1}, kk = k0 - g
+            const int kk = k0 - g;
+            if (tid < C * n && kk >= 1) K.pv[(kk - 1) * n + i] = pval;
+        }
+#pragma unroll
+        for (int l = 0; l < n; l++) col[l] = coln[l];
+        qv = qvn;
+    }
+    K.sync();
+}
+
+// forward: dy_k = Phicl_k dy_{k-1} + ct_k, k = 0..N-1; dY[k] holds ct_k on entry and dy_k on exit
+template <class BLK> GD void forward_sweep_1w(BLK& K) {
+    constexpr int n = BLK::n, C = 64 / n;
+    const int tid = K.tid, N = K.N;
+    const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
+    double row[n], rown[n], cv, cvn = 0, yval = 0.0;
+    auto fetch = [&](int k0, double* r, double& c) {
+        const int kk = k0 + g;
+        const bool ok = kk < N;
+#pragma unroll
+        for (int l = 0; l < n; l++) r[l] = ok ? K.Phicl[(size_t)kk * n * n + i * n + l] : 0.0;
+        c = ok ? K.dY[kk * n + i] : 0.0;
+    };
+    fetch(0, row, cv);
+    K.sync();
+    for (int k0 = 0; k0 < N; k0 += C) {
+        if (k0 + C < N) fetch(k0 + C, rown, cvn);
+#pragma unroll
+        for (int gs = 0; gs < C; gs++) {
+            if (k0 + gs < N) {
+                const int sg = (gs == 0) ? C - 1 : gs - 1;
+                double s = cv;
+#pragma unroll
+                for (int l = 0; l < n; l++) s += row[l] * readlane_f64(yval, sg * n + l);
+                yval = (g == gs) ? s : yval;
+            }
+        }
+        {
+            const int kk = k0 + g;
+            if (tid < C * n && kk < N) K.dY[kk * n + i] = yval;
+        }
+#pragma unroll
+        for (int l = 0; l < n; l++) row[l] = rown[l];
+        cv = cvn;
+    }
+    K.sync();
+}
+
+template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail) {
+    if constexpr (BLK::ONE) factor_sweep_1w<MODEL>(K, fail); else factor_sweep_mw<MODEL>(K, fail);
+}
+template <class BLK> GD void backward_sweep(BLK& K) {
+    if constexpr (BLK::ONE) backward_sweep_1w(K); else backward_sweep_mw(K);
+}
+template <class BLK> GD void forward_sweep(BLK& K) {
+    if constexpr (BLK::ONE) forward_sweep_1w(K); else forward_sweep_mw(K);
 }
 
 // ---- the interior point method ---------------------------------------------------------------------
@@ -717,7 +1022,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                     double s = gy[i];
 #pragma unroll
                     for (int l = 0; l < m; l++) s -= K.Kg[(size_t)k * m * n + l * n + i] * quk[l];
-                    K.pv[k * n + i] = s;
+                    K.pv[k * n + i] = s + (k >= 1 ? K.rv[(k - 1) * n + i] : 0.0);   // qq_k = qt_k + r_{k-1}
                 }
             }
             K.sync();
@@ -744,7 +1049,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                     for (int i = 0; i < n * m; i++) Gamk[i] *= hdt;
                 }
 #pragma unroll
-                for (int i = 0; i < n; i++) tt[i] = K.pv[k * n + i] + K.rv[k * n + i];
+                for (int i = 0; i < n; i++) tt[i] = K.pv[k * n + i];   // pt_k = p_k + r_k
 #pragma unroll
                 for (int i = 0; i < m; i++) {
                     double s = K.qu[k * m + i];
@@ -861,7 +1166,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 if (k + 1 < N) {  // nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g
 #pragma unroll
                     for (int i = 0; i < n; i++) {
-                        double s = K.pv[k * n + i];
+                        double s = K.pv[k * n + i] - K.rv[k * n + i];
 #pragma unroll
                         for (int l = 0; l < n; l++)
                             s += K.Paft[(size_t)k * n * n + i * n + l] * K.dY[k * n + l] +

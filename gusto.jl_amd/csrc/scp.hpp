@@ -4,6 +4,10 @@
 #pragma once
 #include "ipm.hpp"
 
+#ifndef GUSTO_WAVES_PER_EU
+#define GUSTO_WAVES_PER_EU 1
+#endif
+
 namespace gusto {
 
 // cost_true: trapezoid control effort (freeflyer_se2.jl:66-76)
@@ -71,8 +75,8 @@ template <class BLK> GD void store_traj(BLK& K, const double* Xs, const double* 
     for (int e = K.tid; e < K.N * m; e += K.nt()) Ug[e] = Us[e];
 }
 
-template <int MODEL, bool ONEWAVE> __global__ void __launch_bounds__(ONEWAVE ? 64 : 256)
-__attribute__((amdgpu_waves_per_eu(1, 1))) scp_kernel(const KParams P) {
+template <int MODEL, bool ONEWAVE> __global__ void __launch_bounds__(ONEWAVE ? 64 : 256, GUSTO_WAVES_PER_EU)
+scp_kernel(const KParams P) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m;
     extern __shared__ double lds[];
