@@ -229,6 +229,14 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
             s += add;
             if (e < NPG) K.sT[e] = s; else K.sZ[e - NPG] = s;
         }
+        for (int e = tid; e < 2 * n; e += NT) {  // r_k = P_k c_k and Pi_k^T c_k
+            const bool isr = e < n;
+            const int i = isr ? e : e - n;
+            double s = 0;
+#pragma unroll
+            for (int l = 0; l < n; l++) s += (isr ? K.sP[i * n + l] : K.sPi[l * n + i]) * K.cv[k * n + l];
+            (isr ? K.rv : K.nun)[k * n + i] = s;
+        }
         K.sync();
         // phase 2: Hh = QQ + [Phi Gam]^T T (one triangle, mirrored)
 #pragma unroll
@@ -426,6 +434,38 @@ template <class BLK> GD void forward_sweep_mw(BLK& K) {
 }
 
 
+// Compact by-value view of a problem for the one-wave sweeps (only what their knot loops touch).  Out-of-line
+// (noinline) sweeps were measured and are slower on gfx950: the calls force ABI spills in the caller.
+template <int MODEL> struct SweepView {
+    using T = MT<MODEL>;
+    using C = LdsC<MODEL>;
+    static constexpr int n = T::n, m = T::m, NZ = n + m;
+    static constexpr bool ONE = true;
+    double *lds, *sP, *sPi, *sPG, *sT, *sHh, *sZ, *sK, *sD, *sW, *sV, *sGd;
+    int* lut;
+    double *cv, *rv, *nun, *pv, *dY;
+    double *PG, *QQ, *Paft, *Piaft, *Kg, *Sinvg, *Dg, *Phicl;
+    const gusto_model_params* mpp;
+    struct PW { const gusto_model_params& mp; } ;
+    int tid, N;
+    double dt;
+    unsigned goalmask;
+    GD void sync() const { blk_sync<true>(); }
+    GD const double* PGk(int k) const { return PG + (size_t)(T::LTI ? 0 : k) * n * NZ; }
+    GD bool is_goal(int i) const { return (goalmask >> i) & 1u; }
+    template <class BLK> GD static SweepView make(const BLK& K) {
+        SweepView v;
+        v.lds = K.lds;
+        v.sP = K.lds + C::sP; v.sPi = K.lds + C::sPi; v.sPG = K.lds + C::sPG; v.sT = K.lds + C::sT; v.sHh = K.lds + C::sHh;
+        v.sZ = K.lds + C::sZ; v.sK = K.lds + C::sK; v.sD = K.lds + C::sD; v.sW = K.lds + C::sW; v.sV = K.lds + C::sV;
+        v.sGd = K.lds + C::sGd; v.lut = K.lut;
+        v.cv = K.cv; v.rv = K.rv; v.nun = K.nun; v.pv = K.pv; v.dY = K.dY;
+        v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.Kg = K.Kg; v.Sinvg = K.Sinvg; v.Dg = K.Dg;
+        v.Phicl = K.Phicl; v.mpp = &K.P.mp; v.tid = K.tid; v.N = K.N; v.dt = K.dt; v.goalmask = K.goalmask;
+        return v;
+    }
+};
+
 // ---- one-wave variants: every lane's role and LDS addresses are fixed before the knot loop ---------------
 GD double readlane_f64(double v, int lane) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -436,13 +476,13 @@ GD double readlane_f64(double v, int lane) {
 
 // LDS buffer holding [Phi Gam] of knot k: knot 0 has its own ([0 | b_0], x_1 is pinned), LTI models one more,
 // time-varying models double-buffer.
-template <int MODEL, class BLK> GD double* pg_buf(BLK& K, int k) {
+template <int MODEL, class BLK> GD double* pg_buf(const BLK& K, int k) {
     using T = MT<MODEL>;
     constexpr int NPG = T::n * (T::n + T::m);
     return K.sPG + (k == 0 ? 2 * NPG : (T::LTI ? 0 : (k & 1) * NPG));
 }
 
-template <int MODEL, class BLK> GD void factor_sweep_1w(BLK& K, double* fail) {
+template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n;
     constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64;
@@ -468,7 +508,7 @@ template <int MODEL, class BLK> GD void factor_sweep_1w(BLK& K, double* fail) {
     // knot-0 operands [0 | b_0] and, for LTI models, the one [Phi Gam] block
     {
         double B[n * m];
-        Dyn<MODEL>::B(K.P.mp, B);
+        Dyn<MODEL>::B(*K.mpp, B);
 #pragma unroll
         for (int r = 0; r < RT; r++) {
             const int e = tid + 64 * r;
@@ -539,6 +579,19 @@ template <int MODEL, class BLK> GD void factor_sweep_1w(BLK& K, double* fail) {
                 if (k == N - 1 && K.is_goal(zG[r])) s += 0.5 * (PGs[zG[r] * NZ + zJ[r]] + ((zJ[r] == zG[r]) ? 1.0 : 0.0));
                 K.sZ[tid + 64 * r] = s;
             }
+        }
+        // phase 1c: r_k = P_k c_k and Pi_k^T c_k (consumed by the stage-parallel right-hand-side blocks)
+        for (int e = tid; e < 2 * n; e += 64) {
+            const bool isr = e < n;
+            const int i = isr ? e : e - n;
+            double a[n], bb[n];
+#pragma unroll
+            for (int l = 0; l < n; l++) { a[l] = isr ? K.sP[i * n + l] : K.sPi[l * n + i]; bb[l] = K.cv[k * n + l]; }
+            __builtin_amdgcn_sched_barrier(0);
+            double s = 0;
+#pragma unroll
+            for (int l = 0; l < n; l++) s += a[l] * bb[l];
+            (isr ? K.rv : K.nun)[k * n + i] = s;
         }
         K.sync();
         // phase 2: Hh = QQ + [Phi Gam]^T T (one triangle, mirrored)
@@ -641,7 +694,7 @@ template <int MODEL, class BLK> GD void factor_sweep_1w(BLK& K, double* fail) {
 //
 // backward: pt_{k-1} = Phicl_k^T pt_k + qq_k, k = N-1..1, pt := p + r (so qq_k = qt_k + r_{k-1}), pt_{N-1} = r_{N-1}.
 //           pv[k] holds qq_k on entry and pt_k on exit.
-template <class BLK> GD void backward_sweep_1w(BLK& K) {
+template <class BLK> GD void backward_sweep_1w(BLK K) {
     constexpr int n = BLK::n, C = 64 / n;
     const int tid = K.tid, N = K.N;
     const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
@@ -681,7 +734,7 @@ template <class BLK> GD void backward_sweep_1w(BLK& K) {
 }
 
 // forward: dy_k = Phicl_k dy_{k-1} + ct_k, k = 0..N-1; dY[k] holds ct_k on entry and dy_k on exit
-template <class BLK> GD void forward_sweep_1w(BLK& K) {
+template <class BLK> GD void forward_sweep_1w(BLK K) {
     constexpr int n = BLK::n, C = 64 / n;
     const int tid = K.tid, N = K.N;
     const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
@@ -719,13 +772,13 @@ template <class BLK> GD void forward_sweep_1w(BLK& K) {
 }
 
 template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail) {
-    if constexpr (BLK::ONE) factor_sweep_1w<MODEL>(K, fail); else factor_sweep_mw<MODEL>(K, fail);
+    if constexpr (BLK::ONE) factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail); else factor_sweep_mw<MODEL>(K, fail);
 }
-template <class BLK> GD void backward_sweep(BLK& K) {
-    if constexpr (BLK::ONE) backward_sweep_1w(K); else backward_sweep_mw(K);
+template <int MODEL, class BLK> GD void backward_sweep(BLK& K) {
+    if constexpr (BLK::ONE) backward_sweep_1w(SweepView<MODEL>::make(K)); else backward_sweep_mw(K);
 }
-template <class BLK> GD void forward_sweep(BLK& K) {
-    if constexpr (BLK::ONE) forward_sweep_1w(K); else forward_sweep_mw(K);
+template <int MODEL, class BLK> GD void forward_sweep(BLK& K) {
+    if constexpr (BLK::ONE) forward_sweep_1w(SweepView<MODEL>::make(K)); else forward_sweep_mw(K);
 }
 
 // ---- the interior point method ---------------------------------------------------------------------
@@ -781,7 +834,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     pf.tick(PF_INIT);
 
     int status = GUSTO_SOLVER_FAILED, it = 0;
-    double res_p = 0, res_d = 0, mu = 0;
+    double res_p = 0, res_d = 0, mu = 0, alpha_prev = 0.0;
     for (it = 0;; it++) {
         // (1) linearised xdot at each knot: a_k = f_k + A_k (x_k - xp_k) + B (u_k - up_k)
         if (act) {
@@ -836,7 +889,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             }
 #pragma unroll
             for (int i = 0; i < n; i++) K.rd[k * n + i] = rdk[i];
-            OpResidHess<n, m> op{rs, Hx, Hu, rdx, rdu};
+            OpResidHess<n, m> op{rs, Hx, Hu, rdx, rdu, alpha_prev};
             visit_rows<MODEL>(ctx, xs, us, op);
             l_comp = op.comp;
             l_resp = nanmax(l_resp, op.maxrp);
@@ -964,18 +1017,27 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         // (4) factorise
         factor_sweep<MODEL>(K, fail);
         pf.tick(PF_FACTOR);
-        if (k == 0) {  // Gd^-1 with an identity block on the coordinates without a point goal
-            for (int i = 0; i < n; i++)
-                if (!K.is_goal(i)) K.sGd[i * n + i] = 1.0;
-            if (!inv_spd_rt(K.sGd, K.sP, K.sGd + n * n, n)) *fail = 1.0;  // sP <- Gd^-1
-        }
-        if (act) {  // r_k = P_k c_k
+        if (k == 0) {  // Gd^-1 with an identity block on the coordinates without a point goal -> sP
+            if constexpr (n <= 8) {
+                double G[n * n], Li[n * n];
 #pragma unroll
-            for (int i = 0; i < n; i++) {
-                double s = 0;
+                for (int i = 0; i < n; i++)
 #pragma unroll
-                for (int l = 0; l < n; l++) s += K.Paft[(size_t)k * n * n + i * n + l] * K.cv[k * n + l];
-                K.rv[k * n + i] = s;
+                    for (int j = 0; j < n; j++) G[i * n + j] = (i == j && !K.is_goal(i)) ? 1.0 : K.sGd[i * n + j];
+                if (!chol_inv<n>(G, Li)) *fail = 1.0;
+#pragma unroll
+                for (int i = 0; i < n; i++)
+#pragma unroll
+                    for (int j = 0; j < n; j++) {
+                        double s2 = 0;
+#pragma unroll
+                        for (int l = 0; l < n; l++) if (l >= i && l >= j) s2 += Li[l * n + i] * Li[l * n + j];
+                        K.sP[i * n + j] = s2;
+                    }
+            } else {
+                for (int i = 0; i < n; i++)
+                    if (!K.is_goal(i)) K.sGd[i * n + i] = 1.0;
+                if (!inv_spd_rt(K.sGd, K.sP, K.sGd + n * n, n)) *fail = 1.0;
             }
         }
         K.sync();
@@ -1027,7 +1089,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             }
             K.sync();
             pf.tick(PF_RHS);
-            backward_sweep(K);
+            backward_sweep<MODEL>(K);
             pf.tick(PF_BACK);
             // feed-forward d0 = S^-1 lu and the goal multiplier
             double th[n], d0[m];
@@ -1067,9 +1129,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 // theta_j = sum_k Pi_k^T c_k - D_k^T lu_k  (+ C M rd_{N-1} - rg at the last knot)
 #pragma unroll
                 for (int j = 0; j < n; j++) {
-                    double s = 0;
-#pragma unroll
-                    for (int i = 0; i < n; i++) s += K.Piaft[(size_t)k * n * n + i * n + j] * K.cv[k * n + i];
+                    double s = K.nun[k * n + j];   // Pi_k^T c_k from the factor sweep (nun is free until the corrector's costates)
 #pragma unroll
                     for (int i = 0; i < m; i++) s -= K.Dg[(size_t)k * m * n + i * n + j] * lu[i];
                     if (k == N - 1 && K.is_goal(j)) {
@@ -1125,11 +1185,11 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             }
             K.sync();
             pf.tick(PF_MID);
-            forward_sweep(K);
+            forward_sweep<MODEL>(K);
             pf.tick(PF_FWD);
             // primal step of this knot, the new costates, row steps + fraction to the boundary
             const double tau = pass ? fmax(0.995, 1.0 - mu) : 1.0;
-            double l_amax = 1.0;
+            double l_amax = 1.0, l_c0 = 0, l_c1 = 0, l_c2 = 0;
             if (act) {
                 double dxs[n], dus[m], dyp[n];
 #pragma unroll
@@ -1163,7 +1223,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 }
 #pragma unroll
                 for (int i = 0; i < n; i++) K.dXs[k * n + i] = dxs[i];
-                if (k + 1 < N) {  // nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g
+                if (k + 1 < N && (pass == 1 || ncomp == 0)) {  // nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g
 #pragma unroll
                     for (int i = 0; i < n; i++) {
                         double s = K.pv[k * n + i] - K.rv[k * n + i];
@@ -1178,10 +1238,10 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 load_iter(xs, us);
                 OpStep op{rs, dxs, dus, pass, mu_t, tau};
                 visit_rows<MODEL>(ctx, xs, us, op);
-                l_amax = op.amax;
+                l_amax = op.amax; l_c0 = op.c0; l_c1 = op.c1; l_c2 = op.c2;
             }
             K.sync();
-            if (k == 0) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0
+            if (k == 0 && (pass == 1 || ncomp == 0)) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0
                 double Ad[n * n], x0[n], u0[m];
 #pragma unroll
                 for (int i = 0; i < n; i++) x0[i] = K.Xp[i];
@@ -1199,15 +1259,9 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             const double a_max = block_reduce(l_amax, OpMin(), red);
             alpha = a_max;
             if (pass == 0) {
-                double l_ca = 0;
-                if (act) {
-                    double xs[n], us[m];
-                    load_iter(xs, us);
-                    OpAff op{rs, a_max};
-                    visit_rows<MODEL>(ctx, xs, us, op);
-                    l_ca = op.comp;
-                }
-                const double ca = block_reduce(l_ca, OpSum(), red);
+                const double q0 = block_reduce(l_c0, OpSum(), red), q1 = block_reduce(l_c1, OpSum(), red),
+                             q2 = block_reduce(l_c2, OpSum(), red);
+                const double ca = q0 + a_max * (q1 + a_max * q2);   // complementarity after the affine step
                 const double mu_aff = ncomp > 0 ? ca / ncomp : 0.0;
                 const double rr = (mu > 0) ? mu_aff / mu : 0.0;
                 sigma = rr * rr * rr;
@@ -1229,9 +1283,8 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             }
 #pragma unroll
             for (int i = 0; i < m; i++) { us[i] += alpha * K.dUs[k * m + i]; K.Uw[k * m + i] = us[i]; }
-            OpUpdate op{rs, alpha};
-            visit_rows<MODEL>(ctx, xs, us, op);
         }
+        alpha_prev = alpha;   // the row state is advanced by the next residual pass
         if (k == 0) {
             for (int i = 0; i < n; i++) mug[i] += alpha * (mugn[i] - mug[i]);
         }

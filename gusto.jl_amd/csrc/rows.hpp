@@ -108,8 +108,8 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
             mk &= mk - 1;
             double b[T::WS];
 #pragma unroll
-            for (int j = 0; j < T::WS; j++) b[j] = -c.obs_nh[((size_t)i * T::WS + j) * c.N + c.k];
-            lin_row<false, 0, T::WS>(op, slot_obs + i, ROW_PEN, xs, b, c.obs_c0[(size_t)i * c.N + c.k], kw, 0.0);
+            for (int j = 0; j < T::WS; j++) b[j] = -(c.obs_nh + (size_t)(i * T::WS + j) * (size_t)c.N)[c.k];
+            lin_row<false, 0, T::WS>(op, slot_obs + i, ROW_PEN, xs, b, (c.obs_c0 + (size_t)i * (size_t)c.N)[c.k], kw, 0.0);
         }
         if (c.k < c.N - 1) {  // cci_*_accel_bound on k = 1..N-1 only (freeflyer_se2.jl:236-245,380-381)
             constexpr int nf = is2 ? 2 : 3, im = is2 ? 2 : 3, nm = is2 ? 1 : 3;
@@ -155,7 +155,9 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
 struct RowState {
     double* base;
     int nslot, N, k;
-    GD double& at(int var, int slot) const { return base[((size_t)var * nslot + slot) * N + k]; }
+    // uniform (scalar) row base + per-lane knot index: lets the compiler use the SGPR-base + VGPR-offset form of
+    // global_load/store instead of materialising (and hoisting, and spilling) one 64-bit VGPR address per row
+    GD double& at(int var, int slot) const { return (base + (size_t)(var * nslot + slot) * (size_t)N)[k]; }
 };
 
 // ---- the Ops ---------------------------------------------------------------------------------------
@@ -176,20 +178,33 @@ struct OpInit {
     }
 };
 
-// residuals + condensed Hessian:  H += sigma * grad grad^T + lam * hess,  dual residual += lam * grad
+// residuals + condensed Hessian:  H += sigma * grad grad^T + lam * hess,  dual residual += lam * grad.
+// The row update of the previous interior point step (t += alpha dt, ...) is folded into this pass.
 template <int n, int m> struct OpResidHess {
     RowState rs;
     double *Hx, *Hu, *rdx, *rdu;
+    double alpha_prev;  // 0 on the first trip
     double comp = 0, maxrp = 0;
     template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
-        const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
+        double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
         double sig, rp;
+        if (alpha_prev != 0.0) {
+            const double dl = rs.at(RS_DL, slot);
+            t += alpha_prev * rs.at(RS_DT, slot);
+            lam += alpha_prev * dl;
+            rs.at(RS_T, slot) = t; rs.at(RS_LAM, slot) = lam;
+        }
         if (row_is_hard(kind)) {
             rp = ev.g + t;
             comp += t * lam;
             sig = lam / t;
         } else {
-            const double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
+            double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
+            if (alpha_prev != 0.0) {
+                s += alpha_prev * rs.at(RS_DS, slot);
+                lamb -= alpha_prev * rs.at(RS_DL, slot);
+                rs.at(RS_S, slot) = s; rs.at(RS_LAMB, slot) = lamb;
+            }
             rp = ev.g - s + t;
             comp += t * lam + s * lamb;
             sig = lam / (t + lam * s / lamb);
@@ -240,13 +255,15 @@ GD double max_step(double a, double v, double dv, double tau) {
     return a;
 }
 
-// row steps (dt, dlam, ds) from the primal step and the fraction-to-boundary step length
+// row steps (dt, dlam, ds) from the primal step and the fraction-to-boundary step length.  In the predictor pass
+// the complementarity after a step alpha is accumulated as c0 + c1 alpha + c2 alpha^2 (so no second row pass is
+// needed once alpha_aff is known) and the Mehrotra second-order terms are stored.
 struct OpStep {
     RowState rs;
     const double *dxs, *dus;
     int pass;
     double mu_t, tau;
-    double amax = 1.0;
+    double amax = 1.0, c0 = 0, c1 = 0, c2 = 0;
     template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
         const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
         const double ka = pass ? rs.at(RS_KA, slot) : 0.0;
@@ -271,41 +288,12 @@ struct OpStep {
             dt = -rp - w + ds;
             amax = max_step(amax, s, ds, tau);
             amax = max_step(amax, lamb, -dl, tau);
+            if (pass == 0) { c0 += s * lamb; c1 += ds * lamb - s * dl; c2 -= ds * dl; rs.at(RS_KB, slot) = -ds * dl; }
         }
         amax = max_step(amax, t, dt, tau);
         amax = max_step(amax, lam, dl, tau);
+        if (pass == 0) { c0 += t * lam; c1 += dt * lam + t * dl; c2 += dt * dl; rs.at(RS_KA, slot) = dt * dl; }
         rs.at(RS_DT, slot) = dt; rs.at(RS_DL, slot) = dl; rs.at(RS_DS, slot) = ds;
-    }
-};
-
-// complementarity after the affine step + Mehrotra second-order terms
-struct OpAff {
-    RowState rs;
-    double a_aff;
-    double comp = 0;
-    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>&) {
-        const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
-        const double dt = rs.at(RS_DT, slot), dl = rs.at(RS_DL, slot), ds = rs.at(RS_DS, slot);
-        comp += (t + a_aff * dt) * (lam + a_aff * dl);
-        if (!row_is_hard(kind)) {
-            const double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
-            comp += (s + a_aff * ds) * (lamb - a_aff * dl);
-        }
-        rs.at(RS_KA, slot) = dt * dl;
-        rs.at(RS_KB, slot) = -ds * dl;
-    }
-};
-
-struct OpUpdate {
-    RowState rs;
-    double alpha;
-    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>&) {
-        rs.at(RS_T, slot) += alpha * rs.at(RS_DT, slot);
-        rs.at(RS_LAM, slot) += alpha * rs.at(RS_DL, slot);
-        if (!row_is_hard(kind)) {
-            rs.at(RS_S, slot) += alpha * rs.at(RS_DS, slot);
-            rs.at(RS_LAMB, slot) -= alpha * rs.at(RS_DL, slot);
-        }
     }
 };
 
@@ -313,7 +301,7 @@ struct OpSlackSum {
     RowState rs;
     double sum = 0;
     template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>&) {
-        if (!row_is_hard(kind)) sum += rs.at(RS_S, slot);
+        if (!row_is_hard(kind)) sum += rs.at(RS_S, slot);   // (the last residual pass already applied every update)
     }
 };
 
