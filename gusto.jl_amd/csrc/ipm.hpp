@@ -788,7 +788,8 @@ template <int MODEL, class BLK> GD void forward_sweep(BLK& K) {
 template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double omega, IpmOut& out, Prof& pf) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NHX = n * (n + 1) / 2, NHU = m * (m + 1) / 2, NQ = NZ * (NZ + 1) / 2;
-    const int k = K.tid, N = K.N;
+    int k = K.tid;
+    const int N = K.N;
     const bool act = k < N;
     const gusto_ipm_opts& io = K.P.io;
     const double kappa = 1.0 / fmax(1.0, omega);
@@ -805,6 +806,14 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     ctx.xp = K.Xp + (act ? k : 0) * n; ctx.mask = act ? K.obs_mask[k] : 0; ctx.obs_nh = K.obs_nh; ctx.obs_c0 = K.obs_c0;
     ctx.goal_lo = K.goal_lo; ctx.goal_hi = K.goal_hi;
     RowState rs{K.rowstate, K.P.wl.nslot, N, act ? k : 0};
+    // The knot index is made opaque at every phase boundary: otherwise the compiler hoists each phase's address
+    // arithmetic out of the interior point loop and its registers (hundreds) stay live across the sweeps.
+#define GUSTO_REFRESH_K()                                     \
+    do {                                                      \
+        asm volatile("" : "+v"(k));                           \
+        ctx.k = k; rs.k = act ? k : 0;                        \
+        ctx.xp = K.Xp + (act ? k : 0) * n;                    \
+    } while (0)
 
     auto load_iter = [&](double* xs, double* us) {
 #pragma unroll
@@ -836,6 +845,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     int status = GUSTO_SOLVER_FAILED, it = 0;
     double res_p = 0, res_d = 0, mu = 0, alpha_prev = 0.0;
     for (it = 0;; it++) {
+        GUSTO_REFRESH_K();
         // (1) linearised xdot at each knot: a_k = f_k + A_k (x_k - xp_k) + B (u_k - up_k)
         if (act) {
             double xs[n], us[m], xpk[n], upk[m], fp[n], Ad[n * n], Bd[n * m];
@@ -1017,6 +1027,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         // (4) factorise
         factor_sweep<MODEL>(K, fail);
         pf.tick(PF_FACTOR);
+        GUSTO_REFRESH_K();
         if (k == 0) {  // Gd^-1 with an identity block on the coordinates without a point goal -> sP
             if constexpr (n <= 8) {
                 double G[n * n], Li[n * n];
@@ -1047,6 +1058,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         // (5) predictor (mu_t = 0) and centred corrector share the factorisation
         double sigma = 0, mu_t = 0, alpha = 1.0;
         for (int pass = 0; pass < 2; pass++) {
+            GUSTO_REFRESH_K();
             if (act) {  // right-hand side: qt_k = gy - K^T qu, qu = gu + b^T gy, gy = Qt rd + M^T gx
                 double xs[n], us[m], gx[n], gu[m], quk[m], gy[n], Bd[n * m];
                 load_iter(xs, us);
@@ -1091,6 +1103,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             pf.tick(PF_RHS);
             backward_sweep<MODEL>(K);
             pf.tick(PF_BACK);
+            GUSTO_REFRESH_K();
             // feed-forward d0 = S^-1 lu and the goal multiplier
             double th[n], d0[m];
 #pragma unroll
@@ -1187,6 +1200,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             pf.tick(PF_MID);
             forward_sweep<MODEL>(K);
             pf.tick(PF_FWD);
+            GUSTO_REFRESH_K();
             // primal step of this knot, the new costates, row steps + fraction to the boundary
             const double tau = pass ? fmax(0.995, 1.0 - mu) : 1.0;
             double l_amax = 1.0, l_c0 = 0, l_c1 = 0, l_c2 = 0;
@@ -1271,6 +1285,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         }
         pf.tick(PF_STEP);
         // (6) update
+        GUSTO_REFRESH_K();
         K.sync();
         if (act) {
             double xs[n], us[m];
@@ -1304,6 +1319,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     }
     const double obj = block_reduce(l_obj, OpSum(), red);
     K.sync();
+#undef GUSTO_REFRESH_K
     out.status = status; out.iters = it; out.obj = obj / kappa; out.res_p = res_p; out.res_d = res_d; out.mu = mu;
 }
 
