@@ -209,8 +209,18 @@ template <int n> GD bool inv_gauss_jordan(const double* A, double* Ainv) {
     return ok;
 }
 
+// 1/sqrt(d) to double precision: v_rsq_f64 seed (~2^-26) + two Newton-Raphson steps, ~14 dependent flops
+// instead of the ~40 of sqrt() followed by a division -- the Cholesky of the m x m block sits on the critical
+// path of every knot of the factor sweep.
+GD double rsqrt_nr(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    r = r * (1.5 - h * r * r);
+    r = r * (1.5 - h * r * r);
+    return r;
+}
+
 // Cholesky S = L L^T on register arrays: returns Li = L^-1 (lower, row-major m x m); false if not PD.
-// One sqrt and one division per column (r = 1/sqrt(d); L_jj = d r).
 template <int m> GD bool chol_inv(const double* S, double* Li) {
     double L[m][m], r[m];
     bool ok = true;
@@ -224,7 +234,7 @@ template <int m> GD bool chol_inv(const double* S, double* Li) {
 #pragma unroll
         for (int l = 0; l < j; l++) d -= L[j][l] * L[j][l];
         if (!(d > 0.0)) ok = false;
-        r[j] = 1.0 / sqrt(d);
+        r[j] = rsqrt_nr(d);
         L[j][j] = d * r[j];
 #pragma unroll
         for (int i = j + 1; i < m; i++) {

@@ -482,31 +482,25 @@ template <int MODEL, class BLK> GD double* pg_buf(const BLK& K, int k) {
     return K.sPG + (k == 0 ? 2 * NPG : (T::LTI ? 0 : (k & 1) * NPG));
 }
 
+// Two LDS phases per knot (the dependency chain is P_k -> H -> P_{k-1}):
+//   AB: H = QQ + [Phi Gam]^T (P [Phi Gam]) entry-per-lane (each lane forms the column of P [Phi Gam] it needs itself
+//       instead of waiting for a shared T), Z = [Phi Gam]^T Pi (+E), r_k = P_k c_k, Pi_k^T c_k
+//   CD: every lane factors the m x m block S itself, forms the columns of W = L^-1 Hyu^T, V = L^-1 Zu it needs and
+//       writes P' = Hyy - W^T W, Pi' = Zy - W^T V, Phicl = Phi - Gam K, Gd += V^T V (Schur complements never
+//       through an explicit S^-1: with barrier weights ~1/mu in Hyy that loses every digit).
 template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail) {
     using T = MT<MODEL>;
-    constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n;
-    constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64;
+    constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n, NZN = NZ * n;
+    constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64, RZ = (NZN + 63) / 64;
     const int tid = K.tid, N = K.N;
-    // fixed roles: T/Z entries (phase 1), packed H entries (phase 2), n x n entries (phase 4)
-    int tI[RT], tJ[RT], zJ[RT], zG[RT], hI[RQ], hJ[RQ], nI[RN], nJ[RN];
+    int zJ[RZ], zG[RZ], hI[RQ], hJ[RQ], nI[RN], nJ[RN];
 #pragma unroll
-    for (int r = 0; r < RT; r++) {
-        const int e = tid + 64 * r;
-        tI[r] = (e < NPG) ? e / NZ : 0; tJ[r] = (e < NPG) ? e % NZ : 0;
-        zJ[r] = (e < NPG) ? e / n : 0; zG[r] = (e < NPG) ? e % n : 0;
-    }
+    for (int r = 0; r < RZ; r++) { const int e = tid + 64 * r; zJ[r] = (e < NZN) ? e / n : 0; zG[r] = (e < NZN) ? e % n : 0; }
 #pragma unroll
-    for (int r = 0; r < RQ; r++) {
-        const int e = tid + 64 * r, ij = (e < NQ) ? K.lut[e] : 0;
-        hI[r] = ij >> 8; hJ[r] = ij & 255;
-    }
+    for (int r = 0; r < RQ; r++) { const int e = tid + 64 * r, ij = (e < NQ) ? K.lut[e] : 0; hI[r] = ij >> 8; hJ[r] = ij & 255; }
 #pragma unroll
-    for (int r = 0; r < RN; r++) {
-        const int e = tid + 64 * r;
-        nI[r] = (e < NN) ? e / n : 0; nJ[r] = (e < NN) ? e % n : 0;
-    }
-    // knot-0 operands [0 | b_0] and, for LTI models, the one [Phi Gam] block
-    {
+    for (int r = 0; r < RN; r++) { const int e = tid + 64 * r; nI[r] = (e < NN) ? e / n : 0; nJ[r] = (e < NN) ? e % n : 0; }
+    {   // knot-0 operands [0 | b_0] and the [Phi Gam] block of knot N-1
         double B[n * m];
         Dyn<MODEL>::B(*K.mpp, B);
 #pragma unroll
@@ -539,36 +533,39 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail) {
     K.sync();
     for (int k = N - 1; k >= 0; k--) {
         const double* PGs = pg_buf<MODEL>(K, k);
-        // prefetch the operands of knot k-1
         double qqn[RQ];
 #pragma unroll
-        for (int r = 0; r < RQ; r++) {
-            const int e = tid + 64 * r;
-            qqn[r] = (k > 0 && e < NQ) ? K.QQ[(size_t)(k - 1) * NQ + e] : 0.0;
-        }
+        for (int r = 0; r < RQ; r++) { const int e = tid + 64 * r; qqn[r] = (k > 0 && e < NQ) ? K.QQ[(size_t)(k - 1) * NQ + e] : 0.0; }
         if (!T::LTI && k > 1) {
             const double* pg = K.PGk(k - 1);
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = (e < NPG) ? pg[e] : 0.0; }
         }
-        // phase 1a: T = P [Phi Gam]
+        // ---- phase AB -------------------------------------------------------------------------------
 #pragma unroll
-        for (int r = 0; r < RT; r++) {
-            if (tid + 64 * r < NPG) {
-                double a[n], bb[n];
+        for (int r = 0; r < RQ; r++) {
+            if (tid + 64 * r < NQ) {
+                double pgj[n], pgi[n], pm[n * n];
 #pragma unroll
-                for (int l = 0; l < n; l++) { a[l] = K.sP[tI[r] * n + l]; bb[l] = PGs[l * NZ + tJ[r]]; }
+                for (int l = 0; l < n; l++) { pgj[l] = PGs[l * NZ + hJ[r]]; pgi[l] = PGs[l * NZ + hI[r]]; }
+#pragma unroll
+                for (int e = 0; e < n * n; e++) pm[e] = K.sP[e];
                 __builtin_amdgcn_sched_barrier(0);
-                double s = 0;
+                double s = qq[r];
 #pragma unroll
-                for (int l = 0; l < n; l++) s += a[l] * bb[l];
-                K.sT[tid + 64 * r] = s;
+                for (int l = 0; l < n; l++) {
+                    double t = 0;   // (P [Phi Gam])[l][j]
+#pragma unroll
+                    for (int q = 0; q < n; q++) t += pm[l * n + q] * pgj[q];
+                    s += pgi[l] * t;
+                }
+                K.sHh[hI[r] * NZ + hJ[r]] = s;
+                K.sHh[hJ[r] * NZ + hI[r]] = s;
             }
         }
-        // phase 1b: Z = [Phi Gam]^T Pi (+ E at the last knot; E = [M^T C^T; b^T M^T C^T], M = (Phi+I)/2, M b = Gam/2)
 #pragma unroll
-        for (int r = 0; r < RT; r++) {
-            if (tid + 64 * r < NPG) {
+        for (int r = 0; r < RZ; r++) {
+            if (tid + 64 * r < NZN) {
                 double a[n], bb[n];
 #pragma unroll
                 for (int l = 0; l < n; l++) { a[l] = PGs[l * NZ + zJ[r]]; bb[l] = K.sPi[l * n + zG[r]]; }
@@ -576,12 +573,12 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail) {
                 double s = 0;
 #pragma unroll
                 for (int l = 0; l < n; l++) s += a[l] * bb[l];
+                // E = [M^T C^T; b^T M^T C^T], M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
                 if (k == N - 1 && K.is_goal(zG[r])) s += 0.5 * (PGs[zG[r] * NZ + zJ[r]] + ((zJ[r] == zG[r]) ? 1.0 : 0.0));
                 K.sZ[tid + 64 * r] = s;
             }
         }
-        // phase 1c: r_k = P_k c_k and Pi_k^T c_k (consumed by the stage-parallel right-hand-side blocks)
-        for (int e = tid; e < 2 * n; e += 64) {
+        for (int e = tid; e < 2 * n; e += 64) {   // r_k = P_k c_k and Pi_k^T c_k for the stage-parallel blocks
             const bool isr = e < n;
             const int i = isr ? e : e - n;
             double a[n], bb[n];
@@ -594,56 +591,59 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail) {
             (isr ? K.rv : K.nun)[k * n + i] = s;
         }
         K.sync();
-        // phase 2: Hh = QQ + [Phi Gam]^T T (one triangle, mirrored)
-#pragma unroll
-        for (int r = 0; r < RQ; r++) {
-            if (tid + 64 * r < NQ) {
-                double a[n], bb[n];
-#pragma unroll
-                for (int l = 0; l < n; l++) { a[l] = PGs[l * NZ + hI[r]]; bb[l] = K.sT[l * NZ + hJ[r]]; }
-                __builtin_amdgcn_sched_barrier(0);
-                double s = qq[r];
-#pragma unroll
-                for (int l = 0; l < n; l++) s += a[l] * bb[l];
-                K.sHh[hI[r] * NZ + hJ[r]] = s;
-                K.sHh[hJ[r] * NZ + hI[r]] = s;
-            }
-        }
-        K.sync();
-        // phase 3: block Cholesky of [S Hyu^T; Hyu Hyy]: L = chol(S), W = L^-1 Hyu^T, V = L^-1 Zu, K = L^-T W,
-        // D = L^-T V; one lane per column, each recomputes the m x m factor
-        if (tid < 2 * n || tid < m * m) {
+        // ---- phase CD -------------------------------------------------------------------------------
+        {
             double S[m * m], Li[m * m];
 #pragma unroll
             for (int i = 0; i < m; i++)
 #pragma unroll
                 for (int j = 0; j < m; j++) S[i * m + j] = K.sHh[(n + i) * NZ + n + j];
-            const bool isK = tid < n;
-            const int g = isK ? tid : tid - n;
-            double col[m], w[m], kk[m];
-#pragma unroll
-            for (int l = 0; l < m; l++) col[l] = (tid < 2 * n) ? (isK ? K.sHh[g * NZ + n + l] : K.sZ[(n + l) * n + g]) : 0.0;
             if (!chol_inv<m>(S, Li)) *fail = 1.0;
 #pragma unroll
-            for (int i = 0; i < m; i++) {
-                double s = 0;
+            for (int r = 0; r < RN; r++) {
+                const int e2 = tid + 64 * r;
+                if (e2 < NN) {
+                    const int i = nI[r], j = nJ[r];
+                    double hi[m], hj[m], zi[m], zj[m], gi[m];
 #pragma unroll
-                for (int l = 0; l <= i; l++) s += Li[i * m + l] * col[l];
-                w[i] = s;
-            }
+                    for (int l = 0; l < m; l++) {
+                        hi[l] = K.sHh[i * NZ + n + l]; hj[l] = K.sHh[j * NZ + n + l];
+                        zi[l] = K.sZ[(n + l) * n + i]; zj[l] = K.sZ[(n + l) * n + j];
+                        gi[l] = PGs[i * NZ + n + l];
+                    }
+                    double pn = K.sHh[i * NZ + j], ph = PGs[i * NZ + j], pin = K.sZ[i * n + j], gd = K.sGd[e2];
+                    __builtin_amdgcn_sched_barrier(0);
+                    double wi[m], wj[m], vi[m], vj[m], kj[m], dj[m];
 #pragma unroll
-            for (int i = 0; i < m; i++) {
-                double s = 0;
+                    for (int a = 0; a < m; a++) {   // W = L^-1 Hyu^T, V = L^-1 Zu (columns i and j)
+                        double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
 #pragma unroll
-                for (int l = i; l < m; l++) s += Li[l * m + i] * w[l];
-                kk[i] = s;
-            }
-            if (tid < 2 * n) {
-                double* sw = isK ? K.sW : K.sV;
-                double* sk = isK ? K.sK : K.sD;
-                double* gk = (isK ? K.Kg : K.Dg) + (size_t)k * m * n;
+                        for (int l = 0; l <= a; l++) {
+                            s1 += Li[a * m + l] * hi[l]; s2 += Li[a * m + l] * hj[l];
+                            s3 += Li[a * m + l] * zi[l]; s4 += Li[a * m + l] * zj[l];
+                        }
+                        wi[a] = s1; wj[a] = s2; vi[a] = s3; vj[a] = s4;
+                    }
 #pragma unroll
-                for (int i = 0; i < m; i++) { sw[i * n + g] = w[i]; sk[i * n + g] = kk[i]; gk[i * n + g] = kk[i]; }
+                    for (int a = 0; a < m; a++) {   // K = L^-T W, D = L^-T V (column j)
+                        double s1 = 0, s2 = 0;
+#pragma unroll
+                        for (int l = a; l < m; l++) { s1 += Li[l * m + a] * wj[l]; s2 += Li[l * m + a] * vj[l]; }
+                        kj[a] = s1; dj[a] = s2;
+                    }
+#pragma unroll
+                    for (int l = 0; l < m; l++) { pn -= wi[l] * wj[l]; ph -= gi[l] * kj[l]; pin -= wi[l] * vj[l]; gd += vi[l] * vj[l]; }
+                    K.sP[e2] = pn; K.sPi[e2] = pin; K.sGd[e2] = gd;
+                    K.Phicl[(size_t)k * NN + e2] = ph;
+                    if (k > 0) { K.Paft[(size_t)(k - 1) * NN + e2] = pn; K.Piaft[(size_t)(k - 1) * NN + e2] = pin; }
+                    if (i == 0) {   // the lanes of row 0 own column j of K and D
+#pragma unroll
+                        for (int a = 0; a < m; a++) {
+                            K.Kg[(size_t)k * m * n + a * n + j] = kj[a];
+                            K.Dg[(size_t)k * m * n + a * n + j] = dj[a];
+                        }
+                    }
+                }
             }
             if (tid < m * m) {  // S^-1 = L^-T L^-1 (feed-forward only)
                 const int i = tid / m, j = tid % m;
@@ -651,30 +651,6 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail) {
 #pragma unroll
                 for (int l = 0; l < m; l++) if (l >= i && l >= j) s += Li[l * m + i] * Li[l * m + j];
                 K.Sinvg[(size_t)k * m * m + tid] = s;
-            }
-        }
-        K.sync();
-        // phase 4: P' = Hyy - W^T W, Pi' = Zy - W^T V, Phicl = Phi - Gam K, Gd += V^T V (never through S^-1:
-        // with barrier weights ~1/mu in Hyy the explicit form loses every digit).  P', Pi' are the value function
-        // after knot k-1 and are stored as such.
-#pragma unroll
-        for (int r = 0; r < RN; r++) {
-            const int e2 = tid + 64 * r;
-            if (e2 < NN) {
-                const int i = nI[r], j = nJ[r];
-                double wi[m], wj[m], vj[m], vi[m], gi[m], kj[m];
-#pragma unroll
-                for (int l = 0; l < m; l++) {
-                    wi[l] = K.sW[l * n + i]; wj[l] = K.sW[l * n + j]; vj[l] = K.sV[l * n + j]; vi[l] = K.sV[l * n + i];
-                    gi[l] = PGs[i * NZ + n + l]; kj[l] = K.sK[l * n + j];
-                }
-                double pn = K.sHh[i * NZ + j], ph = PGs[i * NZ + j], pin = K.sZ[i * n + j], gd = K.sGd[e2];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int l = 0; l < m; l++) { pn -= wi[l] * wj[l]; ph -= gi[l] * kj[l]; pin -= wi[l] * vj[l]; gd += vi[l] * vj[l]; }
-                K.sP[e2] = pn; K.sPi[e2] = pin; K.sGd[e2] = gd;
-                K.Phicl[(size_t)k * NN + e2] = ph;
-                if (k > 0) { K.Paft[(size_t)(k - 1) * NN + e2] = pn; K.Piaft[(size_t)(k - 1) * NN + e2] = pin; }
             }
         }
         if (!T::LTI && k > 1) {
