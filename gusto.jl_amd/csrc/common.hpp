@@ -48,7 +48,7 @@ GD constexpr int sidx(int i, int j, int n) {
 // per-problem global workspace, offsets in doubles
 struct WsLayout {
     int nslot;
-    size_t rowstate, obs_nh, obs_c0, obs_mask, PG, QQ, Paft, Piaft, K, Sinv, D, Phicl, total;
+    size_t rowstate, obs_nh, obs_c0, obs_mask, PG, QQ, Paft, Piaft, K, Sinv, D, Phicl, pvt, total;
 };
 template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     using T = MT<MODEL>;
@@ -69,6 +69,7 @@ template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     L.Sinv = take((size_t)N * m * m);
     L.D = take((size_t)N * m * n);
     L.Phicl = take((size_t)N * n * n);
+    L.pvt = take((size_t)N * (3 * n + 3 * m));
     L.total = o;
     return L;
 }
@@ -82,8 +83,10 @@ template <int MODEL> struct LdsC {
                          sZ = sHh + NZ * NZ, sK = sZ + NZ * n, sD = sK + m * n, sW = sD + m * n, sV = sW + m * n,
                          sGd = sV + m * n, misc = sGd + 2 * n * n, lut = misc + 64,
                          vecs = lut + (NZ * (NZ + 1) / 2 + 1) / 2 + 1;
-    // per-knot vectors: n-vectors first (Xw Xp dY rd pv cv rv qrd nu nun dXs), then m-vectors (Uw Up qu dv dUs)
-    static constexpr int NVN = 11, NVM = 5;
+    // per-knot vectors shared between lanes: n-vectors (Xw dY pv cv rv nu nun) then the m-vector Uw; vectors only
+    // their own knot touches (rd qrd dXs | dUs qu dv) live in the per-problem global workspace, the linearisation
+    // point (Xp, Up) is read from the problem's trajectory in HBM/L2
+    static constexpr int NVN = 7, NVM = 1;
 };
 struct LdsLayout {
     int total;

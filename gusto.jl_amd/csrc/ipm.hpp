@@ -68,16 +68,20 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         sK = lds + C::sK; sD = lds + C::sD; sW = lds + C::sW; sV = lds + C::sV; sGd = lds + C::sGd; misc = lds + C::misc;
         lut = reinterpret_cast<int*>(lds + C::lut);
         double* v = lds + C::vecs;
-        Xw = v; Xp = v + N * n; dY = v + 2 * N * n; rd = v + 3 * N * n; pv = v + 4 * N * n; cv = v + 5 * N * n;
-        rv = v + 6 * N * n; qrd = v + 7 * N * n; nu = v + 8 * N * n; nun = v + 9 * N * n; dXs = v + 10 * N * n;
-        double* u = v + C::NVN * N * n;
-        Uw = u; Up = u + N * m; qu = u + 2 * N * m; dv = u + 3 * N * m; dUs = u + 4 * N * m;
+        Xw = v; dY = v + N * n; pv = v + 2 * N * n; cv = v + 3 * N * n; rv = v + 4 * N * n; nu = v + 5 * N * n;
+        nun = v + 6 * N * n;
+        Uw = v + C::NVN * N * n;
         double* w = P.ws + (size_t)b * P.wl.total;
         const WsLayout& W = P.wl;
         rowstate = w + W.rowstate; obs_nh = w + W.obs_nh; obs_c0 = w + W.obs_c0;
         obs_mask = reinterpret_cast<uint64_t*>(w + W.obs_mask);
         PG = w + W.PG; QQ = w + W.QQ; Paft = w + W.Paft; Piaft = w + W.Piaft; Kg = w + W.K; Sinvg = w + W.Sinv;
         Dg = w + W.D; Phicl = w + W.Phicl;
+        {   // knot-private vectors in the global workspace, the linearisation point = the stored trajectory
+            double* q = w + W.pvt;
+            rd = q; qrd = q + N * n; dXs = q + 2 * N * n; dUs = q + 3 * N * n; qu = dUs + N * m; dv = qu + N * m;
+            Xp = P.X + (size_t)b * N * n; Up = P.U + (size_t)b * N * m;
+        }
         x_init = P.x_init + (size_t)b * n; goal_lo = P.goal_lo + (size_t)b * n; goal_hi = P.goal_hi + (size_t)b * n;
         dt = P.tf[b] / (N - 1);  // Trajectory(X,U,Tf): dt = Tf/(N-1), types.jl:235
         goalmask = 0;

@@ -87,9 +87,6 @@ scp_kernel(const KParams P) {
     double* Ug = P.U + (size_t)b * N * m;
 
     if (P.mode == 1) {  // one convex subproblem around the stored (Xp,Up): parity hook
-        for (int e = tid; e < N * n; e += K.nt()) K.Xp[e] = Xg[e];
-        for (int e = tid; e < N * m; e += K.nt()) K.Up[e] = Ug[e];
-        K.sync();
         linearize<MODEL>(K, P.sub_toggle[b]);
         IpmOut io;
         ipm_solve<MODEL>(K, P.sub_Delta[b], P.sub_omega[b], io, pf);
@@ -110,10 +107,7 @@ scp_kernel(const KParams P) {
     int total_ipm = sti[ST_IPM], n_hist = sti[ST_NHIST], nJ = sti[ST_NJ], n_rho = sti[ST_NRHO];
     const int iter_cap = iterations + P.max_iter;  // scp_gusto.jl:67
 
-    for (int e = tid; e < N * n; e += K.nt()) K.Xp[e] = Xg[e];
-    for (int e = tid; e < N * m; e += K.nt()) K.Up[e] = Ug[e];
-    K.sync();
-
+    // K.Xp / K.Up are the stored trajectory (SCPS.traj) itself
     // scp_gusto.jl:73-76
     double Jt = cost_true(K, K.Up);
     double rho0v = trust_region_ratio<MODEL>(K, K.Xp, K.Up, K.Xp, K.Up);
@@ -213,7 +207,6 @@ scp_kernel(const KParams P) {
     }
     pf.tick(PF_SCP);
     pf.flush(P.prof);
-    store_traj(K, K.Xp, K.Up, Xg, Ug);
     if (tid == 0) {
         sti[ST_ITER] = iterations; sti[ST_CONV] = converged; sti[ST_SUCC] = successful; sti[ST_STOP] = stop;
         sti[ST_IPM] = total_ipm; sti[ST_NHIST] = n_hist; sti[ST_NJ] = nJ; sti[ST_NRHO] = n_rho;
