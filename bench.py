@@ -76,7 +76,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:      # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 

@@ -330,3 +330,62 @@ def test_host_mirror_solve_SCP_through_the_seam():
     for S in outs:
         assert S.converged and np.array_equal(S.traj.X, outs[0].traj.X)
     assert np.abs(outs[0].traj.X.T - r["X"]).max() < TRAJ_ATOL
+
+
+@pytest.mark.parametrize("N", [5, 33, 64, 65, 130])
+def test_horizon_edge_cases(N):
+    """Ragged and boundary horizons: 64 knots is the last one-wave size, 65 the first multi-wave (2 waves + real
+    barriers) one; small N exercises the chunked vector recurrences with fewer knots than one chunk."""
+    g, go = _mods()
+    P = g.problems
+    env = P.freeflyer_env()
+    x0, glo, ghi, tf = P.freeflyer_batch(6)
+    x0[0] = P.FREEFLYER_X_INIT
+    s = g.BatchSolver(g.FREEFLYER_SE2, N, 6, hist_cap=40, boxes=env)
+    s.set_problems(x0, glo, ghi, tf)
+    X0, U0 = s.traj()
+    sub = s.subproblem(X0, U0, 3.0, 1.0, 3.0 / 8 + 0.05)
+    s.set_problems(x0, glo, ghi, tf)
+    s.solve(12)
+    X, U = s.traj()
+    st = s.status()
+    o = go.Oracle(go.FREEFLYER_SE2, N, boxes=env)
+    for b in range(6):
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        Xi, Ui = o.init_straightline()
+        ro = o.subproblem(Xi, Ui, 3.0, 1.0, 3.0 / 8 + 0.05)
+        ok = (1, 2)     # OPTIMAL / ALMOST_LOCALLY_SOLVED are both accepted by scp_gusto.jl:106-111
+        assert (int(sub["status"][b]) in ok) == (ro["status"] in ok)
+        if ro["status"] == 1 and int(sub["status"][b]) == 1:
+            assert np.abs(sub["X"][b] - ro["X"]).max() < SUB_ATOL and np.abs(sub["U"][b] - ro["U"]).max() < SUB_ATOL
+        r = o.solve(12)
+        if r["omega"].max() > 1e3:
+            continue
+        assert int(st["iterations"][b]) == r["iterations"] and bool(st["converged"][b]) == r["converged"]
+        assert np.abs(X[b] - r["X"]).max() < TRAJ_ATOL
+
+
+def test_partial_goal_and_box_goal_freeflyer():
+    """Goal rows on a subset of coordinates (free final heading / rates) and a BoxGoal on the final position."""
+    g, go = _mods()
+    P = g.problems
+    env = P.freeflyer_env()
+    B, N = 8, 40
+    x0, glo, ghi, tf = P.freeflyer_batch(B)
+    glo[:, 2] = -np.inf; ghi[:, 2] = np.inf            # theta free
+    glo[:, 5] = -np.inf; ghi[:, 5] = np.inf            # omega free
+    glo[:4, 0] -= 0.05; ghi[:4, 0] += 0.05             # BoxGoal on x for half of the batch
+    s = g.BatchSolver(g.FREEFLYER_SE2, N, B, hist_cap=40, boxes=env)
+    s.set_problems(x0, glo, ghi, tf)
+    X0, U0 = s.traj()
+    sub = s.subproblem(X0, U0, 3.0, 1.0, 3.0 / 8 + 0.05)
+    o = go.Oracle(go.FREEFLYER_SE2, N, boxes=env)
+    for b in range(B):
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        Xi, Ui = o.init_straightline()
+        assert np.abs(Xi - X0[b]).max() < 1e-14
+        ro = o.subproblem(Xi, Ui, 3.0, 1.0, 3.0 / 8 + 0.05)
+        assert int(sub["status"][b]) == ro["status"] == 1
+        assert np.abs(sub["X"][b] - ro["X"]).max() < SUB_ATOL and np.abs(sub["U"][b] - ro["U"]).max() < SUB_ATOL
+        if b < 4:
+            assert glo[b, 0] - 1e-7 <= sub["X"][b, -1, 0] <= ghi[b, 0] + 1e-7
