@@ -847,10 +847,11 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
         const double* v = (r->isu ? U + r->k * m : X + r->k * n);
         double g = r->mul * row_val(r, v) - r->off;
         if (r->kind == ROW_HARD || r->kind == ROW_HARD_EQ) {
-            p->rt[i] = fmax(-g, 1e-2); p->rlam[i] = 0.1 / p->rt[i]; p->rlamb[i] = 0; p->rs[i] = 0;
+            /* start: slacks just inside, multipliers small (tuned on the freeflyer batch: -15 % iterations) */
+            p->rt[i] = fmax(-g, 1e-2); p->rlam[i] = 0.01 / p->rt[i]; p->rlamb[i] = 0; p->rs[i] = 0;
             ncomp += 1;
         } else {
-            p->rs[i] = fmax(g, 0.0) + 1.0; p->rt[i] = p->rs[i] - g; p->rlam[i] = 0.5; p->rlamb[i] = 0.5;
+            p->rs[i] = fmax(g, 0.0) + 0.01; p->rt[i] = p->rs[i] - g; p->rlam[i] = 0.5; p->rlamb[i] = 0.5;
             ncomp += 2;
         }
     }
