@@ -128,7 +128,8 @@ constexpr int SD_TOGGLE = 0, SD_DUAL = 2, SD_ND = 2 + GUSTO_MAXN;
 
 // ---- optional phase timers (compile with -DGUSTO_PROFILE) ---------------------------------------------
 constexpr int PROF_N = 16;
-enum { PF_RESID = 0, PF_BUILD, PF_FACTOR, PF_POSTF, PF_RHS, PF_BACK, PF_MID, PF_FWD, PF_STEP, PF_UPDATE, PF_LIN, PF_SCP, PF_INIT };
+enum { PF_RESID = 0, PF_BUILD, PF_FACTOR, PF_POSTF, PF_RHS, PF_BACK, PF_MID, PF_FWD, PF_STEP, PF_UPDATE, PF_LIN, PF_SCP, PF_INIT,
+       PF_FPRE, PF_FAB, PF_FCD };
 struct Prof {
 #ifdef GUSTO_PROFILE
     long long t0, acc[PROF_N];

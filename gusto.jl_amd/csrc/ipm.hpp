@@ -492,7 +492,7 @@ template <int MODEL, class BLK> GD double* pg_buf(const BLK& K, int k) {
 //   CD: every lane factors the m x m block S itself, forms the columns of W = L^-1 Hyu^T, V = L^-1 Zu it needs and
 //       writes P' = Hyy - W^T W, Pi' = Zy - W^T V, Phicl = Phi - Gam K, Gd += V^T V (Schur complements never
 //       through an explicit S^-1: with barrier weights ~1/mu in Hyy that loses every digit).
-template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail) {
+template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, Prof& pf) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n, NZN = NZ * n;
     constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64, RZ = (NZN + 63) / 64;
@@ -545,6 +545,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail) {
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = (e < NPG) ? pg[e] : 0.0; }
         }
+        pf.tick(PF_FPRE);
         // ---- phase AB -------------------------------------------------------------------------------
 #pragma unroll
         for (int r = 0; r < RQ; r++) {
@@ -595,6 +596,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail) {
             (isr ? K.rv : K.nun)[k * n + i] = s;
         }
         K.sync();
+        pf.tick(PF_FAB);
         // ---- phase CD -------------------------------------------------------------------------------
         {
             double S[m * m], Li[m * m];
@@ -664,6 +666,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail) {
 #pragma unroll
         for (int r = 0; r < RQ; r++) qq[r] = qqn[r];
         K.sync();
+        pf.tick(PF_FCD);
     }
 }
 
@@ -751,8 +754,8 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
     K.sync();
 }
 
-template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail) {
-    if constexpr (BLK::ONE) factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail); else factor_sweep_mw<MODEL>(K, fail);
+template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof& pf) {
+    if constexpr (BLK::ONE) factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail, pf); else factor_sweep_mw<MODEL>(K, fail);
 }
 template <int MODEL, class BLK> GD void backward_sweep(BLK& K) {
     if constexpr (BLK::ONE) backward_sweep_1w(SweepView<MODEL>::make(K)); else backward_sweep_mw(K);
@@ -1005,7 +1008,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         if (!isfinite(res_p) || !isfinite(res_d) || !isfinite(mu)) break;
         pf.tick(PF_BUILD);
         // (4) factorise
-        factor_sweep<MODEL>(K, fail);
+        factor_sweep<MODEL>(K, fail, pf);
         pf.tick(PF_FACTOR);
         GUSTO_REFRESH_K();
         if (k == 0) {  // Gd^-1 with an identity block on the coordinates without a point goal -> sP
