@@ -40,7 +40,7 @@ class ModelParams(C.Structure):
 
 class IpmOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("tol_acc", C.c_double), ("mu_floor", C.c_double), ("tr_tol", C.c_double),
-                ("max_iter", C.c_int)]
+                ("mu_warm", C.c_double), ("max_iter", C.c_int)]
 
 
 class History(C.Structure):

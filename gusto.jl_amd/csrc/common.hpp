@@ -123,7 +123,7 @@ struct KParams {
     WsLayout wl;
     LdsLayout ll;
 };
-constexpr int ST_ITER = 0, ST_CONV = 1, ST_SUCC = 2, ST_STOP = 3, ST_IPM = 4, ST_NHIST = 5, ST_NJ = 6, ST_NRHO = 7, ST_NI = 8;
+constexpr int ST_ITER = 0, ST_CONV = 1, ST_SUCC = 2, ST_STOP = 3, ST_IPM = 4, ST_NHIST = 5, ST_NJ = 6, ST_NRHO = 7, ST_WARM = 8, ST_NI = 9;
 constexpr int SD_TOGGLE = 0, SD_DUAL = 2, SD_ND = 2 + GUSTO_MAXN;
 
 // ---- optional phase timers (compile with -DGUSTO_PROFILE) ---------------------------------------------

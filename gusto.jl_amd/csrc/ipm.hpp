@@ -768,7 +768,7 @@ template <int MODEL, class BLK> GD void forward_sweep(BLK& K) {
 // Register discipline: nothing per-thread stays live across a sequential sweep.  Every stage-parallel block
 // re-reads the iterate (Xw/Uw), the linearisation point (Xp/Up) and the stage matrices it needs from LDS / L2
 // and leaves its results in LDS, so the sweeps get the whole register file for latency hiding.
-template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double omega, IpmOut& out, Prof& pf) {
+template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double omega, double muw, IpmOut& out, Prof& pf) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NHX = n * (n + 1) / 2, NHU = m * (m + 1) / 2, NQ = NZ * (NZ + 1) / 2;
     int k = K.tid;
@@ -813,7 +813,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         for (int i = 0; i < n; i++) { xs[i] = (k == 0) ? K.x_init[i] : K.Xp[k * n + i]; K.Xw[k * n + i] = xs[i]; K.nu[k * n + i] = 0; }
 #pragma unroll
         for (int i = 0; i < m; i++) { us[i] = K.Up[k * m + i]; K.Uw[k * m + i] = us[i]; }
-        OpInit op{rs};
+        OpInit op{rs, muw};
         visit_rows<MODEL>(ctx, xs, us, op);
         ncomp_l = op.ncomp;
     }

@@ -161,16 +161,26 @@ struct RowState {
 };
 
 // ---- the Ops ---------------------------------------------------------------------------------------
-// start point: slacks just inside (offset 0.01), penalised multipliers centred (lam_a = lam_b = 1/2), hard-row
-// multipliers 0.01/t -- tuned on the freeflyer batch, 15 % fewer interior point iterations than offset 1
+// Start point.  Cold (muw == 0: the first subproblem of an SCP run, or after a solver failure): slacks just inside (offset 0.01),
+// penalised multipliers lam_a = lam_b = 1/2, hard-row multipliers 0.01/t -- tuned on the freeflyer batch.
+// Warm (the iterate starts at the optimum of the previous subproblem): every penalised row is put ON the central
+// path at muw for its value g at the start point:  s - t = g, t lam_a = s lam_b = muw, lam_a + lam_b = 1
+//   <=>  {s, t} = muw + (sqrt(g^2 + 4 muw^2) +- g) / 2;   hard rows get lam = muw / t.
 struct OpInit {
     RowState rs;
+    double muw;
     int ncomp = 0;
     template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
         if (row_is_hard(kind)) {
-            const double t = fmax(-ev.g, 1e-2);
-            rs.at(RS_T, slot) = t; rs.at(RS_LAM, slot) = 0.01 / t; rs.at(RS_LAMB, slot) = 0.0; rs.at(RS_S, slot) = 0.0;
+            const double t = fmax(-ev.g, 1e-2), mu0 = (muw > 0) ? muw : 0.01;
+            rs.at(RS_T, slot) = t; rs.at(RS_LAM, slot) = mu0 / t; rs.at(RS_LAMB, slot) = 0.0; rs.at(RS_S, slot) = 0.0;
             ncomp += 1;
+        } else if (muw > 0) {
+            const double g = ev.g, ag = fabs(g), rr = sqrt(g * g + 4 * muw * muw);
+            const double big = muw + 0.5 * (rr + ag), small = muw + 2 * muw * muw / (rr + ag);
+            const double s = (g >= 0) ? big : small, t = (g >= 0) ? small : big;
+            rs.at(RS_S, slot) = s; rs.at(RS_T, slot) = t; rs.at(RS_LAM, slot) = muw / t; rs.at(RS_LAMB, slot) = muw / s;
+            ncomp += 2;
         } else {
             const double s = fmax(ev.g, 0.0) + 0.01;
             rs.at(RS_S, slot) = s; rs.at(RS_T, slot) = s - ev.g; rs.at(RS_LAM, slot) = 0.5; rs.at(RS_LAMB, slot) = 0.5;

@@ -89,7 +89,7 @@ scp_kernel(const KParams P) {
     if (P.mode == 1) {  // one convex subproblem around the stored (Xp,Up): parity hook
         linearize<MODEL>(K, P.sub_toggle[b]);
         IpmOut io;
-        ipm_solve<MODEL>(K, P.sub_Delta[b], P.sub_omega[b], io, pf);
+        ipm_solve<MODEL>(K, P.sub_Delta[b], P.sub_omega[b], 0.0, io, pf);
         pf.flush(P.prof);
         store_traj(K, K.Xw, K.Uw, P.sub_X + (size_t)b * N * n, P.sub_U + (size_t)b * N * m);
         if (tid == 0) {
@@ -118,12 +118,14 @@ scp_kernel(const KParams P) {
     double toggle = Delta / 8 + P.mp.clearance;
     double conv_prev = (n_hist >= 1) ? P.conv[hb + n_hist - 1] : 0.0;
 
+    bool warm = sti[ST_WARM] != 0;  // the previous subproblem ended OPTIMAL: the next one starts centred at mu_warm
     while (iterations < iter_cap && n_hist < P.hist_cap && nJ < P.hist_cap && n_rho < P.hist_cap) {
         pf.tick(PF_SCP);
         linearize<MODEL>(K, toggle);                       // :95  update_model_params!
         pf.tick(PF_LIN);
         IpmOut io;
-        ipm_solve<MODEL>(K, Delta, omega, io, pf);         // :96-104
+        ipm_solve<MODEL>(K, Delta, omega, warm ? P.io.mu_warm : 0.0, io, pf);  // :96-104
+        warm = io.status == GUSTO_SOLVER_OPTIMAL;
         total_ipm += io.iters;
         const int h = n_hist;
         if (tid == 0) { P.solver_status[hb + h] = io.status; P.ipm_it[hb + h] = io.iters; }
@@ -209,7 +211,7 @@ scp_kernel(const KParams P) {
     pf.flush(P.prof);
     if (tid == 0) {
         sti[ST_ITER] = iterations; sti[ST_CONV] = converged; sti[ST_SUCC] = successful; sti[ST_STOP] = stop;
-        sti[ST_IPM] = total_ipm; sti[ST_NHIST] = n_hist; sti[ST_NJ] = nJ; sti[ST_NRHO] = n_rho;
+        sti[ST_IPM] = total_ipm; sti[ST_NHIST] = n_hist; sti[ST_NJ] = nJ; sti[ST_NRHO] = n_rho; sti[ST_WARM] = warm;
         std_[SD_TOGGLE] = toggle;
     }
 }

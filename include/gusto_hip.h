@@ -65,6 +65,8 @@ typedef struct {
 /* inner convex solver (stands in for the `kwarg...` forwarded to the optimizer, scp_gusto.jl:82-92) */
 typedef struct {
     double tol, tol_acc, mu_floor, tr_tol;
+    double mu_warm; /* complementarity of the centred start used from the second subproblem of an SCP run on (the
+                       iterate then starts at the previous optimum); 0 = always the cold start */
     int max_iter;
 } gusto_ipm_opts;
 

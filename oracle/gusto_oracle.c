@@ -67,6 +67,7 @@ struct go_problem {
     double *dX, *dU, *nun, *nu, *Xw, *Uw;
     double mug[NX], mugn[NX];
     double Gd[NX * NX];
+    int warm; /* the previous subproblem of this problem's SCP run ended GO_SOLVER_OPTIMAL */
 };
 
 /* ------------------------------------------------------------------------------------------ */
@@ -222,7 +223,7 @@ void go_default_params(int model, go_scp_params* sp, go_model_params* mp) {
     }
 }
 void go_default_ipm_opts(go_ipm_opts* o) {
-    o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = 1e-11; o->tr_tol = 1e-6; o->max_iter = 60;
+    o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = 1e-11; o->tr_tol = 1e-6; o->mu_warm = 1e-4; o->max_iter = 60;
 }
 int go_model_dims(int model, int* n, int* m) {
     switch (model) {
@@ -841,15 +842,27 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
     memset(p->mug, 0, sizeof(p->mug));
     memset(p->mugn, 0, sizeof(p->mugn));
 
+    /* Start point.  Cold (first subproblem after go_set_problem, or after a solver failure): slacks just inside, multipliers small (tuned on the
+     * freeflyer batch).  Warm (the iterate starts at the optimum of the previous subproblem): every penalised row is
+     * put ON the central path at mu_warm for its value g at the start point -- s - t = g, t*lam_a = s*lam_b = mu,
+     * lam_a + lam_b = 1  <=>  s,t = mu + (sqrt(g^2 + 4 mu^2) +- g)/2 -- and hard rows get lam = mu/t. */
+    const double muw = p->warm ? io->mu_warm : 0.0;
+    p->warm = 0;
     int ncomp = 0;
     for (int i = 0; i < nr; i++) {
         go_row* r = &p->rows[i];
         const double* v = (r->isu ? U + r->k * m : X + r->k * n);
         double g = r->mul * row_val(r, v) - r->off;
         if (r->kind == ROW_HARD || r->kind == ROW_HARD_EQ) {
-            /* start: slacks just inside, multipliers small (tuned on the freeflyer batch: -15 % iterations) */
-            p->rt[i] = fmax(-g, 1e-2); p->rlam[i] = 0.01 / p->rt[i]; p->rlamb[i] = 0; p->rs[i] = 0;
+            const double mu0 = (muw > 0) ? muw : 0.01;
+            p->rt[i] = fmax(-g, 1e-2); p->rlam[i] = mu0 / p->rt[i]; p->rlamb[i] = 0; p->rs[i] = 0;
             ncomp += 1;
+        } else if (muw > 0) {
+            const double ag = fabs(g), rr = sqrt(g * g + 4 * muw * muw);
+            const double big = muw + 0.5 * (rr + ag), small = muw + 2 * muw * muw / (rr + ag);
+            p->rs[i] = (g >= 0) ? big : small; p->rt[i] = (g >= 0) ? small : big;
+            p->rlam[i] = muw / p->rt[i]; p->rlamb[i] = muw / p->rs[i];
+            ncomp += 2;
         } else {
             p->rs[i] = fmax(g, 0.0) + 0.01; p->rt[i] = p->rs[i] - g; p->rlam[i] = 0.5; p->rlamb[i] = 0.5;
             ncomp += 2;
@@ -1043,6 +1056,7 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
         if (!(p->rows[i].kind == ROW_HARD || p->rows[i].kind == ROW_HARD_EQ)) obj += p->rs[i];
     info->obj = obj / kappa;
     info->res_p = res_p; info->res_d = res_d; info->mu = mu; info->iters = it; info->status = status;
+    p->warm = (status == GO_SOLVER_OPTIMAL);
     for (int i = 0; i < n; i++) p->dual[i] = p->nu[i] / kappa; /* get_dual_jump: -dual(init rows) */
     return status;
 }
@@ -1214,7 +1228,7 @@ int go_set_problem(go_problem* p, const double* x_init, const double* goal_lo, c
     /* SCPSolution(SCPP, traj_init) (types.jl:233) and SCPParam_GuSTO ctor (scp_gusto.jl:21-23) */
     free_hist(p);
     grow_hist(p, 8);
-    p->iterations = 0; p->converged = 0; p->successful = 0; p->stop_reason = GO_STOP_MAXITER; p->total_ipm = 0;
+    p->iterations = 0; p->converged = 0; p->successful = 0; p->stop_reason = GO_STOP_MAXITER; p->total_ipm = 0; p->warm = 0;
     p->nJ_true = 0; p->nJ_full = 0;
     p->n_hist = 1;
     p->solver_status[0] = GO_SOLVER_NA; p->scp_status[0] = GO_SCP_NA; p->accept[0] = 1; p->conv[0] = 0.0; p->ipm_it[0] = 0;
@@ -1332,7 +1346,10 @@ int go_get_dual(const go_problem* p, double* dual) { memcpy(dual, p->dual, sizeo
 
 int go_subproblem(go_problem* p, const double* Xp, const double* Up, double Delta, double omega, double toggle,
                   double* Xn, double* Un, double* dual, go_sub_info* info) {
+    const int warm_saved = p->warm; /* the hook always starts cold and leaves the SCP run's state alone */
+    p->warm = 0;
     int st = ipm_solve(p, Xp, Up, Delta, omega, toggle, info);
+    p->warm = warm_saved;
     if (Xn) memcpy(Xn, p->Xw, sizeof(double) * p->n * p->N);
     if (Un) memcpy(Un, p->Uw, sizeof(double) * p->m * p->N);
     if (dual) memcpy(dual, p->dual, sizeof(double) * p->n);

@@ -61,6 +61,8 @@ typedef struct {
     double tol_acc;    /* acceptable tolerance at the iteration cap             */
     double mu_floor;   /* smallest complementarity target                        */
     double tr_tol;     /* slack on the `max||dx||^2 - Delta <= 0` post-check     */
+    double mu_warm;    /* centred start at this mu once a subproblem of the same SCP run has been solved
+                          (the iterate starts at the previous optimum); 0 = always the cold start */
     int max_iter;
 } go_ipm_opts;
 
