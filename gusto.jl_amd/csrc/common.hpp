@@ -48,7 +48,7 @@ GD constexpr int sidx(int i, int j, int n) {
 // per-problem global workspace, offsets in doubles
 struct WsLayout {
     int nslot;
-    size_t rowstate, obs_nh, obs_c0, obs_mask, PG, QQ, Paft, Piaft, K, Sinv, D, Phicl, pvt, total;
+    size_t rowstate, obs_nh, obs_c0, obs_mask, PG, QQ, Paft, Piaft, K, Sinv, D, Phicl, pvt, dummy, total;
 };
 template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     using T = MT<MODEL>;
@@ -70,6 +70,7 @@ template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     L.D = take((size_t)N * m * n);
     L.Phicl = take((size_t)N * n * n);
     L.pvt = take((size_t)N * (3 * n + 3 * m));
+    L.dummy = take(64);  // store target of the idle lanes of the sweeps (keeps their VMEM ops branch-free)
     L.total = o;
     return L;
 }
@@ -127,9 +128,9 @@ constexpr int ST_ITER = 0, ST_CONV = 1, ST_SUCC = 2, ST_STOP = 3, ST_IPM = 4, ST
 constexpr int SD_TOGGLE = 0, SD_DUAL = 2, SD_ND = 2 + GUSTO_MAXN;
 
 // ---- optional phase timers (compile with -DGUSTO_PROFILE) ---------------------------------------------
-constexpr int PROF_N = 16;
+constexpr int PROF_N = 32;
 enum { PF_RESID = 0, PF_BUILD, PF_FACTOR, PF_POSTF, PF_RHS, PF_BACK, PF_MID, PF_FWD, PF_STEP, PF_UPDATE, PF_LIN, PF_SCP, PF_INIT,
-       PF_FPRE, PF_FAB, PF_FCD };
+       PF_FPRE, PF_FAB, PF_FCD, PF_F1, PF_F2, PF_F3, PF_F4, PF_F5, PF_F6, PF_F7, PF_F8 };
 struct Prof {
 #ifdef GUSTO_PROFILE
     long long t0, acc[PROF_N];

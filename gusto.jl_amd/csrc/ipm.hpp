@@ -55,7 +55,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     // LDS per-knot vectors
     double *Xw, *Xp, *dY, *rd, *pv, *cv, *rv, *qrd, *nu, *nun, *dXs, *Uw, *Up, *qu, *dv, *dUs;
     // global workspace of this problem
-    double *rowstate, *obs_nh, *obs_c0, *PG, *QQ, *Paft, *Piaft, *Kg, *Sinvg, *Dg, *Phicl;
+    double *rowstate, *obs_nh, *obs_c0, *PG, *QQ, *Paft, *Piaft, *Kg, *Sinvg, *Dg, *Phicl, *dummy;
     uint64_t* obs_mask;
     const double *x_init, *goal_lo, *goal_hi;
     unsigned goalmask;  // bit i: coordinate i of x_N has a point goal (goal_lo == goal_hi)
@@ -76,7 +76,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         rowstate = w + W.rowstate; obs_nh = w + W.obs_nh; obs_c0 = w + W.obs_c0;
         obs_mask = reinterpret_cast<uint64_t*>(w + W.obs_mask);
         PG = w + W.PG; QQ = w + W.QQ; Paft = w + W.Paft; Piaft = w + W.Piaft; Kg = w + W.K; Sinvg = w + W.Sinv;
-        Dg = w + W.D; Phicl = w + W.Phicl;
+        Dg = w + W.D; Phicl = w + W.Phicl; dummy = w + W.dummy;
         {   // knot-private vectors in the global workspace, the linearisation point = the stored trajectory
             double* q = w + W.pvt;
             rd = q; qrd = q + N * n; dXs = q + 2 * N * n; dUs = q + 3 * N * n; qu = dUs + N * m; dv = qu + N * m;
@@ -448,7 +448,7 @@ template <int MODEL> struct SweepView {
     double *lds, *sP, *sPi, *sPG, *sT, *sHh, *sZ, *sK, *sD, *sW, *sV, *sGd;
     int* lut;
     double *cv, *rv, *nun, *pv, *dY;
-    double *PG, *QQ, *Paft, *Piaft, *Kg, *Sinvg, *Dg, *Phicl;
+    double *PG, *QQ, *Paft, *Piaft, *Kg, *Sinvg, *Dg, *Phicl, *dummy;
     const gusto_model_params* mpp;
     struct PW { const gusto_model_params& mp; } ;
     int tid, N;
@@ -464,7 +464,7 @@ template <int MODEL> struct SweepView {
         v.sZ = K.lds + C::sZ; v.sK = K.lds + C::sK; v.sD = K.lds + C::sD; v.sW = K.lds + C::sW; v.sV = K.lds + C::sV;
         v.sGd = K.lds + C::sGd; v.lut = K.lut;
         v.cv = K.cv; v.rv = K.rv; v.nun = K.nun; v.pv = K.pv; v.dY = K.dY;
-        v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.Kg = K.Kg; v.Sinvg = K.Sinvg; v.Dg = K.Dg;
+        v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.Kg = K.Kg; v.Sinvg = K.Sinvg; v.Dg = K.Dg; v.dummy = K.dummy;
         v.Phicl = K.Phicl; v.mpp = &K.P.mp; v.tid = K.tid; v.N = K.N; v.dt = K.dt; v.goalmask = K.goalmask;
         return v;
     }
@@ -539,11 +539,14 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
         const double* PGs = pg_buf<MODEL>(K, k);
         double qqn[RQ];
 #pragma unroll
-        for (int r = 0; r < RQ; r++) { const int e = tid + 64 * r; qqn[r] = (k > 0 && e < NQ) ? K.QQ[(size_t)(k - 1) * NQ + e] : 0.0; }
-        if (!T::LTI && k > 1) {
-            const double* pg = K.PGk(k - 1);
+        for (int r = 0; r < RQ; r++) {   // unconditional (clamped) prefetch: see phase CD
+            const int e = tid + 64 * r;
+            qqn[r] = K.QQ[(size_t)((k > 0) ? k - 1 : 0) * NQ + ((e < NQ) ? e : NQ - 1)];
+        }
+        if (!T::LTI) {
+            const double* pg = K.PGk((k > 1) ? k - 1 : 0);
 #pragma unroll
-            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = (e < NPG) ? pg[e] : 0.0; }
+            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
         }
         pf.tick(PF_FPRE);
         // ---- phase AB -------------------------------------------------------------------------------
@@ -568,6 +571,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 K.sHh[hJ[r] * NZ + hI[r]] = s;
             }
         }
+        pf.tick(PF_F1);
 #pragma unroll
         for (int r = 0; r < RZ; r++) {
             if (tid + 64 * r < NZN) {
@@ -583,6 +587,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 K.sZ[tid + 64 * r] = s;
             }
         }
+        pf.tick(PF_F2);
         for (int e = tid; e < 2 * n; e += 64) {   // r_k = P_k c_k and Pi_k^T c_k for the stage-parallel blocks
             const bool isr = e < n;
             const int i = isr ? e : e - n;
@@ -595,9 +600,13 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             for (int l = 0; l < n; l++) s += a[l] * bb[l];
             (isr ? K.rv : K.nun)[k * n + i] = s;
         }
+        pf.tick(PF_F3);
         K.sync();
         pf.tick(PF_FAB);
         // ---- phase CD -------------------------------------------------------------------------------
+        // Every global store below is unconditional (idle lanes and k == 0 aim at the dummy pad): with no VMEM op
+        // under a branch the compiler can count the stores issued after the QQ prefetch and wait with vmcnt(#stores)
+        // instead of draining them all with vmcnt(0) at the end of every stage.
         {
             double S[m * m], Li[m * m];
 #pragma unroll
@@ -605,58 +614,72 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
 #pragma unroll
                 for (int j = 0; j < m; j++) S[i * m + j] = K.sHh[(n + i) * NZ + n + j];
             if (!chol_inv<m>(S, Li)) *fail = 1.0;
+            pf.tick(PF_F4);
 #pragma unroll
             for (int r = 0; r < RN; r++) {
                 const int e2 = tid + 64 * r;
-                if (e2 < NN) {
-                    const int i = nI[r], j = nJ[r];
-                    double hi[m], hj[m], zi[m], zj[m], gi[m];
+                const bool on = e2 < NN;
+                const int i = nI[r], j = nJ[r];   // (0, 0) on idle lanes: every LDS address below stays valid
+                double hi[m], hj[m], zi[m], zj[m], gi[m];
 #pragma unroll
-                    for (int l = 0; l < m; l++) {
-                        hi[l] = K.sHh[i * NZ + n + l]; hj[l] = K.sHh[j * NZ + n + l];
-                        zi[l] = K.sZ[(n + l) * n + i]; zj[l] = K.sZ[(n + l) * n + j];
-                        gi[l] = PGs[i * NZ + n + l];
-                    }
-                    double pn = K.sHh[i * NZ + j], ph = PGs[i * NZ + j], pin = K.sZ[i * n + j], gd = K.sGd[e2];
-                    __builtin_amdgcn_sched_barrier(0);
-                    double wi[m], wj[m], vi[m], vj[m], kj[m], dj[m];
-#pragma unroll
-                    for (int a = 0; a < m; a++) {   // W = L^-1 Hyu^T, V = L^-1 Zu (columns i and j)
-                        double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-#pragma unroll
-                        for (int l = 0; l <= a; l++) {
-                            s1 += Li[a * m + l] * hi[l]; s2 += Li[a * m + l] * hj[l];
-                            s3 += Li[a * m + l] * zi[l]; s4 += Li[a * m + l] * zj[l];
-                        }
-                        wi[a] = s1; wj[a] = s2; vi[a] = s3; vj[a] = s4;
-                    }
-#pragma unroll
-                    for (int a = 0; a < m; a++) {   // K = L^-T W, D = L^-T V (column j)
-                        double s1 = 0, s2 = 0;
-#pragma unroll
-                        for (int l = a; l < m; l++) { s1 += Li[l * m + a] * wj[l]; s2 += Li[l * m + a] * vj[l]; }
-                        kj[a] = s1; dj[a] = s2;
-                    }
-#pragma unroll
-                    for (int l = 0; l < m; l++) { pn -= wi[l] * wj[l]; ph -= gi[l] * kj[l]; pin -= wi[l] * vj[l]; gd += vi[l] * vj[l]; }
-                    K.sP[e2] = pn; K.sPi[e2] = pin; K.sGd[e2] = gd;
-                    K.Phicl[(size_t)k * NN + e2] = ph;
-                    if (k > 0) { K.Paft[(size_t)(k - 1) * NN + e2] = pn; K.Piaft[(size_t)(k - 1) * NN + e2] = pin; }
-                    if (i == 0) {   // the lanes of row 0 own column j of K and D
-#pragma unroll
-                        for (int a = 0; a < m; a++) {
-                            K.Kg[(size_t)k * m * n + a * n + j] = kj[a];
-                            K.Dg[(size_t)k * m * n + a * n + j] = dj[a];
-                        }
-                    }
+                for (int l = 0; l < m; l++) {
+                    hi[l] = K.sHh[i * NZ + n + l]; hj[l] = K.sHh[j * NZ + n + l];
+                    zi[l] = K.sZ[(n + l) * n + i]; zj[l] = K.sZ[(n + l) * n + j];
+                    gi[l] = PGs[i * NZ + n + l];
                 }
-            }
-            if (tid < m * m) {  // S^-1 = L^-T L^-1 (feed-forward only)
-                const int i = tid / m, j = tid % m;
-                double s = 0;
+                double pn = K.sHh[i * NZ + j], ph = PGs[i * NZ + j], pin = K.sZ[i * n + j], gd = K.sGd[on ? e2 : 0];
+                __builtin_amdgcn_sched_barrier(0);
+                pf.tick(PF_F5);
+                double wi[m], wj[m], vi[m], vj[m], kj[m], dj[m];
 #pragma unroll
-                for (int l = 0; l < m; l++) if (l >= i && l >= j) s += Li[l * m + i] * Li[l * m + j];
-                K.Sinvg[(size_t)k * m * m + tid] = s;
+                for (int a = 0; a < m; a++) {   // W = L^-1 Hyu^T, V = L^-1 Zu (columns i and j)
+                    double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+                    for (int l = 0; l <= a; l++) {
+                        s1 += Li[a * m + l] * hi[l]; s2 += Li[a * m + l] * hj[l];
+                        s3 += Li[a * m + l] * zi[l]; s4 += Li[a * m + l] * zj[l];
+                    }
+                    wi[a] = s1; wj[a] = s2; vi[a] = s3; vj[a] = s4;
+                }
+#pragma unroll
+                for (int a = 0; a < m; a++) {   // K = L^-T W, D = L^-T V (column j)
+                    double s1 = 0, s2 = 0;
+#pragma unroll
+                    for (int l = a; l < m; l++) { s1 += Li[l * m + a] * wj[l]; s2 += Li[l * m + a] * vj[l]; }
+                    kj[a] = s1; dj[a] = s2;
+                }
+#pragma unroll
+                for (int l = 0; l < m; l++) { pn -= wi[l] * wj[l]; ph -= gi[l] * kj[l]; pin -= wi[l] * vj[l]; gd += vi[l] * vj[l]; }
+                pf.tick(PF_F6);
+                if (on) { K.sP[e2] = pn; K.sPi[e2] = pin; K.sGd[e2] = gd; }
+                double* const dmy = K.dummy + tid;
+                const bool onp = on && k > 0;
+                *(on ? K.Phicl + (size_t)k * NN + e2 : dmy) = ph;
+                *(onp ? K.Paft + (size_t)(k - 1) * NN + e2 : dmy) = pn;
+                *(onp ? K.Piaft + (size_t)(k - 1) * NN + e2 : dmy) = pin;
+                // lanes of rows 0..m-1 own K[i][j], rows m..2m-1 own D[i-m][j]  (n >= 2m for every model)
+                static_assert(n >= 2 * m, "K/D store mapping");
+                double kd = kj[0];
+#pragma unroll
+                for (int a = 1; a < m; a++) kd = (i == a) ? kj[a] : kd;
+#pragma unroll
+                for (int a = 0; a < m; a++) kd = (i == m + a) ? dj[a] : kd;
+                const int ia = (i < m) ? i : i - m;
+                double* kdp = ((i < m) ? K.Kg : K.Dg) + (size_t)k * m * n + ia * n + j;
+                *((on && i < 2 * m) ? kdp : dmy) = kd;
+            }
+            {   // S^-1 = L^-T L^-1 (feed-forward only): computed wave-uniformly, lane e < m*m keeps entry e
+                double sv = 0;
+#pragma unroll
+                for (int a = 0; a < m; a++)
+#pragma unroll
+                    for (int c = 0; c <= a; c++) {
+                        double s = 0;
+#pragma unroll
+                        for (int l = a; l < m; l++) s += Li[l * m + a] * Li[l * m + c];
+                        sv = (tid == a * m + c || tid == c * m + a) ? s : sv;
+                    }
+                *((tid < m * m) ? K.Sinvg + (size_t)k * m * m + tid : K.dummy + tid) = sv;
             }
         }
         if (!T::LTI && k > 1) {
@@ -665,6 +688,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
         }
 #pragma unroll
         for (int r = 0; r < RQ; r++) qq[r] = qqn[r];
+        pf.tick(PF_F7);
         K.sync();
         pf.tick(PF_FCD);
     }
