@@ -550,57 +550,105 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
         }
         pf.tick(PF_FPRE);
         // ---- phase AB -------------------------------------------------------------------------------
+        // Small models: every LDS operand of the three products (H, Z, r) is requested before the first FMA, so the
+        // stage pays ONE LDS latency here instead of three back-to-back read -> wait -> compute chains.
+        if constexpr (n * n + 2 * (RQ + RZ + 1) * n <= 112) {
+            double pm[n * n], pgj[RQ][n], pgi[RQ][n], za[RZ][n], zb[RZ][n], ra[n], rb[n];
+            const bool isr = tid < n;
+            const int ri = isr ? tid : ((tid < 2 * n) ? tid - n : 0);
 #pragma unroll
-        for (int r = 0; r < RQ; r++) {
-            if (tid + 64 * r < NQ) {
-                double pgj[n], pgi[n], pm[n * n];
+            for (int e = 0; e < n * n; e++) pm[e] = K.sP[e];
 #pragma unroll
-                for (int l = 0; l < n; l++) { pgj[l] = PGs[l * NZ + hJ[r]]; pgi[l] = PGs[l * NZ + hI[r]]; }
+            for (int r = 0; r < RQ; r++)
 #pragma unroll
-                for (int e = 0; e < n * n; e++) pm[e] = K.sP[e];
-                __builtin_amdgcn_sched_barrier(0);
+                for (int l = 0; l < n; l++) { pgj[r][l] = PGs[l * NZ + hJ[r]]; pgi[r][l] = PGs[l * NZ + hI[r]]; }
+#pragma unroll
+            for (int r = 0; r < RZ; r++)
+#pragma unroll
+                for (int l = 0; l < n; l++) { za[r][l] = PGs[l * NZ + zJ[r]]; zb[r][l] = K.sPi[l * n + zG[r]]; }
+#pragma unroll
+            for (int l = 0; l < n; l++) { ra[l] = *(isr ? K.sP + ri * n + l : K.sPi + l * n + ri); rb[l] = K.cv[k * n + l]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RQ; r++) {
                 double s = qq[r];
 #pragma unroll
                 for (int l = 0; l < n; l++) {
                     double t = 0;   // (P [Phi Gam])[l][j]
 #pragma unroll
-                    for (int q = 0; q < n; q++) t += pm[l * n + q] * pgj[q];
-                    s += pgi[l] * t;
+                    for (int q = 0; q < n; q++) t += pm[l * n + q] * pgj[r][q];
+                    s += pgi[r][l] * t;
                 }
-                K.sHh[hI[r] * NZ + hJ[r]] = s;
-                K.sHh[hJ[r] * NZ + hI[r]] = s;
+                if (tid + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = s; K.sHh[hJ[r] * NZ + hI[r]] = s; }
             }
-        }
-        pf.tick(PF_F1);
 #pragma unroll
-        for (int r = 0; r < RZ; r++) {
-            if (tid + 64 * r < NZN) {
+            for (int r = 0; r < RZ; r++) {
+                double s = 0;
+#pragma unroll
+                for (int l = 0; l < n; l++) s += za[r][l] * zb[r][l];
+                // E = [M^T C^T; b^T M^T C^T], M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
+                if (k == N - 1 && K.is_goal(zG[r])) s += 0.5 * (PGs[zG[r] * NZ + zJ[r]] + ((zJ[r] == zG[r]) ? 1.0 : 0.0));
+                if (tid + 64 * r < NZN) K.sZ[tid + 64 * r] = s;
+            }
+            {   // r_k = P_k c_k and Pi_k^T c_k for the stage-parallel blocks
+                double s = 0;
+#pragma unroll
+                for (int l = 0; l < n; l++) s += ra[l] * rb[l];
+                if (tid < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = s;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RQ; r++) {
+                if (tid + 64 * r < NQ) {
+                    double pgj[n], pgi[n], pm[n * n];
+#pragma unroll
+                    for (int l = 0; l < n; l++) { pgj[l] = PGs[l * NZ + hJ[r]]; pgi[l] = PGs[l * NZ + hI[r]]; }
+#pragma unroll
+                    for (int e = 0; e < n * n; e++) pm[e] = K.sP[e];
+                    __builtin_amdgcn_sched_barrier(0);
+                    double s = qq[r];
+#pragma unroll
+                    for (int l = 0; l < n; l++) {
+                        double t = 0;   // (P [Phi Gam])[l][j]
+#pragma unroll
+                        for (int q = 0; q < n; q++) t += pm[l * n + q] * pgj[q];
+                        s += pgi[l] * t;
+                    }
+                    K.sHh[hI[r] * NZ + hJ[r]] = s;
+                    K.sHh[hJ[r] * NZ + hI[r]] = s;
+                }
+            }
+        
+#pragma unroll
+            for (int r = 0; r < RZ; r++) {
+                if (tid + 64 * r < NZN) {
+                    double a[n], bb[n];
+#pragma unroll
+                    for (int l = 0; l < n; l++) { a[l] = PGs[l * NZ + zJ[r]]; bb[l] = K.sPi[l * n + zG[r]]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double s = 0;
+#pragma unroll
+                    for (int l = 0; l < n; l++) s += a[l] * bb[l];
+                    // E = [M^T C^T; b^T M^T C^T], M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
+                    if (k == N - 1 && K.is_goal(zG[r])) s += 0.5 * (PGs[zG[r] * NZ + zJ[r]] + ((zJ[r] == zG[r]) ? 1.0 : 0.0));
+                    K.sZ[tid + 64 * r] = s;
+                }
+            }
+        
+            for (int e = tid; e < 2 * n; e += 64) {   // r_k = P_k c_k and Pi_k^T c_k for the stage-parallel blocks
+                const bool isr = e < n;
+                const int i = isr ? e : e - n;
                 double a[n], bb[n];
 #pragma unroll
-                for (int l = 0; l < n; l++) { a[l] = PGs[l * NZ + zJ[r]]; bb[l] = K.sPi[l * n + zG[r]]; }
+                for (int l = 0; l < n; l++) { a[l] = isr ? K.sP[i * n + l] : K.sPi[l * n + i]; bb[l] = K.cv[k * n + l]; }
                 __builtin_amdgcn_sched_barrier(0);
                 double s = 0;
 #pragma unroll
                 for (int l = 0; l < n; l++) s += a[l] * bb[l];
-                // E = [M^T C^T; b^T M^T C^T], M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
-                if (k == N - 1 && K.is_goal(zG[r])) s += 0.5 * (PGs[zG[r] * NZ + zJ[r]] + ((zJ[r] == zG[r]) ? 1.0 : 0.0));
-                K.sZ[tid + 64 * r] = s;
+                (isr ? K.rv : K.nun)[k * n + i] = s;
             }
+        
         }
-        pf.tick(PF_F2);
-        for (int e = tid; e < 2 * n; e += 64) {   // r_k = P_k c_k and Pi_k^T c_k for the stage-parallel blocks
-            const bool isr = e < n;
-            const int i = isr ? e : e - n;
-            double a[n], bb[n];
-#pragma unroll
-            for (int l = 0; l < n; l++) { a[l] = isr ? K.sP[i * n + l] : K.sPi[l * n + i]; bb[l] = K.cv[k * n + l]; }
-            __builtin_amdgcn_sched_barrier(0);
-            double s = 0;
-#pragma unroll
-            for (int l = 0; l < n; l++) s += a[l] * bb[l];
-            (isr ? K.rv : K.nun)[k * n + i] = s;
-        }
-        pf.tick(PF_F3);
         K.sync();
         pf.tick(PF_FAB);
         // ---- phase CD -------------------------------------------------------------------------------
@@ -613,31 +661,43 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             for (int i = 0; i < m; i++)
 #pragma unroll
                 for (int j = 0; j < m; j++) S[i * m + j] = K.sHh[(n + i) * NZ + n + j];
+            // the operands of the solves do not depend on the Cholesky factor: request them first, they land while
+            // the (latency-bound, wave-uniform) factorisation runs
+            double hi[RN][m], hj[RN][m], zi[RN][m], zj[RN][m], gi[RN][m], pn_[RN], ph_[RN], pin_[RN], gd_[RN];
+#pragma unroll
+            for (int r = 0; r < RN; r++) {
+                const int i = nI[r], j = nJ[r];   // (0, 0) on idle lanes: every LDS address stays valid
+#pragma unroll
+                for (int l = 0; l < m; l++) {
+                    hi[r][l] = K.sHh[i * NZ + n + l]; hj[r][l] = K.sHh[j * NZ + n + l];
+                    zi[r][l] = K.sZ[(n + l) * n + i]; zj[r][l] = K.sZ[(n + l) * n + j];
+                    gi[r][l] = PGs[i * NZ + n + l];
+                }
+                pn_[r] = K.sHh[i * NZ + j]; ph_[r] = PGs[i * NZ + j]; pin_[r] = K.sZ[i * n + j];
+                gd_[r] = K.sGd[(tid + 64 * r < NN) ? tid + 64 * r : 0];
+            }
+            if constexpr (RN * m <= 6) __builtin_amdgcn_sched_barrier(0);   // (larger models: leave the order to the compiler)
             if (!chol_inv<m>(S, Li)) *fail = 1.0;
             pf.tick(PF_F4);
+            // take the prefetched QQ_{k-1} here, BEFORE this stage's stores are issued: the wait then covers the
+            // prefetch and the previous stage's stores (a whole phase old), not a store issued a moment ago
+#pragma unroll
+            for (int r = 0; r < RQ; r++) qq[r] = qqn[r];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < RN; r++) {
                 const int e2 = tid + 64 * r;
                 const bool on = e2 < NN;
-                const int i = nI[r], j = nJ[r];   // (0, 0) on idle lanes: every LDS address below stays valid
-                double hi[m], hj[m], zi[m], zj[m], gi[m];
-#pragma unroll
-                for (int l = 0; l < m; l++) {
-                    hi[l] = K.sHh[i * NZ + n + l]; hj[l] = K.sHh[j * NZ + n + l];
-                    zi[l] = K.sZ[(n + l) * n + i]; zj[l] = K.sZ[(n + l) * n + j];
-                    gi[l] = PGs[i * NZ + n + l];
-                }
-                double pn = K.sHh[i * NZ + j], ph = PGs[i * NZ + j], pin = K.sZ[i * n + j], gd = K.sGd[on ? e2 : 0];
-                __builtin_amdgcn_sched_barrier(0);
-                pf.tick(PF_F5);
+                const int i = nI[r], j = nJ[r];
+                double pn = pn_[r], ph = ph_[r], pin = pin_[r], gd = gd_[r];
                 double wi[m], wj[m], vi[m], vj[m], kj[m], dj[m];
 #pragma unroll
                 for (int a = 0; a < m; a++) {   // W = L^-1 Hyu^T, V = L^-1 Zu (columns i and j)
                     double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
 #pragma unroll
                     for (int l = 0; l <= a; l++) {
-                        s1 += Li[a * m + l] * hi[l]; s2 += Li[a * m + l] * hj[l];
-                        s3 += Li[a * m + l] * zi[l]; s4 += Li[a * m + l] * zj[l];
+                        s1 += Li[a * m + l] * hi[r][l]; s2 += Li[a * m + l] * hj[r][l];
+                        s3 += Li[a * m + l] * zi[r][l]; s4 += Li[a * m + l] * zj[r][l];
                     }
                     wi[a] = s1; wj[a] = s2; vi[a] = s3; vj[a] = s4;
                 }
@@ -649,7 +709,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                     kj[a] = s1; dj[a] = s2;
                 }
 #pragma unroll
-                for (int l = 0; l < m; l++) { pn -= wi[l] * wj[l]; ph -= gi[l] * kj[l]; pin -= wi[l] * vj[l]; gd += vi[l] * vj[l]; }
+                for (int l = 0; l < m; l++) { pn -= wi[l] * wj[l]; ph -= gi[r][l] * kj[l]; pin -= wi[l] * vj[l]; gd += vi[l] * vj[l]; }
                 pf.tick(PF_F6);
                 if (on) { K.sP[e2] = pn; K.sPi[e2] = pin; K.sGd[e2] = gd; }
                 double* const dmy = K.dummy + tid;
@@ -686,8 +746,6 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; if (e < NPG) K.sPG[((k - 1) & 1) * NPG + e] = pgn[r]; }
         }
-#pragma unroll
-        for (int r = 0; r < RQ; r++) qq[r] = qqn[r];
         pf.tick(PF_F7);
         K.sync();
         pf.tick(PF_FCD);
@@ -1074,8 +1132,10 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 for (int i = 0; i < n; i++) { gx[i] = 0; gy[i] = 0; }
 #pragma unroll
                 for (int i = 0; i < m; i++) gu[i] = 2 * wk * us[i];
+                pf.tick(PF_F1);
                 OpRhs op{rs, gx, gu, pass, mu_t};
                 visit_rows<MODEL>(ctx, xs, us, op);
+                pf.tick(PF_F2);
                 if (k >= 1) {
                     double Mk[n * n], Gamk[n * m];
                     load_M_Gam(K, k, Mk, Gamk);
@@ -1090,6 +1150,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
 #pragma unroll
                     for (int i = 0; i < n; i++) gxs[i] = gx[i];
                 }
+                pf.tick(PF_F3);
 #pragma unroll
                 for (int i = 0; i < m; i++) {
                     double s = gu[i];
@@ -1105,6 +1166,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                     for (int l = 0; l < m; l++) s -= K.Kg[(size_t)k * m * n + l * n + i] * quk[l];
                     K.pv[k * n + i] = s + (k >= 1 ? K.rv[(k - 1) * n + i] : 0.0);   // qq_k = qt_k + r_{k-1}
                 }
+                pf.tick(PF_F8);
             }
             K.sync();
             pf.tick(PF_RHS);

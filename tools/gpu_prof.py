@@ -6,7 +6,8 @@ import gusto_jl_amd as g
 P = g.problems
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 x0, glo, ghi, tf = P.freeflyer_batch(B)
-s = g.BatchSolver(g.FREEFLYER_SE2, 50, B, hist_cap=64, boxes=P.freeflyer_env())
+boxes = None if (len(sys.argv) > 2 and sys.argv[2] == 'noobs') else P.freeflyer_env()
+s = g.BatchSolver(g.FREEFLYER_SE2, 50, B, hist_cap=64, boxes=boxes)
 for rep in range(2):
     s.set_problems(x0, glo, ghi, tf); s.solve(30)
 st = s.status()
