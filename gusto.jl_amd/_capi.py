@@ -20,7 +20,8 @@ STOP_REASON = {0: "MaxIter", 1: "Converged", 2: "SubproblemFailed", 3: "OmegaMax
 # every symbol include/gusto_hip.h declares
 SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims", "gusto_create", "gusto_destroy",
            "gusto_last_error", "gusto_set_params", "gusto_set_ipm_opts", "gusto_set_env", "gusto_set_stream",
-           "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_last_solve_ms", "gusto_get_traj",
+           "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_solve_async", "gusto_wait",
+           "gusto_last_solve_ms", "gusto_get_traj",
            "gusto_get_traj_dev", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_subproblem"]
 
 
@@ -109,6 +110,8 @@ def lib():
         L.gusto_set_problems.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
         L.gusto_set_problems_dev.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
         L.gusto_solve.argtypes = [vp, ci, ci]
+        L.gusto_solve_async.argtypes = [vp, ci, ci]
+        L.gusto_wait.argtypes = [vp]
         L.gusto_last_solve_ms.argtypes = [vp, C.POINTER(C.c_double)]
         L.gusto_get_traj.argtypes = [vp, vp, vp]
         L.gusto_get_traj_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -199,6 +202,19 @@ class BatchSolver:
 
     def solve(self, max_iter=30, force=False):
         self._chk(self.L.gusto_solve(self.h, int(max_iter), int(bool(force))), "solve")
+
+    def solve_async(self, max_iter=30, force=False):
+        """Enqueue the solve on the handle's stream and return; wait() (or any getter) completes it."""
+        self._chk(self.L.gusto_solve_async(self.h, int(max_iter), int(bool(force))), "solve_async")
+
+    def wait(self):
+        self._chk(self.L.gusto_wait(self.h), "wait")
+
+    def set_problems_dev(self, B, x_init_ptr, goal_lo_ptr, goal_hi_ptr, tf_ptr, X0_ptr=None, U0_ptr=None):
+        """gusto_set_problems_dev: inputs already resident in HBM (raw device pointers)."""
+        self._chk(self.L.gusto_set_problems_dev(self.h, int(B), x_init_ptr, goal_lo_ptr, goal_hi_ptr, tf_ptr, X0_ptr,
+                                                U0_ptr), "set_problems_dev")
+        self.B = int(B)
 
     def last_solve_ms(self):
         ms = C.c_double()

@@ -198,6 +198,7 @@ static int set_problems_impl(gusto_handle h, int B, const double* x_init, const 
         return GUSTO_ERR_ARG;
     }
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcw = gusto_finish(h); if (rcw) return rcw; }
     const size_t n = h->n, m = h->m, N = h->N;
     h->B = B;
     HIPCHK(h, hipMemcpyAsync(h->d_xinit, x_init, sizeof(double) * B * n, kind, h->stream));
@@ -227,7 +228,25 @@ int gusto_solve(gusto_handle h, int max_iter, int force) {
     if (!h || max_iter < 0) return GUSTO_ERR_ARG;
     if (!h->have_problems) { h->err = "gusto_solve: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
+    int rc = gusto_finish(h);
+    if (rc) return rc;
+    rc = do_scp(h, 0, max_iter, force ? 1 : 0);
+    return rc ? rc : gusto_finish(h);
+}
+
+int gusto_solve_async(gusto_handle h, int max_iter, int force) {
+    if (!h || max_iter < 0) return GUSTO_ERR_ARG;
+    if (!h->have_problems) { h->err = "gusto_solve_async: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = gusto_finish(h);
+    if (rc) return rc;
     return do_scp(h, 0, max_iter, force ? 1 : 0);
+}
+
+int gusto_wait(gusto_handle h) {
+    if (!h) return GUSTO_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    return gusto_finish(h);
 }
 
 // development hook (GUSTO_PROFILE builds): per-problem phase cycle counters [B][16]; not part of gusto_hip.h
@@ -238,12 +257,14 @@ int gusto_dev_get_prof(gusto_handle h, long long* out) {
 }
 
 int gusto_last_solve_ms(gusto_handle h, double* ms) {
+    if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
     if (!h || !ms) return GUSTO_ERR_ARG;
     *ms = h->last_ms;
     return GUSTO_OK;
 }
 
 int gusto_get_traj(gusto_handle h, double* X, double* U) {
+    if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
     if (!h || !h->have_problems) return GUSTO_ERR_STATE;
     HIPCHK(h, hipSetDevice(h->device));
     if (X) HIPCHK(h, hipMemcpy(X, h->d_X, sizeof(double) * h->B * h->N * h->n, hipMemcpyDeviceToHost));
@@ -251,6 +272,7 @@ int gusto_get_traj(gusto_handle h, double* X, double* U) {
     return GUSTO_OK;
 }
 int gusto_get_traj_dev(gusto_handle h, const double** X, const double** U) {
+    if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
     if (!h) return GUSTO_ERR_ARG;
     if (X) *X = h->d_X;
     if (U) *U = h->d_U;
@@ -258,6 +280,7 @@ int gusto_get_traj_dev(gusto_handle h, const double** X, const double** U) {
 }
 
 int gusto_get_status(gusto_handle h, int* iterations, int* converged, int* successful, int* stop, int* ipm) {
+    if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
     if (!h || !h->have_problems) return GUSTO_ERR_STATE;
     HIPCHK(h, hipSetDevice(h->device));
     std::vector<int> st((size_t)h->B * ST_NI);
@@ -273,6 +296,7 @@ int gusto_get_status(gusto_handle h, int* iterations, int* converged, int* succe
 }
 
 int gusto_get_dual(gusto_handle h, double* dual) {
+    if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
     if (!h || !dual || !h->have_problems) return GUSTO_ERR_STATE;
     HIPCHK(h, hipSetDevice(h->device));
     std::vector<double> sd((size_t)h->B * SD_ND);
@@ -283,6 +307,7 @@ int gusto_get_dual(gusto_handle h, double* dual) {
 }
 
 int gusto_get_history(gusto_handle h, gusto_history* o) {
+    if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
     if (!h || !o || !h->have_problems) return GUSTO_ERR_STATE;
     HIPCHK(h, hipSetDevice(h->device));
     o->hist_cap = h->hist_cap;
@@ -310,6 +335,7 @@ int gusto_subproblem(gusto_handle h, int B, const double* Xp, const double* Up, 
         return GUSTO_ERR_STATE;
     }
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcw = gusto_finish(h); if (rcw) return rcw; }
     const size_t n = h->n, m = h->m, N = h->N;
     HIPCHK(h, hipMemcpy(h->d_X, Xp, sizeof(double) * B * N * n, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_U, Up, sizeof(double) * B * N * m, hipMemcpyHostToDevice));
@@ -317,6 +343,7 @@ int gusto_subproblem(gusto_handle h, int B, const double* Xp, const double* Up, 
     HIPCHK(h, hipMemcpy(h->d_subW, omega, sizeof(double) * B, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_subT, toggle, sizeof(double) * B, hipMemcpyHostToDevice));
     int rc = do_scp(h, 1, 0, 0);
+    if (!rc) rc = gusto_finish(h);
     if (rc) return rc;
     if (Xn) HIPCHK(h, hipMemcpy(Xn, h->d_subX, sizeof(double) * B * N * n, hipMemcpyDeviceToHost));
     if (Un) HIPCHK(h, hipMemcpy(Un, h->d_subU, sizeof(double) * B * N * m, hipMemcpyDeviceToHost));

@@ -27,6 +27,7 @@ struct gusto_handle_s {
     int *d_subSt = nullptr, *d_subIt = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
+    bool pending = false;  // a gusto_solve_async launch has not been waited for yet
     bool have_problems = false;
     std::string err;
 };
@@ -49,7 +50,18 @@ template <class Tp> static hipError_t dalloc(Tp** p, size_t count) {
 }
 
 
-// defined in model_<id>.hip
+// completes an enqueued solve: blocks on the handle's stream and takes the kernel time from its events
+static inline int gusto_finish(gusto_handle h) {
+    if (!h->pending) return GUSTO_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_ms = ms;
+    h->pending = false;
+    return GUSTO_OK;
+}
+
+// defined in model_<id>.hip (the scp launch only enqueues; gusto_finish completes it)
 int gusto_launch_init_m0(gusto_handle h, bool straight);
 int gusto_launch_init_m1(gusto_handle h, bool straight);
 int gusto_launch_init_m2(gusto_handle h, bool straight);

@@ -55,10 +55,7 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     hipLaunchKernelGGL(kern, dim3(h->B), dim3(NT), lds, h->stream, P);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    h->last_ms = ms;
+    h->pending = true;   // completed by gusto_finish (handle.hpp)
     return GUSTO_OK;
 }
 

@@ -104,6 +104,11 @@ int gusto_set_problems_dev(gusto_handle h, int B, const double* x_init_dev, cons
 /* solve_gusto_jump!(SCPS, SCPP, solver, max_iter, force) for the whole batch (scp_gusto.jl:49-176).
  * Synchronous.  Re-entrant: a second call resumes every problem (iter_cap = iterations + max_iter, :67). */
 int gusto_solve(gusto_handle h, int max_iter, int force);
+/* The same solve, enqueued on the handle's stream without blocking the host; gusto_wait (or any getter, setter or
+ * solve on the handle) completes it.  New: the reference is blocking.  Two handles used alternately keep the GPU
+ * full across consecutive batches -- the tail of one batch (its slowest problems) overlaps the head of the next. */
+int gusto_solve_async(gusto_handle h, int max_iter, int force);
+int gusto_wait(gusto_handle h);
 /* GPU time of the last gusto_solve, measured with HIP events on the stream the kernel ran on */
 int gusto_last_solve_ms(gusto_handle h, double* ms);
 

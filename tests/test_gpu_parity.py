@@ -86,7 +86,9 @@ def test_subproblem_parity_astrobee_manifold():
     P = g.problems
     boxes, sph = P.iss_corner_env(True)
     x0, glo, ghi, tf = P.astrobee_manifold_batch(8)
-    _sub_parity(g.ASTROBEE_SE3_MANIFOLD, 50, boxes, sph, x0, glo, ghi, tf, 1e3, 1.0, 1e3 / 8 + 0.03)
+    # 1e-5 as for the manifold golden vectors: Delta0 = 1e3 leaves positions (O(10) m) weakly determined, so the two
+    # implementations' different summation orders show at the 1e-6 level in x while u agrees to 1e-9
+    _sub_parity(g.ASTROBEE_SE3_MANIFOLD, 50, boxes, sph, x0, glo, ghi, tf, 1e3, 1.0, 1e3 / 8 + 0.03, atol=1e-5)
 
 
 def _scp_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30):
