@@ -497,7 +497,9 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
     constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n, NZN = NZ * n;
     constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64, RZ = (NZN + 63) / 64;
     const int tid = K.tid, N = K.N;
-    int zJ[RZ], zG[RZ], hI[RQ], hJ[RQ], nI[RN], nJ[RN];
+    int zJ[RZ], zG[RZ], hI[RQ], hJ[RQ], nI[RN], nJ[RN], tL[RT], tC[RT];
+#pragma unroll
+    for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; tL[r] = (e < NPG) ? e / NZ : 0; tC[r] = (e < NPG) ? e % NZ : 0; }
 #pragma unroll
     for (int r = 0; r < RZ; r++) { const int e = tid + 64 * r; zJ[r] = (e < NZN) ? e / n : 0; zG[r] = (e < NZN) ? e % n : 0; }
 #pragma unroll
@@ -552,6 +554,62 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
         // ---- phase AB -------------------------------------------------------------------------------
         // Small models: every LDS operand of the three products (H, Z, r) is requested before the first FMA, so the
         // stage pays ONE LDS latency here instead of three back-to-back read -> wait -> compute chains.
+#ifndef GUSTO_FACTOR_ONESTEP
+        // Two steps, T = P [Phi Gam] then H = QQ + [Phi Gam]^T T: each lane contracts ONE index per step (2 x n FMAs
+        // and 4 n operands instead of n^2 + n FMAs and n^2 + 2 n operands), at the price of one more trip through LDS.
+        if constexpr (2 * (RT + RZ + 1) * n <= 96) {
+            double tp[RT][n], tg[RT][n], za[RZ][n], zb[RZ][n], ra[n], rb[n];
+            const bool isr = tid < n;
+            const int ri = isr ? tid : ((tid < 2 * n) ? tid - n : 0);
+#pragma unroll
+            for (int r = 0; r < RT; r++)
+#pragma unroll
+                for (int q = 0; q < n; q++) { tp[r][q] = K.sP[tL[r] * n + q]; tg[r][q] = PGs[q * NZ + tC[r]]; }
+#pragma unroll
+            for (int r = 0; r < RZ; r++)
+#pragma unroll
+                for (int l = 0; l < n; l++) { za[r][l] = PGs[l * NZ + zJ[r]]; zb[r][l] = K.sPi[l * n + zG[r]]; }
+#pragma unroll
+            for (int l = 0; l < n; l++) { ra[l] = *(isr ? K.sP + ri * n + l : K.sPi + l * n + ri); rb[l] = K.cv[k * n + l]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                double t = 0;
+#pragma unroll
+                for (int q = 0; q < n; q++) t += tp[r][q] * tg[r][q];
+                if (tid + 64 * r < NPG) K.sT[tid + 64 * r] = t;
+            }
+#pragma unroll
+            for (int r = 0; r < RZ; r++) {
+                double z = 0;
+#pragma unroll
+                for (int l = 0; l < n; l++) z += za[r][l] * zb[r][l];
+                // E = [M^T C^T; b^T M^T C^T], M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
+                if (k == N - 1 && K.is_goal(zG[r])) z += 0.5 * (PGs[zG[r] * NZ + zJ[r]] + ((zJ[r] == zG[r]) ? 1.0 : 0.0));
+                if (tid + 64 * r < NZN) K.sZ[tid + 64 * r] = z;
+            }
+            {   // r_k = P_k c_k and Pi_k^T c_k for the stage-parallel blocks
+                double rr = 0;
+#pragma unroll
+                for (int l = 0; l < n; l++) rr += ra[l] * rb[l];
+                if (tid < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = rr;
+            }
+            K.sync();
+            double pgi[RQ][n], tj[RQ][n];
+#pragma unroll
+            for (int r = 0; r < RQ; r++)
+#pragma unroll
+                for (int l = 0; l < n; l++) { pgi[r][l] = PGs[l * NZ + hI[r]]; tj[r][l] = K.sT[l * NZ + hJ[r]]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RQ; r++) {
+                double h = qq[r];
+#pragma unroll
+                for (int l = 0; l < n; l++) h += pgi[r][l] * tj[r][l];
+                if (tid + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = h; K.sHh[hJ[r] * NZ + hI[r]] = h; }
+            }
+        } else
+#endif
         if constexpr (n * n + 2 * (RQ + RZ + 1) * n <= 112) {
             double pm[n * n], pgj[RQ][n], pgi[RQ][n], za[RZ][n], zb[RZ][n], ra[n], rb[n];
             const bool isr = tid < n;

@@ -1,5 +1,7 @@
 // launch.hpp -- kernel launch templates, instantiated once per model in model_<id>.hip
 #pragma once
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "handle.hpp"
@@ -46,7 +48,8 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     if (rc) return rc;
     P.mode = mode; P.max_iter = max_iter; P.force = force;
     const int NT = 64 * ((h->N + 63) / 64);
-    const size_t lds = (size_t)P.ll.total * sizeof(double);
+    size_t lds = (size_t)P.ll.total * sizeof(double);
+    if (const char* pad = getenv("GUSTO_DEV_LDS_KB")) lds = std::max(lds, (size_t)atoi(pad) * 1024);  // occupancy experiments
     if (lds > 160 * 1024) { h->err = "problem does not fit the 160 KiB LDS of a CU"; return GUSTO_ERR_ARG; }
     // a problem with N <= 64 knots runs as one wave per workgroup (no barriers at all)
     auto kern = (NT == 64) ? &scp_kernel<MODEL, true> : &scp_kernel<MODEL, false>;
