@@ -61,8 +61,8 @@ def cpu_baseline(problems, env, n_sample, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--cpu-sample", type=int, default=0, help="0 = 2048 problems per usable host core (about 15-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

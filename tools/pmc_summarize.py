@@ -1,0 +1,53 @@
+"""Turns the rocprofv3 CSVs of tools/profile_round.sh into the committed summaries under profiles/.
+   python tools/pmc_summarize.py gpurun_out/<tag> <round>"""
+import collections, csv, glob, json, os, shutil, sys
+src, rnd = sys.argv[1], int(sys.argv[2])
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+tag = f"r{rnd:02d}"
+
+
+def per_kernel(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+    return acc
+
+
+out = {"round": rnd, "workload": "freeflyerSE2 batch=4096 N=50, ONE gusto_solve launch (tools/pmc_probe.py)"}
+log = open(os.path.join(src, "pmc_FETCH_SIZE.log")).read()
+for ln in log.splitlines():
+    if ln.startswith("kernel_ms"):
+        p = ln.split()
+        out["kernel_ms"], ipm, scp = float(p[1]), int(p[3]), int(p[5])
+f = per_kernel(os.path.join(src, "pmc", "FETCH_SIZE_counter_collection.csv"))
+w = per_kernel(os.path.join(src, "pmc", "WRITE_SIZE_counter_collection.csv"))
+scp_k = [k for k in f if "scp_kernel" in k][0]
+cal_k = [k for k in f if "vectorized_elementwise" in k][0]
+out["kernel"] = scp_k.replace("void ", "").split("(")[0]
+out["FETCH_SIZE_kb_raw"], out["WRITE_SIZE_kb_raw"] = f[scp_k]["FETCH_SIZE"], w[scp_k]["WRITE_SIZE"]
+out["calibration"] = {
+    "pattern": "torch float64 elementwise over 1 GiB: zeros fill + (a + 1.0)",
+    "FETCH_SIZE_kb": f[cal_k]["FETCH_SIZE"], "expected_read_kb": 1048576,
+    "WRITE_SIZE_kb": w[cal_k]["WRITE_SIZE"], "expected_write_kb": 2097152,
+    "note": "FETCH_SIZE reports 1/2 of the bytes read on gfx950 (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE is exact"}
+out["fetch_bytes"] = 2.0 * 1024 * out["FETCH_SIZE_kb_raw"]
+out["write_bytes"] = 1024 * out["WRITE_SIZE_kb_raw"]
+out["traffic_bytes_per_launch"] = out["fetch_bytes"] + out["write_bytes"]
+out["hbm_gbs"] = out["traffic_bytes_per_launch"] / (out["kernel_ms"] * 1e-3) / 1e9
+out["algorithmic_bytes_per_launch"] = 51600 * ipm + 24000 * scp
+out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
+sq = {}
+for p in sorted(glob.glob(os.path.join(src, "sq", "*counter_collection.csv"))):
+    for k, v in per_kernel(p).items():
+        if "scp_kernel" in k:
+            sq.update(v)
+out["sq_counters_per_launch"] = sq
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
+shutil.copy(os.path.join(src, "pmc", "FETCH_SIZE_counter_collection.csv"), os.path.join(dst, f"{tag}_pmc_FETCH_SIZE.csv"))
+shutil.copy(os.path.join(src, "pmc", "WRITE_SIZE_counter_collection.csv"), os.path.join(dst, f"{tag}_pmc_WRITE_SIZE.csv"))
+shutil.copy(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "stats", "stats_kernel_trace.csv"), os.path.join(dst, f"{tag}_kernel_trace.csv"))
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+if os.path.exists(os.path.join(src, "bench_serial.json")):
+    shutil.copy(os.path.join(src, "bench_serial.json"), os.path.join(dst, f"{tag}_bench_overlap1.json"))
+print(json.dumps({k: v for k, v in out.items() if k != "calibration"}, indent=1))

@@ -7,8 +7,9 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --overlap 1 --no-cpu-baseline > $OUT/bench_serial.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc -o $c -- python tools/pmc_probe.py > $OUT/pmc_$c.log 2>&1
 done
