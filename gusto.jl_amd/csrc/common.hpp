@@ -45,10 +45,22 @@ GD constexpr int sidx(int i, int j, int n) {
     return i <= j ? i * n - i * (i - 1) / 2 + (j - i) : j * n - j * (j - 1) / 2 + (i - j);
 }
 
+// Stage records of the per-problem workspace: every per-knot factor array is padded to a multiple of 64 doubles per
+// knot, so a sweep stores/loads a record with ONE unconditional, fully coalesced access per 64 entries at
+// `uniform base + (k * stride + lane)` (SGPR base + VGPR offset; no per-lane pointers, no predication).
+// K (m x n), D (m x n) and S^-1 (m x m) of a knot share one record.
+template <int MODEL> struct Rec {
+    using T = MT<MODEL>;
+    static constexpr int n = T::n, m = T::m, NZ = n + m;
+    static constexpr int r64(int c) { return (c + 63) / 64 * 64; }
+    static constexpr int SQQ = r64(NZ * (NZ + 1) / 2), SNN = r64(n * n), SKD = r64(2 * m * n + m * m);
+    static constexpr int oK = 0, oD = m * n, oS = 2 * m * n;
+};
+
 // per-problem global workspace, offsets in doubles
 struct WsLayout {
     int nslot;
-    size_t rowstate, obs_nh, obs_c0, obs_mask, PG, QQ, Paft, Piaft, K, Sinv, D, Phicl, pvt, dummy, total;
+    size_t rowstate, obs_nh, obs_c0, obs_mask, PG, QQ, Paft, Piaft, KD, Phicl, pvt, total;
 };
 template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     using T = MT<MODEL>;
@@ -62,15 +74,13 @@ template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     L.obs_c0 = take((size_t)n_obs * N);
     L.obs_mask = take((size_t)N);
     L.PG = take((size_t)(T::LTI ? 1 : N) * n * NZ);
-    L.QQ = take((size_t)N * (NZ * (NZ + 1) / 2));
-    L.Paft = take((size_t)N * n * n);
-    L.Piaft = take((size_t)N * n * n);
-    L.K = take((size_t)N * m * n);
-    L.Sinv = take((size_t)N * m * m);
-    L.D = take((size_t)N * m * n);
-    L.Phicl = take((size_t)N * n * n);
+    using R = Rec<MODEL>;
+    L.QQ = take((size_t)N * R::SQQ);
+    L.Paft = take((size_t)(N + 1) * R::SNN) + R::SNN;    // record -1 exists: the sweep stores P_{k-1} unconditionally
+    L.Piaft = take((size_t)(N + 1) * R::SNN) + R::SNN;
+    L.KD = take((size_t)N * R::SKD);
+    L.Phicl = take((size_t)N * R::SNN);
     L.pvt = take((size_t)N * (3 * n + 3 * m));
-    L.dummy = take(64);  // store target of the idle lanes of the sweeps (keeps their VMEM ops branch-free)
     L.total = o;
     return L;
 }

@@ -42,6 +42,7 @@ template <bool ONEWAVE> GD void blk_sync() {
 template <int MODEL, bool ONEWAVE> struct Blk {
     using T = MT<MODEL>;
     using C = LdsC<MODEL>;
+    using R = Rec<MODEL>;
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr bool ONE = ONEWAVE;
     const KParams& P;
@@ -55,7 +56,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     // LDS per-knot vectors
     double *Xw, *Xp, *dY, *rd, *pv, *cv, *rv, *qrd, *nu, *nun, *dXs, *Uw, *Up, *qu, *dv, *dUs;
     // global workspace of this problem
-    double *rowstate, *obs_nh, *obs_c0, *PG, *QQ, *Paft, *Piaft, *Kg, *Sinvg, *Dg, *Phicl, *dummy;
+    double *rowstate, *obs_nh, *obs_c0, *PG, *QQ, *Paft, *Piaft, *KD, *Phicl;
     uint64_t* obs_mask;
     const double *x_init, *goal_lo, *goal_hi;
     unsigned goalmask;  // bit i: coordinate i of x_N has a point goal (goal_lo == goal_hi)
@@ -75,8 +76,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         const WsLayout& W = P.wl;
         rowstate = w + W.rowstate; obs_nh = w + W.obs_nh; obs_c0 = w + W.obs_c0;
         obs_mask = reinterpret_cast<uint64_t*>(w + W.obs_mask);
-        PG = w + W.PG; QQ = w + W.QQ; Paft = w + W.Paft; Piaft = w + W.Piaft; Kg = w + W.K; Sinvg = w + W.Sinv;
-        Dg = w + W.D; Phicl = w + W.Phicl; dummy = w + W.dummy;
+        PG = w + W.PG; QQ = w + W.QQ; Paft = w + W.Paft; Piaft = w + W.Piaft; KD = w + W.KD; Phicl = w + W.Phicl;
         {   // knot-private vectors in the global workspace, the linearisation point = the stored trajectory
             double* q = w + W.pvt;
             rd = q; qrd = q + N * n; dXs = q + 2 * N * n; dUs = q + 3 * N * n; qu = dUs + N * m; dv = qu + N * m;
@@ -116,6 +116,7 @@ template <class BLK> GD void load_M_Gam(const BLK& K, int k, double* M, double* 
 // the signed distances of the linearisation point and freezes which obstacle rows are active this trip.
 template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
     using T = MT<MODEL>;
+    using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m;
     const int k = K.tid;
     if (k < K.N) {
@@ -175,6 +176,7 @@ template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
 // zero when coordinate i has no point goal.
 template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
     using T = MT<MODEL>;
+    using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ;
     constexpr int QPT = (NQ + 63) / 64, PPT = (NPG + 63) / 64;
     const int tid = K.tid, NT = K.nt(), N = K.N;
@@ -182,7 +184,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
     // operands of knot N-1
     double qq[QPT], pgn[PPT];
 #pragma unroll
-    for (int r = 0; r < QPT; r++) { const int e = tid + r * NT; qq[r] = (e < NQ) ? K.QQ[(size_t)(N - 1) * NQ + e] : 0.0; }
+    for (int r = 0; r < QPT; r++) { const int e = tid + r * NT; qq[r] = (e < NQ) ? K.QQ[(size_t)(N - 1) * R::SQQ + e] : 0.0; }
 #pragma unroll
     for (int r = 0; r < PPT; r++) pgn[r] = 0.0;
     {
@@ -197,7 +199,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
 #pragma unroll
         for (int r = 0; r < QPT; r++) {
             const int e = tid + r * NT;
-            qqn[r] = (k > 0 && e < NQ) ? K.QQ[(size_t)(k - 1) * NQ + e] : 0.0;
+            qqn[r] = (k > 0 && e < NQ) ? K.QQ[(size_t)(k - 1) * R::SQQ + e] : 0.0;
         }
         if (!T::LTI && k > 1) {
             const double* pg = K.PGk(k - 1);
@@ -206,8 +208,8 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
         }
         // value function after knot k
         for (int e = tid; e < n * n; e += NT) {
-            K.Paft[(size_t)k * n * n + e] = K.sP[e];
-            K.Piaft[(size_t)k * n * n + e] = K.sPi[e];
+            K.Paft[(size_t)k * R::SNN + e] = K.sP[e];
+            K.Piaft[(size_t)k * R::SNN + e] = K.sPi[e];
         }
         // phase 1: T = P [Phi Gam],  Z = [Phi Gam]^T Pi (+ E at the last knot)
         // (operands are fetched as a batch, then pinned with a scheduling barrier: left alone, the compiler
@@ -291,7 +293,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
                 }
                 double* sw = isK ? K.sW : K.sV;
                 double* sk = isK ? K.sK : K.sD;
-                double* gk = (isK ? K.Kg : K.Dg) + (size_t)k * m * n;
+                double* gk = K.KD + (size_t)k * R::SKD + (isK ? R::oK : R::oD);
 #pragma unroll
                 for (int i = 0; i < m; i++) { sw[i * n + g] = w[i]; sk[i * n + g] = kk[i]; gk[i * n + g] = kk[i]; }
             }
@@ -300,7 +302,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
                 double s = 0;
 #pragma unroll
                 for (int l = 0; l < m; l++) if (l >= i && l >= j) s += Li[l * m + i] * Li[l * m + j];
-                K.Sinvg[(size_t)k * m * m + e] = s;
+                K.KD[(size_t)k * R::SKD + R::oS + e] = s;
             }
         }
         K.sync();
@@ -331,7 +333,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
 #pragma unroll
             for (int l = 0; l < m; l++) s += a[l] * bb[l];
             if (q == 0) K.sP[e2] = s;
-            else if (q == 1) K.Phicl[(size_t)k * n * n + e2] = s;
+            else if (q == 1) K.Phicl[(size_t)k * R::SNN + e2] = s;
             else if (q == 2) K.sPi[e2] = s;
             else K.sGd[e2] = s;
         }
@@ -364,13 +366,14 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
 template <class BLK> GD void backward_sweep_mw(BLK& K) {
     // pt_{k-1} = Phicl_k^T pt_k + qq_k (pt = p + r, qq_k = qt_k + r_{k-1}); pv[k]: qq_k on entry, pt_k on exit
     constexpr int n = BLK::n;
+    using R = typename BLK::R;
     const int tid = K.tid, N = K.N;
     double p = 0.0, col[n], coln[n];
 #pragma unroll
     for (int l = 0; l < n; l++) { col[l] = 0; coln[l] = 0; }
     if (tid < n) {
 #pragma unroll
-        for (int l = 0; l < n; l++) col[l] = K.Phicl[(size_t)(N - 1) * n * n + l * n + tid];
+        for (int l = 0; l < n; l++) col[l] = K.Phicl[(size_t)(N - 1) * R::SNN + l * n + tid];
         p = K.rv[(N - 1) * n + tid];
     }
     for (int k = N - 1; k >= 1; k--) {
@@ -378,7 +381,7 @@ template <class BLK> GD void backward_sweep_mw(BLK& K) {
         if (tid < n) {
             if (k > 1) {
 #pragma unroll
-                for (int l = 0; l < n; l++) coln[l] = K.Phicl[(size_t)(k - 1) * n * n + l * n + tid];
+                for (int l = 0; l < n; l++) coln[l] = K.Phicl[(size_t)(k - 1) * R::SNN + l * n + tid];
             }
             buf[tid] = p;
         }
@@ -403,6 +406,7 @@ template <class BLK> GD void backward_sweep_mw(BLK& K) {
 // dy_k = Phicl_k dy_{k-1} + ct_k, k = 0..N-1; dY[k] holds ct_k on entry and dy_k on exit
 template <class BLK> GD void forward_sweep_mw(BLK& K) {
     constexpr int n = BLK::n;
+    using R = typename BLK::R;
     const int tid = K.tid, N = K.N;
     double y = 0.0, row[n], rown[n];
 #pragma unroll
@@ -416,7 +420,7 @@ template <class BLK> GD void forward_sweep_mw(BLK& K) {
         if (tid < n) {
             if (k + 1 < N) {
 #pragma unroll
-                for (int l = 0; l < n; l++) rown[l] = K.Phicl[(size_t)(k + 1) * n * n + tid * n + l];
+                for (int l = 0; l < n; l++) rown[l] = K.Phicl[(size_t)(k + 1) * R::SNN + tid * n + l];
             }
             buf[tid] = y;
         }
@@ -443,12 +447,13 @@ template <class BLK> GD void forward_sweep_mw(BLK& K) {
 template <int MODEL> struct SweepView {
     using T = MT<MODEL>;
     using C = LdsC<MODEL>;
+    using R = Rec<MODEL>;
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr bool ONE = true;
     double *lds, *sP, *sPi, *sPG, *sT, *sHh, *sZ, *sK, *sD, *sW, *sV, *sGd;
     int* lut;
     double *cv, *rv, *nun, *pv, *dY;
-    double *PG, *QQ, *Paft, *Piaft, *Kg, *Sinvg, *Dg, *Phicl, *dummy;
+    double *PG, *QQ, *Paft, *Piaft, *KD, *Phicl;
     const gusto_model_params* mpp;
     struct PW { const gusto_model_params& mp; } ;
     int tid, N;
@@ -464,7 +469,7 @@ template <int MODEL> struct SweepView {
         v.sZ = K.lds + C::sZ; v.sK = K.lds + C::sK; v.sD = K.lds + C::sD; v.sW = K.lds + C::sW; v.sV = K.lds + C::sV;
         v.sGd = K.lds + C::sGd; v.lut = K.lut;
         v.cv = K.cv; v.rv = K.rv; v.nun = K.nun; v.pv = K.pv; v.dY = K.dY;
-        v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.Kg = K.Kg; v.Sinvg = K.Sinvg; v.Dg = K.Dg; v.dummy = K.dummy;
+        v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.KD = K.KD;
         v.Phicl = K.Phicl; v.mpp = &K.P.mp; v.tid = K.tid; v.N = K.N; v.dt = K.dt; v.goalmask = K.goalmask;
         return v;
     }
@@ -482,6 +487,7 @@ GD double readlane_f64(double v, int lane) {
 // time-varying models double-buffer.
 template <int MODEL, class BLK> GD double* pg_buf(const BLK& K, int k) {
     using T = MT<MODEL>;
+    using R = Rec<MODEL>;
     constexpr int NPG = T::n * (T::n + T::m);
     return K.sPG + (k == 0 ? 2 * NPG : (T::LTI ? 0 : (k & 1) * NPG));
 }
@@ -494,8 +500,9 @@ template <int MODEL, class BLK> GD double* pg_buf(const BLK& K, int k) {
 //       through an explicit S^-1: with barrier weights ~1/mu in Hyy that loses every digit).
 template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, Prof& pf) {
     using T = MT<MODEL>;
+    using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n, NZN = NZ * n;
-    constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64, RZ = (NZN + 63) / 64;
+    constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64, RZ = (NZN + 63) / 64, RKD = R::SKD / 64;
     const int tid = K.tid, N = K.N;
     int zJ[RZ], zG[RZ], hI[RQ], hJ[RQ], nI[RN], nJ[RN], tL[RT], tC[RT];
 #pragma unroll
@@ -524,7 +531,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
     }
     double qq[RQ], pgn[RT];
 #pragma unroll
-    for (int r = 0; r < RQ; r++) { const int e = tid + 64 * r; qq[r] = (e < NQ) ? K.QQ[(size_t)(N - 1) * NQ + e] : 0.0; }
+    for (int r = 0; r < RQ; r++) { const int e = tid + 64 * r; qq[r] = K.QQ[(size_t)(N - 1) * R::SQQ + e]; }
 #pragma unroll
     for (int r = 0; r < RT; r++) pgn[r] = 0.0;
 #pragma unroll
@@ -532,8 +539,8 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
         const int e = tid + 64 * r;
         if (e < NN) {
             K.sP[e] = 0; K.sPi[e] = 0; K.sGd[e] = 0;
-            K.Paft[(size_t)(N - 1) * NN + e] = 0.0;   // value function after the last knot
-            K.Piaft[(size_t)(N - 1) * NN + e] = 0.0;
+            K.Paft[(size_t)(N - 1) * R::SNN + e] = 0.0;   // value function after the last knot
+            K.Piaft[(size_t)(N - 1) * R::SNN + e] = 0.0;
         }
     }
     K.sync();
@@ -543,7 +550,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
 #pragma unroll
         for (int r = 0; r < RQ; r++) {   // unconditional (clamped) prefetch: see phase CD
             const int e = tid + 64 * r;
-            qqn[r] = K.QQ[(size_t)((k > 0) ? k - 1 : 0) * NQ + ((e < NQ) ? e : NQ - 1)];
+            qqn[r] = K.QQ[(size_t)((k > 0) ? k - 1 : 0) * R::SQQ + e];   // (padded record: every lane has an entry)
         }
         if (!T::LTI) {
             const double* pg = K.PGk((k > 1) ? k - 1 : 0);
@@ -742,6 +749,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
 #pragma unroll
             for (int r = 0; r < RQ; r++) qq[r] = qqn[r];
             __builtin_amdgcn_sched_barrier(0);
+            double kdv[RN];
 #pragma unroll
             for (int r = 0; r < RN; r++) {
                 const int e2 = tid + 64 * r;
@@ -770,24 +778,25 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 for (int l = 0; l < m; l++) { pn -= wi[l] * wj[l]; ph -= gi[r][l] * kj[l]; pin -= wi[l] * vj[l]; gd += vi[l] * vj[l]; }
                 pf.tick(PF_F6);
                 if (on) { K.sP[e2] = pn; K.sPi[e2] = pin; K.sGd[e2] = gd; }
-                double* const dmy = K.dummy + tid;
-                const bool onp = on && k > 0;
-                *(on ? K.Phicl + (size_t)k * NN + e2 : dmy) = ph;
-                *(onp ? K.Paft + (size_t)(k - 1) * NN + e2 : dmy) = pn;
-                *(onp ? K.Piaft + (size_t)(k - 1) * NN + e2 : dmy) = pin;
-                // lanes of rows 0..m-1 own K[i][j], rows m..2m-1 own D[i-m][j]  (n >= 2m for every model)
+                // padded stage records (Rec<MODEL>): every lane stores, idle lanes land in the padding; record -1 of
+                // Paft/Piaft exists for k == 0
+                K.Phicl[(size_t)k * R::SNN + e2] = ph;
+                K.Paft[(size_t)(k - 1) * R::SNN + e2] = pn;
+                K.Piaft[(size_t)(k - 1) * R::SNN + e2] = pin;
+                // lanes of rows 0..m-1 hold K[i][j], rows m..2m-1 hold D[i-m][j]  (n >= 2m for every model): entry
+                // i*n + j of the K|D|S^-1 record
                 static_assert(n >= 2 * m, "K/D store mapping");
                 double kd = kj[0];
 #pragma unroll
                 for (int a = 1; a < m; a++) kd = (i == a) ? kj[a] : kd;
 #pragma unroll
                 for (int a = 0; a < m; a++) kd = (i == m + a) ? dj[a] : kd;
-                const int ia = (i < m) ? i : i - m;
-                double* kdp = ((i < m) ? K.Kg : K.Dg) + (size_t)k * m * n + ia * n + j;
-                *((on && i < 2 * m) ? kdp : dmy) = kd;
+                kdv[r] = kd;
             }
-            {   // S^-1 = L^-T L^-1 (feed-forward only): computed wave-uniformly, lane e < m*m keeps entry e
-                double sv = 0;
+            {   // S^-1 = L^-T L^-1 (feed-forward only): computed wave-uniformly, the lane of record entry oS + e keeps entry e
+                double sv[RKD];
+#pragma unroll
+                for (int r = 0; r < RKD; r++) sv[r] = 0;
 #pragma unroll
                 for (int a = 0; a < m; a++)
 #pragma unroll
@@ -795,9 +804,20 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                         double s = 0;
 #pragma unroll
                         for (int l = a; l < m; l++) s += Li[l * m + a] * Li[l * m + c];
-                        sv = (tid == a * m + c || tid == c * m + a) ? s : sv;
+#pragma unroll
+                        for (int r = 0; r < RKD; r++) {
+                            const int e = tid + 64 * r - R::oS;
+                            sv[r] = (e == a * m + c || e == c * m + a) ? s : sv[r];
+                        }
                     }
-                *((tid < m * m) ? K.Sinvg + (size_t)k * m * m + tid : K.dummy + tid) = sv;
+                // the K|D|S^-1 record: entries [0, 2mn) come from the (i, j) lanes above, [2mn, 2mn + m^2) are S^-1
+#pragma unroll
+                for (int r = 0; r < RKD; r++) {
+                    const int e = tid + 64 * r;
+                    double v = (r < RN) ? kdv[r < RN ? r : 0] : 0.0;
+                    if (e >= R::oS) v = sv[r];
+                    K.KD[(size_t)k * R::SKD + e] = v;
+                }
             }
         }
         if (!T::LTI && k > 1) {
@@ -819,6 +839,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
 //           pv[k] holds qq_k on entry and pt_k on exit.
 template <class BLK> GD void backward_sweep_1w(BLK K) {
     constexpr int n = BLK::n, C = 64 / n;
+    using R = typename BLK::R;
     const int tid = K.tid, N = K.N;
     const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
     double col[n], coln[n], qv, qvn = 0, pval;
@@ -826,7 +847,7 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
         const int kk = k0 - g;
         const bool ok = kk >= 1;
 #pragma unroll
-        for (int l = 0; l < n; l++) c[l] = ok ? K.Phicl[(size_t)kk * n * n + l * n + i] : 0.0;
+        for (int l = 0; l < n; l++) c[l] = ok ? K.Phicl[(size_t)kk * R::SNN + l * n + i] : 0.0;
         q = ok ? K.pv[kk * n + i] : 0.0;
     };
     fetch(N - 1, col, qv);
@@ -859,6 +880,7 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
 // forward: dy_k = Phicl_k dy_{k-1} + ct_k, k = 0..N-1; dY[k] holds ct_k on entry and dy_k on exit
 template <class BLK> GD void forward_sweep_1w(BLK K) {
     constexpr int n = BLK::n, C = 64 / n;
+    using R = typename BLK::R;
     const int tid = K.tid, N = K.N;
     const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
     double row[n], rown[n], cv, cvn = 0, yval = 0.0;
@@ -866,7 +888,7 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
         const int kk = k0 + g;
         const bool ok = kk < N;
 #pragma unroll
-        for (int l = 0; l < n; l++) r[l] = ok ? K.Phicl[(size_t)kk * n * n + i * n + l] : 0.0;
+        for (int l = 0; l < n; l++) r[l] = ok ? K.Phicl[(size_t)kk * R::SNN + i * n + l] : 0.0;
         c = ok ? K.dY[kk * n + i] : 0.0;
     };
     fetch(0, row, cv);
@@ -910,6 +932,7 @@ template <int MODEL, class BLK> GD void forward_sweep(BLK& K) {
 // and leaves its results in LDS, so the sweeps get the whole register file for latency hiding.
 template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double omega, double muw, IpmOut& out, Prof& pf) {
     using T = MT<MODEL>;
+    using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NHX = n * (n + 1) / 2, NHU = m * (m + 1) / 2, NQ = NZ * (NZ + 1) / 2;
     int k = K.tid;
     const int N = K.N;
@@ -1069,7 +1092,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             for (int i = 0; i < m; i++) l_resd = nanmax(l_resd, fabs(rdu[i]));
 
             // (3) QQ = [Qt, Qt b; ., Hu + b^T Qt b], Qt = M^T Hx M (built even on the last trip: cheap)
-            double* qqg = K.QQ + (size_t)k * NQ;
+            double* qqg = K.QQ + (size_t)k * R::SQQ;
             if (k >= 1) {
                 double Mk[n * n], Qt[NHX], Qb[n * m];
                 {
@@ -1221,7 +1244,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 for (int i = 0; i < n; i++) {
                     double s = gy[i];
 #pragma unroll
-                    for (int l = 0; l < m; l++) s -= K.Kg[(size_t)k * m * n + l * n + i] * quk[l];
+                    for (int l = 0; l < m; l++) s -= K.KD[(size_t)k * R::SKD + R::oK + l * n + i] * quk[l];
                     K.pv[k * n + i] = s + (k >= 1 ? K.rv[(k - 1) * n + i] : 0.0);   // qq_k = qt_k + r_{k-1}
                 }
                 pf.tick(PF_F8);
@@ -1263,7 +1286,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 for (int i = 0; i < m; i++) {
                     double s = 0;
 #pragma unroll
-                    for (int l = 0; l < m; l++) s += K.Sinvg[(size_t)k * m * m + i * m + l] * lu[l];
+                    for (int l = 0; l < m; l++) s += K.KD[(size_t)k * R::SKD + R::oS + i * m + l] * lu[l];
                     d0[i] = s;
                 }
                 // theta_j = sum_k Pi_k^T c_k - D_k^T lu_k  (+ C M rd_{N-1} - rg at the last knot)
@@ -1271,7 +1294,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 for (int j = 0; j < n; j++) {
                     double s = K.nun[k * n + j];   // Pi_k^T c_k from the factor sweep (nun is free until the corrector's costates)
 #pragma unroll
-                    for (int i = 0; i < m; i++) s -= K.Dg[(size_t)k * m * n + i * n + j] * lu[i];
+                    for (int i = 0; i < m; i++) s -= K.KD[(size_t)k * R::SKD + R::oD + i * n + j] * lu[i];
                     if (k == N - 1 && K.is_goal(j)) {
                         const double* pg = K.PGk(k);
 #pragma unroll
@@ -1299,7 +1322,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 for (int i = 0; i < m; i++) {
                     double s = d0[i];
 #pragma unroll
-                    for (int j = 0; j < n; j++) s += K.Dg[(size_t)k * m * n + i * n + j] * mugn[j];
+                    for (int j = 0; j < n; j++) s += K.KD[(size_t)k * R::SKD + R::oD + i * n + j] * mugn[j];
                     dk[i] = s;
                     K.dv[k * m + i] = s;
                 }
@@ -1339,7 +1362,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 for (int i = 0; i < m; i++) {
                     double s = -K.dv[k * m + i];
 #pragma unroll
-                    for (int l = 0; l < n; l++) s -= K.Kg[(size_t)k * m * n + i * n + l] * dyp[l];
+                    for (int l = 0; l < n; l++) s -= K.KD[(size_t)k * R::SKD + R::oK + i * n + l] * dyp[l];
                     dus[i] = s;
                     K.dUs[k * m + i] = s;
                 }
@@ -1370,8 +1393,8 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                         double s = K.pv[k * n + i] - K.rv[k * n + i];
 #pragma unroll
                         for (int l = 0; l < n; l++)
-                            s += K.Paft[(size_t)k * n * n + i * n + l] * K.dY[k * n + l] +
-                                 K.Piaft[(size_t)k * n * n + i * n + l] * mugn[l];
+                            s += K.Paft[(size_t)k * R::SNN + i * n + l] * K.dY[k * n + l] +
+                                 K.Piaft[(size_t)k * R::SNN + i * n + l] * mugn[l];
                         K.nun[(k + 1) * n + i] = s;
                     }
                 }
