@@ -98,14 +98,21 @@ template <int MODEL> struct LdsC {
     // their own knot touches (rd qrd dXs | dUs qu dv) live in the per-problem global workspace, the linearisation
     // point (Xp, Up) is read from the problem's trajectory in HBM/L2
     static constexpr int NVN = 7, NVM = 1;
+    // One-wave problems of the small models also keep the closed-loop matrices Phicl_k (written once by the factor
+    // sweep, read by the four vector sweeps of an iteration) in LDS, behind the vectors: [N][n*n].  4 problems per
+    // CU are register-limited anyway, so up to 40 KB of LDS per problem are free.
+    static constexpr bool PHICL_LDS = n <= 8;
 };
 struct LdsLayout {
     int total;
+    int phicl;  // offset of the LDS copy of Phicl (doubles), -1 if it lives in the global workspace
 };
 template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     using C = LdsC<MODEL>;
     LdsLayout L;
     L.total = C::vecs + N * (C::NVN * C::n + C::NVM * C::m);
+    L.phicl = -1;
+    if (C::PHICL_LDS && N <= 64) { L.phicl = L.total; L.total += N * C::n * C::n; }
     return L;
 }
 

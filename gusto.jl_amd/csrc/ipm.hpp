@@ -450,6 +450,7 @@ template <int MODEL> struct SweepView {
     using R = Rec<MODEL>;
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr bool ONE = true;
+    static constexpr int SPH = C::PHICL_LDS ? n * n : R::SNN;   // stride of Phicl records (LDS copy is unpadded)
     double *lds, *sP, *sPi, *sPG, *sT, *sHh, *sZ, *sK, *sD, *sW, *sV, *sGd;
     int* lut;
     double *cv, *rv, *nun, *pv, *dY;
@@ -470,7 +471,8 @@ template <int MODEL> struct SweepView {
         v.sGd = K.lds + C::sGd; v.lut = K.lut;
         v.cv = K.cv; v.rv = K.rv; v.nun = K.nun; v.pv = K.pv; v.dY = K.dY;
         v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.KD = K.KD;
-        v.Phicl = K.Phicl; v.mpp = &K.P.mp; v.tid = K.tid; v.N = K.N; v.dt = K.dt; v.goalmask = K.goalmask;
+        // (one-wave problems of the small models: Phicl lives in LDS, stride n*n; otherwise padded global records)
+        v.Phicl = C::PHICL_LDS ? K.lds + K.P.ll.phicl : K.Phicl; v.mpp = &K.P.mp; v.tid = K.tid; v.N = K.N; v.dt = K.dt; v.goalmask = K.goalmask;
         return v;
     }
 };
@@ -501,6 +503,7 @@ template <int MODEL, class BLK> GD double* pg_buf(const BLK& K, int k) {
 template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, Prof& pf) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
+    using C = LdsC<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n, NZN = NZ * n;
     constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64, RZ = (NZN + 63) / 64, RKD = R::SKD / 64;
     const int tid = K.tid, N = K.N;
@@ -780,7 +783,8 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 if (on) { K.sP[e2] = pn; K.sPi[e2] = pin; K.sGd[e2] = gd; }
                 // padded stage records (Rec<MODEL>): every lane stores, idle lanes land in the padding; record -1 of
                 // Paft/Piaft exists for k == 0
-                K.Phicl[(size_t)k * R::SNN + e2] = ph;
+                if constexpr (C::PHICL_LDS) { if (on) K.Phicl[k * K.SPH + e2] = ph; }
+                else K.Phicl[(size_t)k * R::SNN + e2] = ph;
                 K.Paft[(size_t)(k - 1) * R::SNN + e2] = pn;
                 K.Piaft[(size_t)(k - 1) * R::SNN + e2] = pin;
                 // lanes of rows 0..m-1 hold K[i][j], rows m..2m-1 hold D[i-m][j]  (n >= 2m for every model): entry
@@ -847,7 +851,7 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
         const int kk = k0 - g;
         const bool ok = kk >= 1;
 #pragma unroll
-        for (int l = 0; l < n; l++) c[l] = ok ? K.Phicl[(size_t)kk * R::SNN + l * n + i] : 0.0;
+        for (int l = 0; l < n; l++) c[l] = ok ? K.Phicl[(size_t)kk * BLK::SPH + l * n + i] : 0.0;
         q = ok ? K.pv[kk * n + i] : 0.0;
     };
     fetch(N - 1, col, qv);
@@ -888,7 +892,7 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
         const int kk = k0 + g;
         const bool ok = kk < N;
 #pragma unroll
-        for (int l = 0; l < n; l++) r[l] = ok ? K.Phicl[(size_t)kk * R::SNN + i * n + l] : 0.0;
+        for (int l = 0; l < n; l++) r[l] = ok ? K.Phicl[(size_t)kk * BLK::SPH + i * n + l] : 0.0;
         c = ok ? K.dY[kk * n + i] : 0.0;
     };
     fetch(0, row, cv);
