@@ -1406,7 +1406,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 load_iter(xs, us);
                 OpStep op{rs, dxs, dus, pass, mu_t, tau};
                 visit_rows<MODEL>(ctx, xs, us, op);
-                l_amax = op.amax; l_c0 = op.c0; l_c1 = op.c1; l_c2 = op.c2;
+                l_amax = op.amax.value(); l_c0 = op.c0; l_c1 = op.c1; l_c2 = op.c2;
             }
             K.sync();
             if (k == 0 && (pass == 1 || ncomp == 0)) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0

@@ -208,7 +208,7 @@ template <int n, int m> struct OpResidHess {
         if (row_is_hard(kind)) {
             rp = ev.g + t;
             comp += t * lam;
-            sig = lam / t;
+            sig = lam * rcp_nr(t);
         } else {
             double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
             if (alpha_prev != 0.0) {
@@ -218,7 +218,7 @@ template <int n, int m> struct OpResidHess {
             }
             rp = ev.g - s + t;
             comp += t * lam + s * lamb;
-            sig = lam / (t + lam * s / lamb);
+            sig = lam * lamb * rcp_nr(t * lamb + lam * s);   // = lam / (t + lam s / lamb)
         }
         maxrp = nanmax(maxrp, fabs(rp));
         double* H = ISU ? Hu : Hx;
@@ -246,14 +246,15 @@ struct OpRhs {
         double coef;
         if (row_is_hard(kind)) {
             const double rp = ev.g + t;
-            coef = (mu_t - ka + lam * rp) / t;
+            coef = (mu_t - ka + lam * rp) * rcp_nr(t);
         } else {
             const double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
             const double kb = pass ? rs.at(RS_KB, slot) : 0.0;
             const double rp = ev.g - s + t;
-            const double D = t + lam * s / lamb;
-            const double rho0 = mu_t - t * lam - ka + lam * rp - (lam / lamb) * (mu_t - s * lamb - kb);
-            coef = lam + rho0 / D;
+            const double il = rcp_nr(lamb), lol = lam * il;
+            const double D = t + lol * s;
+            const double rho0 = mu_t - t * lam - ka + lam * rp - lol * (mu_t - s * lamb - kb);
+            coef = lam + rho0 * rcp_nr(D);
         }
         double* g = ISU ? gu : gx;
 #pragma unroll
@@ -261,10 +262,17 @@ struct OpRhs {
     }
 };
 
-GD double max_step(double a, double v, double dv, double tau) {
-    if (dv < 0) { const double c = -tau * v / dv; if (c < a) a = c; }
-    return a;
-}
+// fraction-to-boundary ratio test without a division per candidate: the running minimum is kept as a fraction
+// an/ad (ad > 0); tau v / (-dv) < an / ad  <=>  tau v ad < an (-dv)
+struct StepFrac {
+    double an = 1.0, ad = 1.0;
+    GD void test(double v, double dv, double tau) {
+        const double cn = tau * v, cd = -dv;
+        const bool take = (dv < 0) && (cn * ad < an * cd);
+        an = take ? cn : an; ad = take ? cd : ad;
+    }
+    GD double value() const { return an * rcp_nr(ad); }
+};
 
 // row steps (dt, dlam, ds) from the primal step and the fraction-to-boundary step length.  In the predictor pass
 // the complementarity after a step alpha is accumulated as c0 + c1 alpha + c2 alpha^2 (so no second row pass is
@@ -274,7 +282,8 @@ struct OpStep {
     const double *dxs, *dus;
     int pass;
     double mu_t, tau;
-    double amax = 1.0, c0 = 0, c1 = 0, c2 = 0;
+    StepFrac amax;
+    double c0 = 0, c1 = 0, c2 = 0;
     template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
         const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
         const double ka = pass ? rs.at(RS_KA, slot) : 0.0;
@@ -286,23 +295,24 @@ struct OpStep {
         if (row_is_hard(kind)) {
             const double rp = ev.g + t;
             dt = -rp - w;
-            dl = (mu_t - t * lam - ka - lam * dt) / t;
+            dl = (mu_t - t * lam - ka - lam * dt) * rcp_nr(t);
             ds = 0.0;
         } else {
             const double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
             const double kb = pass ? rs.at(RS_KB, slot) : 0.0;
             const double rp = ev.g - s + t;
-            const double D = t + lam * s / lamb;
-            const double rho0 = mu_t - t * lam - ka + lam * rp - (lam / lamb) * (mu_t - s * lamb - kb);
-            dl = (rho0 + lam * w) / D;
-            ds = (mu_t - s * lamb - kb + s * dl) / lamb;
+            const double il = rcp_nr(lamb), lol = lam * il;
+            const double D = t + lol * s;
+            const double rho0 = mu_t - t * lam - ka + lam * rp - lol * (mu_t - s * lamb - kb);
+            dl = (rho0 + lam * w) * rcp_nr(D);
+            ds = (mu_t - s * lamb - kb + s * dl) * il;
             dt = -rp - w + ds;
-            amax = max_step(amax, s, ds, tau);
-            amax = max_step(amax, lamb, -dl, tau);
+            amax.test(s, ds, tau);
+            amax.test(lamb, -dl, tau);
             if (pass == 0) { c0 += s * lamb; c1 += ds * lamb - s * dl; c2 -= ds * dl; rs.at(RS_KB, slot) = -ds * dl; }
         }
-        amax = max_step(amax, t, dt, tau);
-        amax = max_step(amax, lam, dl, tau);
+        amax.test(t, dt, tau);
+        amax.test(lam, dl, tau);
         if (pass == 0) { c0 += t * lam; c1 += dt * lam + t * dl; c2 += dt * dl; rs.at(RS_KA, slot) = dt * dl; }
         rs.at(RS_DT, slot) = dt; rs.at(RS_DL, slot) = dl; rs.at(RS_DS, slot) = ds;
     }
