@@ -1049,8 +1049,18 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             }
 #pragma unroll
             for (int i = 0; i < n; i++) K.rd[k * n + i] = rdk[i];
-            OpResidHess<n, m> op{rs, Hx, Hu, rdx, rdu, alpha_prev};
+            double gx0[n], gu0[m];
+#pragma unroll
+            for (int i = 0; i < n; i++) gx0[i] = 0;
+#pragma unroll
+            for (int i = 0; i < m; i++) gu0[i] = 0;
+            OpResidHess<n, m> op{rs, Hx, Hu, rdx, rdu, gx0, gu0, alpha_prev};
             visit_rows<MODEL>(ctx, xs, us, op);
+            // row part of the predictor right-hand side, parked in the (currently free) step arrays
+#pragma unroll
+            for (int i = 0; i < n; i++) K.dXs[k * n + i] = gx0[i];
+#pragma unroll
+            for (int i = 0; i < m; i++) K.dUs[k * m + i] = gu0[i];
             l_comp = op.comp;
             l_resp = nanmax(l_resp, op.maxrp);
 #pragma unroll
@@ -1218,8 +1228,15 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
 #pragma unroll
                 for (int i = 0; i < m; i++) gu[i] = 2 * wk * us[i];
                 pf.tick(PF_F1);
-                OpRhs op{rs, gx, gu, pass, mu_t};
-                visit_rows<MODEL>(ctx, xs, us, op);
+                if (pass == 0) {   // the predictor's row sums were accumulated by the residual pass
+#pragma unroll
+                    for (int i = 0; i < n; i++) gx[i] = K.dXs[k * n + i];
+#pragma unroll
+                    for (int i = 0; i < m; i++) gu[i] += K.dUs[k * m + i];
+                } else {
+                    OpRhs op{rs, gx, gu, pass, mu_t};
+                    visit_rows<MODEL>(ctx, xs, us, op);
+                }
                 pf.tick(PF_F2);
                 if (k >= 1) {
                     double Mk[n * n], Gamk[n * m];

@@ -190,10 +190,12 @@ struct OpInit {
 };
 
 // residuals + condensed Hessian:  H += sigma * grad grad^T + lam * hess,  dual residual += lam * grad.
-// The row update of the previous interior point step (t += alpha dt, ...) is folded into this pass.
+// The row update of the previous interior point step (t += alpha dt, ...) is folded into this pass, and so is the
+// row part of the PREDICTOR right-hand side (OpRhs with mu_t = ka = kb = 0 reduces to coef = lam + sigma * g), which
+// saves the predictor its own pass over the rows.
 template <int n, int m> struct OpResidHess {
     RowState rs;
-    double *Hx, *Hu, *rdx, *rdu;
+    double *Hx, *Hu, *rdx, *rdu, *gx0, *gu0;
     double alpha_prev;  // 0 on the first trip
     double comp = 0, maxrp = 0;
     template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
@@ -223,10 +225,13 @@ template <int n, int m> struct OpResidHess {
         maxrp = nanmax(maxrp, fabs(rp));
         double* H = ISU ? Hu : Hx;
         double* r = ISU ? rdu : rdx;
+        double* g0 = ISU ? gu0 : gx0;
+        const double coef0 = lam + sig * ev.g;
         constexpr int dim = ISU ? m : n;
 #pragma unroll
         for (int a = 0; a < CNT; a++) {
             r[I0 + a] += lam * ev.gr[a];
+            g0[I0 + a] += coef0 * ev.gr[a];
 #pragma unroll
             for (int b = a; b < CNT; b++) H[sidx(I0 + a, I0 + b, dim)] += sig * ev.gr[a] * ev.gr[b];
             H[sidx(I0 + a, I0 + a, dim)] += lam * ev.hd[a];
