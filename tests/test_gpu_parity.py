@@ -268,6 +268,38 @@ def test_single_problem_plumbing():
     assert d >= 0.05 - 1e-2
 
 
+def test_async_solves_on_two_handles_match_the_blocking_solve():
+    """gusto_solve_async / gusto_wait: two handles with batches in flight at the same time return bit-identical
+    trajectories, statuses and histories to the blocking gusto_solve of the same batches."""
+    g, _ = _mods()
+    P = g.problems
+    env = P.freeflyer_env()
+    B = 1536
+    batches = [P.freeflyer_batch(B, first=f) for f in (0, 5000)]
+    ref = []
+    for x0, glo, ghi, tf in batches:
+        s = g.BatchSolver(g.FREEFLYER_SE2, 50, B, hist_cap=40, boxes=env)
+        s.set_problems(x0, glo, ghi, tf)
+        s.solve(30)
+        ref.append((s.traj(), s.status(), s.history()))
+    hs = [g.BatchSolver(g.FREEFLYER_SE2, 50, B, hist_cap=40, boxes=env) for _ in batches]
+    for s, (x0, glo, ghi, tf) in zip(hs, batches):
+        s.set_problems(x0, glo, ghi, tf)
+        s.solve_async(30)          # both launches are now in flight
+    for s, ((X, U), st, hist) in zip(hs, ref):
+        s.wait()
+        assert s.last_solve_ms() > 0
+        X2, U2 = s.traj()
+        assert np.array_equal(X, X2) and np.array_equal(U, U2)
+        st2, h2 = s.status(), s.history()
+        for k in st:
+            assert np.array_equal(st[k], st2[k]), k
+        assert np.array_equal(hist["n_hist"], h2["n_hist"])
+        valid = np.arange(hist["Delta"].shape[1])[None, :] < hist["n_hist"][:, None]   # entries past n_hist are unset
+        for k in ("Delta", "omega", "accept_solution", "scp_status", "convergence_measure"):
+            assert np.array_equal(np.asarray(hist[k])[valid], np.asarray(h2[k])[valid]), k
+
+
 GOLDEN = ["freeflyer_se2_n50", "freeflyer_se2_n200_notebook", "dubins_car_n30", "astrobee_se3_n50",
           "astrobee_se3_manifold_n50"]
 
