@@ -564,6 +564,41 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
         // ---- phase AB -------------------------------------------------------------------------------
         // Small models: every LDS operand of the three products (H, Z, r) is requested before the first FMA, so the
         // stage pays ONE LDS latency here instead of three back-to-back read -> wait -> compute chains.
+#ifndef GUSTO_FACTOR_DENSE
+        // Models whose [Phi Gam] has <= 2 nonzeros per column (MT::PG2): the two-step contraction below, over the two
+        // structural rows of the lane's column only -- 2 FMAs and 4 operands per product instead of n and 2n.
+        if constexpr (T::PG2 && RT == 1 && RZ == 1 && RQ == 1) {
+            const int tc = tC[0], tl = tL[0], zc = zJ[0], zg = zG[0], hc = hI[0], hj = hJ[0];
+            const int t0 = T::pg_r0(tc), t1 = T::pg_r1(tc), z0 = T::pg_r0(zc), z1 = T::pg_r1(zc);
+            const int h0 = T::pg_r0(hc), h1 = T::pg_r1(hc);
+            const bool isr = tid < n;
+            const int ri = isr ? tid : ((tid < 2 * n) ? tid - n : 0);
+            double ra[n], rb[n];
+            const double tp0 = K.sP[tl * n + t0], tp1 = K.sP[tl * n + t1], tv0 = PGs[t0 * NZ + tc], tv1 = PGs[t1 * NZ + tc];
+            const double zb0 = K.sPi[z0 * n + zg], zb1 = K.sPi[z1 * n + zg], zv0 = PGs[z0 * NZ + zc], zv1 = PGs[z1 * NZ + zc];
+#pragma unroll
+            for (int l = 0; l < n; l++) { ra[l] = *(isr ? K.sP + ri * n + l : K.sPi + l * n + ri); rb[l] = K.cv[k * n + l]; }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tid < NPG) K.sT[tid] = tp0 * tv0 + tp1 * tv1;
+            {
+                double z = zv0 * zb0 + zv1 * zb1;
+                // E = [M^T C^T; b^T M^T C^T], M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
+                if (k == N - 1 && K.is_goal(zg)) z += 0.5 * (PGs[zg * NZ + zc] + ((zc == zg) ? 1.0 : 0.0));
+                if (tid < NZN) K.sZ[tid] = z;
+            }
+            {   // r_k = P_k c_k and Pi_k^T c_k for the stage-parallel blocks
+                double rr = 0;
+#pragma unroll
+                for (int l = 0; l < n; l++) rr += ra[l] * rb[l];
+                if (tid < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = rr;
+            }
+            K.sync();
+            const double hv0 = PGs[h0 * NZ + hc], hv1 = PGs[h1 * NZ + hc], tj0 = K.sT[h0 * NZ + hj], tj1 = K.sT[h1 * NZ + hj];
+            __builtin_amdgcn_sched_barrier(0);
+            const double h = qq[0] + hv0 * tj0 + hv1 * tj1;
+            if (tid < NQ) { K.sHh[hc * NZ + hj] = h; K.sHh[hj * NZ + hc] = h; }
+        } else
+#endif
 #ifndef GUSTO_FACTOR_ONESTEP
         // Two steps, T = P [Phi Gam] then H = QQ + [Phi Gam]^T T: each lane contracts ONE index per step (2 x n FMAs
         // and 4 n operands instead of n^2 + n FMAs and n^2 + 2 n operands), at the price of one more trip through LDS.
