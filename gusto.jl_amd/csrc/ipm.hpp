@@ -561,6 +561,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
         }
         pf.tick(PF_FPRE);
+        double hreg[RQ];   // this lane's entries of H, kept for the S = H_uu broadcast of phase CD
         // ---- phase AB -------------------------------------------------------------------------------
         // Small models: every LDS operand of the three products (H, Z, r) is requested before the first FMA, so the
         // stage pays ONE LDS latency here instead of three back-to-back read -> wait -> compute chains.
@@ -596,6 +597,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             const double hv0 = PGs[h0 * NZ + hc], hv1 = PGs[h1 * NZ + hc], tj0 = K.sT[h0 * NZ + hj], tj1 = K.sT[h1 * NZ + hj];
             __builtin_amdgcn_sched_barrier(0);
             const double h = qq[0] + hv0 * tj0 + hv1 * tj1;
+            hreg[0] = h;
             if (tid < NQ) { K.sHh[hc * NZ + hj] = h; K.sHh[hj * NZ + hc] = h; }
         } else
 #endif
@@ -651,6 +653,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 double h = qq[r];
 #pragma unroll
                 for (int l = 0; l < n; l++) h += pgi[r][l] * tj[r][l];
+                hreg[r] = h;
                 if (tid + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = h; K.sHh[hJ[r] * NZ + hI[r]] = h; }
             }
         } else
@@ -682,6 +685,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                     for (int q = 0; q < n; q++) t += pm[l * n + q] * pgj[r][q];
                     s += pgi[r][l] * t;
                 }
+                hreg[r] = s;
                 if (tid + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = s; K.sHh[hJ[r] * NZ + hI[r]] = s; }
             }
 #pragma unroll
@@ -719,7 +723,8 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                     }
                     K.sHh[hI[r] * NZ + hJ[r]] = s;
                     K.sHh[hJ[r] * NZ + hI[r]] = s;
-                }
+                    hreg[r] = s;
+                } else hreg[r] = 0.0;
             }
         
 #pragma unroll
@@ -760,10 +765,15 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
         // instead of draining them all with vmcnt(0) at the end of every stage.
         {
             double S[m * m], Li[m * m];
+            // S = H_uu straight from the registers of the lanes that formed it (v_readlane): the Cholesky starts without
+            // waiting for the trip of H through LDS, which only the solve operands below still take
 #pragma unroll
             for (int i = 0; i < m; i++)
 #pragma unroll
-                for (int j = 0; j < m; j++) S[i * m + j] = K.sHh[(n + i) * NZ + n + j];
+                for (int j = 0; j < m; j++) {
+                    const int e = sidx(n + (i < j ? i : j), n + (i < j ? j : i), NZ);
+                    S[i * m + j] = readlane_f64(hreg[e / 64], e % 64);
+                }
             // the operands of the solves do not depend on the Cholesky factor: request them first, they land while
             // the (latency-bound, wave-uniform) factorisation runs
             double hi[RN][m], hj[RN][m], zi[RN][m], zj[RN][m], gi[RN][m], pn_[RN], ph_[RN], pin_[RN], gd_[RN];
