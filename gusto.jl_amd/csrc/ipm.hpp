@@ -566,21 +566,27 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
         // Small models: every LDS operand of the three products (H, Z, r) is requested before the first FMA, so the
         // stage pays ONE LDS latency here instead of three back-to-back read -> wait -> compute chains.
 #ifndef GUSTO_FACTOR_DENSE
-        // Models whose [Phi Gam] has <= 2 nonzeros per column (MT::PG2): the two-step contraction below, over the two
-        // structural rows of the lane's column only -- 2 FMAs and 4 operands per product instead of n and 2n.
-        if constexpr (T::PG2 && RT == 1 && RZ == 1 && RQ == 1) {
-            const int tc = tC[0], tl = tL[0], zc = zJ[0], zg = zG[0], hc = hI[0], hj = hJ[0];
-            const int t0 = T::pg_r0(tc), t1 = T::pg_r1(tc), z0 = T::pg_r0(zc), z1 = T::pg_r1(zc);
-            const int h0 = T::pg_r0(hc), h1 = T::pg_r1(hc);
+        // Models whose [Phi Gam] has <= 2 nonzeros per column (MT::PG2): contractions over the two structural rows of
+        // a column only.
+        if constexpr (T::PG2 && RZ == 1 && RQ == 1) {
+            // H[i][j] = QQ + sum_{a,b} PG[ra(i)][i] P[ra(i)][rb(j)] PG[rb(j)][j]: four entries of P per lane, one phase
+            const int zc = zJ[0], zg = zG[0], hc = hI[0], hj = hJ[0];
+            const int z0 = T::pg_r0(zc), z1 = T::pg_r1(zc);
+            const int i0 = T::pg_r0(hc), i1 = T::pg_r1(hc), j0 = T::pg_r0(hj), j1 = T::pg_r1(hj);
             const bool isr = tid < n;
             const int ri = isr ? tid : ((tid < 2 * n) ? tid - n : 0);
             double ra[n], rb[n];
-            const double tp0 = K.sP[tl * n + t0], tp1 = K.sP[tl * n + t1], tv0 = PGs[t0 * NZ + tc], tv1 = PGs[t1 * NZ + tc];
+            const double a0 = PGs[i0 * NZ + hc], a1 = PGs[i1 * NZ + hc], b0 = PGs[j0 * NZ + hj], b1 = PGs[j1 * NZ + hj];
+            const double p00 = K.sP[i0 * n + j0], p01 = K.sP[i0 * n + j1], p10 = K.sP[i1 * n + j0], p11 = K.sP[i1 * n + j1];
             const double zb0 = K.sPi[z0 * n + zg], zb1 = K.sPi[z1 * n + zg], zv0 = PGs[z0 * NZ + zc], zv1 = PGs[z1 * NZ + zc];
 #pragma unroll
             for (int l = 0; l < n; l++) { ra[l] = *(isr ? K.sP + ri * n + l : K.sPi + l * n + ri); rb[l] = K.cv[k * n + l]; }
             __builtin_amdgcn_sched_barrier(0);
-            if (tid < NPG) K.sT[tid] = tp0 * tv0 + tp1 * tv1;
+            {
+                const double h = qq[0] + a0 * (b0 * p00 + b1 * p01) + a1 * (b0 * p10 + b1 * p11);
+                hreg[0] = h;
+                if (tid < NQ) { K.sHh[hc * NZ + hj] = h; K.sHh[hj * NZ + hc] = h; }
+            }
             {
                 double z = zv0 * zb0 + zv1 * zb1;
                 // E = [M^T C^T; b^T M^T C^T], M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
@@ -593,12 +599,6 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 for (int l = 0; l < n; l++) rr += ra[l] * rb[l];
                 if (tid < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = rr;
             }
-            K.sync();
-            const double hv0 = PGs[h0 * NZ + hc], hv1 = PGs[h1 * NZ + hc], tj0 = K.sT[h0 * NZ + hj], tj1 = K.sT[h1 * NZ + hj];
-            __builtin_amdgcn_sched_barrier(0);
-            const double h = qq[0] + hv0 * tj0 + hv1 * tj1;
-            hreg[0] = h;
-            if (tid < NQ) { K.sHh[hc * NZ + hj] = h; K.sHh[hj * NZ + hc] = h; }
         } else
 #endif
 #ifndef GUSTO_FACTOR_ONESTEP
