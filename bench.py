@@ -185,7 +185,9 @@ def main():
                        "batches_in_flight": D},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gusto::scp_kernel<0>", "avg_launch_ms": avg_ms,
+                         # one gusto_solve = two launches of this kernel (2 probe trips of every problem, then the rest
+                         # longest-first, gusto_set_schedule); avg_launch_ms is their sum per solve, from HIP events
+                         "kernel": "gusto::scp_kernel<0>", "launches_per_solve": 2, "avg_launch_ms": avg_ms,
                          "kkt_solves_per_launch": ipm_iters, "scp_iters_per_launch": scp_iters,
                          # with D > 1 launches overlap, so a launch's duration spans the batches it shares the GPU
                          # with; the job-level rate is the algorithmic bytes of all launches over the timed region

@@ -19,7 +19,8 @@ STOP_REASON = {0: "MaxIter", 1: "Converged", 2: "SubproblemFailed", 3: "OmegaMax
 
 # every symbol include/gusto_hip.h declares
 SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims", "gusto_create", "gusto_destroy",
-           "gusto_last_error", "gusto_set_params", "gusto_set_ipm_opts", "gusto_set_env", "gusto_set_stream",
+           "gusto_last_error", "gusto_set_params", "gusto_set_ipm_opts", "gusto_set_env", "gusto_set_schedule",
+           "gusto_set_stream",
            "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_solve_async", "gusto_wait",
            "gusto_last_solve_ms", "gusto_get_traj",
            "gusto_get_traj_dev", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_subproblem"]
@@ -109,6 +110,7 @@ def lib():
         L.gusto_set_stream.argtypes = [vp, vp]
         L.gusto_set_problems.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
         L.gusto_set_problems_dev.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
+        L.gusto_set_schedule.argtypes = [vp, ci, ci]
         L.gusto_solve.argtypes = [vp, ci, ci]
         L.gusto_solve_async.argtypes = [vp, ci, ci]
         L.gusto_wait.argtypes = [vp]
@@ -199,6 +201,9 @@ class BatchSolver:
                                             tf.ctypes.data, None if X0 is None else self._keep[4].ctypes.data,
                                             None if U0 is None else self._keep[5].ctypes.data), "set_problems")
         self.B = B
+
+    def set_schedule(self, probe_iters=2, min_batch=2048):
+        self._chk(self.L.gusto_set_schedule(self.h, int(probe_iters), int(min_batch)), "set_schedule")
 
     def solve(self, max_iter=30, force=False):
         self._chk(self.L.gusto_solve(self.h, int(max_iter), int(bool(force))), "solve")

@@ -135,6 +135,8 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
 // kernel arguments
 struct KParams {
     int N, B, n_obs, n_box, n_sph, hist_cap, max_iter, force, mode;  // mode 0: SCP solve, 1: one subproblem
+    int cont;           // 1: second launch of the same gusto_solve call (longest-first schedule, launch.hpp)
+    const int* order;   // workgroup -> problem index (nullptr: identity)
     gusto_scp_params sp;
     gusto_model_params mp;
     gusto_ipm_opts io;

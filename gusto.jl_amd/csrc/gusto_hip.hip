@@ -129,6 +129,7 @@ int gusto_destroy(gusto_handle h) {
                     h->d_Delta, h->d_omega, h->d_rho, h->d_acc, h->d_scp, h->d_sol, h->d_tr, h->d_cvx, h->d_ipm, h->d_ws,
                     h->d_prof, h->d_subD, h->d_subW, h->d_subT, h->d_subX, h->d_subU, h->d_subObj, h->d_subSt, h->d_subIt, h->d_box, h->d_sph};
     for (void* p : ptrs) if (p) hipFree(p);
+    if (h->d_order) hipFree(h->d_order);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -147,6 +148,12 @@ int gusto_set_ipm_opts(gusto_handle h, const gusto_ipm_opts* o) {
     h->io = *o;
     return GUSTO_OK;
 }
+int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch) {
+    if (!h || probe_iters < 0 || min_batch < 1) return GUSTO_ERR_ARG;
+    h->probe_iters = probe_iters; h->probe_min_batch = min_batch;
+    return GUSTO_OK;
+}
+
 int gusto_set_stream(gusto_handle h, void* s) {
     if (!h) return GUSTO_ERR_ARG;
     if (h->own_stream && h->stream) { hipStreamDestroy(h->stream); h->own_stream = false; }

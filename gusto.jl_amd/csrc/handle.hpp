@@ -28,6 +28,8 @@ struct gusto_handle_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
     bool pending = false;  // a gusto_solve_async launch has not been waited for yet
+    int probe_iters = 2, probe_min_batch = 2048;  // longest-first schedule (gusto_set_schedule)
+    int* d_order = nullptr;
     bool have_problems = false;
     std::string err;
 };

@@ -64,7 +64,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     GD int nt() const { return ONEWAVE ? 64 : NTr; }
 
     GD Blk(const KParams& P_, double* lds_) : P(P_), lds(lds_) {
-        b = blockIdx.x; tid = threadIdx.x; NTr = blockDim.x; N = P.N;
+        b = P.order ? P.order[blockIdx.x] : (int)blockIdx.x; tid = threadIdx.x; NTr = blockDim.x; N = P.N;
         sP = lds + C::sP; sPi = lds + C::sPi; sPG = lds + C::sPG; sT = lds + C::sT; sHh = lds + C::sHh; sZ = lds + C::sZ;
         sK = lds + C::sK; sD = lds + C::sD; sW = lds + C::sW; sV = lds + C::sV; sGd = lds + C::sGd; misc = lds + C::misc;
         lut = reinterpret_cast<int*>(lds + C::lut);

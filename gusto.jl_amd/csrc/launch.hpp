@@ -55,6 +55,21 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     auto kern = (NT == 64) ? &scp_kernel<MODEL, true> : &scp_kernel<MODEL, false>;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    // Longest-first schedule for big batches.  Workgroups are dispatched in index order onto ~4 slots per CU, so a
+    // long problem with a high index starts late and the batch ends with a few problems on an empty GPU (44 % of
+    // the slot-time of a freeflyer batch of 4096).  Every problem first runs `probe_iters` trips; the rest of the
+    // solve is then launched in order of decreasing penalty weight (scp.hpp:order_kernel).  Results are
+    // bit-identical to the single launch: the second launch continues each problem's state machine.
+    const bool split = mode == 0 && h->probe_iters > 0 && max_iter > h->probe_iters && h->B >= h->probe_min_batch;
+    if (split) {
+        if (!h->d_order) HIPCHK(h, dalloc(&h->d_order, (size_t)h->batch_cap));
+        P.max_iter = h->probe_iters;
+        hipLaunchKernelGGL(kern, dim3(h->B), dim3(NT), lds, h->stream, P);
+        HIPCHK(h, hipGetLastError());
+        hipLaunchKernelGGL(order_kernel<MODEL>, dim3(1), dim3(256), 0, h->stream, P, h->d_order);
+        HIPCHK(h, hipGetLastError());
+        P.max_iter = max_iter - h->probe_iters; P.cont = 1; P.order = h->d_order;
+    }
     hipLaunchKernelGGL(kern, dim3(h->B), dim3(NT), lds, h->stream, P);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));

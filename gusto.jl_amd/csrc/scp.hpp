@@ -106,15 +106,20 @@ scp_kernel(const KParams P) {
     int iterations = sti[ST_ITER], converged = sti[ST_CONV], successful = sti[ST_SUCC], stop = GUSTO_STOP_MAXITER;
     int total_ipm = sti[ST_IPM], n_hist = sti[ST_NHIST], nJ = sti[ST_NJ], n_rho = sti[ST_NRHO];
     const int iter_cap = iterations + P.max_iter;  // scp_gusto.jl:67
+    // second launch of one gusto_solve call: problems that already stopped are done, the others carry on exactly
+    // where the first launch left them (no new leading history entries)
+    if (P.cont && sti[ST_STOP] != GUSTO_STOP_MAXITER) return;
 
     // K.Xp / K.Up are the stored trajectory (SCPS.traj) itself
     // scp_gusto.jl:73-76
     double Jt = cost_true(K, K.Up);
     double rho0v = trust_region_ratio<MODEL>(K, K.Xp, K.Up, K.Xp, K.Up);
     double Delta = P.Delta[hb + n_hist - 1], omega = P.omega[hb + n_hist - 1];
-    if (tid == 0 && nJ < P.hist_cap) { P.J_true[hb + nJ] = Jt; P.J_full[hb + nJ] = Jt; }
-    if (tid == 0 && n_rho < P.hist_cap) P.rho[hb + n_rho] = rho0v;
-    nJ++; n_rho++;
+    if (!P.cont) {
+        if (tid == 0 && nJ < P.hist_cap) { P.J_true[hb + nJ] = Jt; P.J_full[hb + nJ] = Jt; }
+        if (tid == 0 && n_rho < P.hist_cap) P.rho[hb + n_rho] = rho0v;
+        nJ++; n_rho++;
+    }
     double toggle = Delta / 8 + P.mp.clearance;
     double conv_prev = (n_hist >= 1) ? P.conv[hb + n_hist - 1] : 0.0;
 
@@ -232,6 +237,35 @@ template <int MODEL> __global__ void init_straightline_kernel(const KParams P) {
     }
 #pragma unroll
     for (int i = 0; i < m; i++) P.U[((size_t)b * P.N + k) * m + i] = 0.0;
+}
+
+// Longest-first order for the second launch of a gusto_solve call.  Problem lengths are not known in advance, but
+// the long ones are almost exactly those whose penalty weight omega was raised during their first trips
+// (ViolatesConstraints / TrustRegionViolated, scp_gusto.jl:137-147).  Key = number of omega raises so far, problems
+// that already stopped last; counting sort by descending key, stable in the problem index.  One workgroup.
+template <int MODEL> __global__ void __launch_bounds__(256) order_kernel(const KParams P, int* order) {
+    constexpr int NB = 16, NT = 256;
+    __shared__ int cnt[NB][NT + 1];
+    const int t = threadIdx.x, B = P.B;
+    const int chunk = (B + NT - 1) / NT, b0 = t * chunk, b1 = min(B, b0 + chunk);
+    auto key = [&](int b) {
+        const int* sti = P.st_i + (size_t)b * ST_NI;
+        if (sti[ST_STOP] != GUSTO_STOP_MAXITER) return 0;
+        const double w = P.omega[(size_t)b * P.hist_cap + sti[ST_NHIST] - 1] / P.sp.omega0;
+        int lvl = 0;
+        for (double x = 1.5; x < w && lvl < NB - 2; x *= P.sp.gamma_fail) lvl++;
+        return 1 + lvl;
+    };
+    for (int q = 0; q < NB; q++) cnt[q][t] = 0;
+    for (int b = b0; b < b1; b++) cnt[key(b)][t]++;
+    __syncthreads();
+    if (t == 0) {   // exclusive prefix over (key descending, thread ascending)
+        int acc = 0;
+        for (int q = NB - 1; q >= 0; q--)
+            for (int u = 0; u < NT; u++) { const int c = cnt[q][u]; cnt[q][u] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (int b = b0; b < b1; b++) order[cnt[key(b)][t]++] = b;
 }
 
 // SCPSolution(SCPP, traj_init) + SCPParam_GuSTO ctor (types.jl:233, scp_gusto.jl:21-23)

@@ -88,6 +88,11 @@ int gusto_set_ipm_opts(gusto_handle h, const gusto_ipm_opts* o);
 /* Workspace(robot, env) (types.jl:12-24): keep-out set = keepout_zones then obstacle_set, as AABBs
  * (min xyz, max xyz) followed by spheres (centre xyz, radius) */
 int gusto_set_env(gusto_handle h, int n_box, const double* box_min_max, int n_sph, const double* sph_c_r);
+/* Longest-first schedule of a gusto_solve call (new; affects time only, results are bit-identical): batches of at
+ * least `min_batch` problems first run `probe_iters` SCP iterations of every problem, then the rest of the solve in
+ * order of decreasing penalty weight omega -- the problems whose omega was raised early are the long ones.
+ * probe_iters = 0 disables it.  Default (2, 2048). */
+int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch);
 /* run on a caller-owned hipStream_t (NULL = the handle's own stream) */
 int gusto_set_stream(gusto_handle h, void* hip_stream);
 

@@ -300,6 +300,35 @@ def test_async_solves_on_two_handles_match_the_blocking_solve():
             assert np.array_equal(np.asarray(hist[k])[valid], np.asarray(h2[k])[valid]), k
 
 
+def test_longest_first_schedule_is_bit_identical():
+    """gusto_set_schedule: probing every problem for a few trips and then launching the rest in order of decreasing
+    penalty weight changes the time of a solve, not one bit of its results (trajectories, statuses, histories)."""
+    g, _ = _mods()
+    P = g.problems
+    env = P.freeflyer_env()
+    B = 768
+    x0, glo, ghi, tf = P.freeflyer_batch(B, first=100)
+    out = []
+    for probe in (0, 2, 5):
+        s = g.BatchSolver(g.FREEFLYER_SE2, 50, B, hist_cap=40, boxes=env)
+        s.set_schedule(probe, 1)
+        s.set_problems(x0, glo, ghi, tf)
+        s.solve(30)
+        out.append((s.traj(), s.status(), s.history()))
+    (X, U), st, hist = out[0]
+    valid = np.arange(hist["Delta"].shape[1])[None, :] < hist["n_hist"][:, None]
+    validJ = np.arange(hist["J_true"].shape[1])[None, :] < hist["nJ"][:, None]
+    for (X2, U2), st2, h2 in out[1:]:
+        assert np.array_equal(X, X2) and np.array_equal(U, U2)
+        for k in st:
+            assert np.array_equal(st[k], st2[k]), k
+        for k in ("n_hist", "nJ", "n_rho"):
+            assert np.array_equal(hist[k], h2[k]), k
+        for k in ("Delta", "omega", "accept_solution", "scp_status", "solver_status", "convergence_measure", "ipm_iters"):
+            assert np.array_equal(np.asarray(hist[k])[valid], np.asarray(h2[k])[valid]), k
+        assert np.array_equal(hist["J_true"][validJ], h2["J_true"][validJ])
+
+
 GOLDEN = ["freeflyer_se2_n50", "freeflyer_se2_n200_notebook", "dubins_car_n30", "astrobee_se3_n50",
           "astrobee_se3_manifold_n50"]
 
