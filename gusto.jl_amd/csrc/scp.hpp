@@ -244,8 +244,9 @@ template <int MODEL> __global__ void init_straightline_kernel(const KParams P) {
 // (ViolatesConstraints / TrustRegionViolated, scp_gusto.jl:137-147).  Key = number of omega raises so far, problems
 // that already stopped last; counting sort by descending key, stable in the problem index.  One workgroup.
 template <int MODEL> __global__ void __launch_bounds__(256) order_kernel(const KParams P, int* order) {
-    constexpr int NB = 16, NT = 256;
+    constexpr int NB = 16, NT = 256, KC = 16;
     __shared__ int cnt[NB][NT + 1];
+    __shared__ int base[NB];
     const int t = threadIdx.x, B = P.B;
     const int chunk = (B + NT - 1) / NT, b0 = t * chunk, b1 = min(B, b0 + chunk);
     auto key = [&](int b) {
@@ -256,16 +257,28 @@ template <int MODEL> __global__ void __launch_bounds__(256) order_kernel(const K
         for (double x = 1.5; x < w && lvl < NB - 2; x *= P.sp.gamma_fail) lvl++;
         return 1 + lvl;
     };
+    int kc[KC];   // keys of this thread's problems (batches up to NT * KC problems: no second trip to memory)
     for (int q = 0; q < NB; q++) cnt[q][t] = 0;
-    for (int b = b0; b < b1; b++) cnt[key(b)][t]++;
+#pragma unroll
+    for (int i = 0; i < KC; i++) kc[i] = (b0 + i < b1) ? key(b0 + i) : -1;
+#pragma unroll
+    for (int i = 0; i < KC; i++) if (kc[i] >= 0) cnt[kc[i]][t]++;
+    for (int b = b0 + KC; b < b1; b++) cnt[key(b)][t]++;
     __syncthreads();
-    if (t == 0) {   // exclusive prefix over (key descending, thread ascending)
+    if (t < NB) {   // exclusive prefix of row t over the threads; row totals -> offsets in descending key order
         int acc = 0;
-        for (int q = NB - 1; q >= 0; q--)
-            for (int u = 0; u < NT; u++) { const int c = cnt[q][u]; cnt[q][u] = acc; acc += c; }
+        for (int u = 0; u < NT; u++) { const int c = cnt[t][u]; cnt[t][u] = acc; acc += c; }
+        cnt[t][NT] = acc;
     }
     __syncthreads();
-    for (int b = b0; b < b1; b++) order[cnt[key(b)][t]++] = b;
+    if (t == 0) {
+        int acc = 0;
+        for (int q = NB - 1; q >= 0; q--) { base[q] = acc; acc += cnt[q][NT]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KC; i++) if (kc[i] >= 0) order[base[kc[i]] + cnt[kc[i]][t]++] = b0 + i;
+    for (int b = b0 + KC; b < b1; b++) { const int q = key(b); order[base[q] + cnt[q][t]++] = b; }
 }
 
 // SCPSolution(SCPP, traj_init) + SCPParam_GuSTO ctor (types.jl:233, scp_gusto.jl:21-23)

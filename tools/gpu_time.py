@@ -1,4 +1,4 @@
-"""Timing of one model/config: python tools/gpu_time.py <model> <B> <N>"""
+"""Timing of one model/config: python tools/gpu_time.py <model> <B> <N> [probe_iters]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,6 +15,8 @@ elif model == 2:
 else:
     x0, glo, ghi, tf = P.astrobee_manifold_batch(B); boxes, spheres = P.iss_corner_env(True)
 s = g.BatchSolver(model, N, B, hist_cap=64, boxes=boxes, spheres=spheres)
+if len(sys.argv) > 4:
+    s.set_schedule(int(sys.argv[4]), 1)   # probe trips of the longest-first schedule (0 = off)
 for rep in range(2):
     s.set_problems(x0, glo, ghi, tf); s.solve(30)
 st = s.status()
