@@ -106,10 +106,11 @@ template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
 template <int MODEL> struct LdsC {
     using T = MT<MODEL>;
     static constexpr int n = T::n, m = T::m, NZ = n + m;
+    // (sK sD sW sV are used by the multi-wave sweeps only: one-wave problems start their vectors at vecs1w)
     static constexpr int sP = 0, sPi = sP + n * n, sPG = sPi + n * n, sT = sPG + 3 * n * NZ, sHh = sT + n * NZ,
-                         sZ = sHh + NZ * NZ, sK = sZ + NZ * n, sD = sK + m * n, sW = sD + m * n, sV = sW + m * n,
-                         sGd = sV + m * n, misc = sGd + 2 * n * n, lut = misc + 64,
-                         vecs = lut + (NZ * (NZ + 1) / 2 + 1) / 2 + 1;
+                         sZ = sHh + NZ * NZ, sGd = sZ + NZ * n, misc = sGd + 2 * n * n, lut = misc + 64,
+                         vecs1w = lut + (NZ * (NZ + 1) / 2 + 1) / 2 + 1,
+                         sK = vecs1w, sD = sK + m * n, sW = sD + m * n, sV = sW + m * n, vecs = sV + m * n;
     // per-knot vectors shared between lanes: n-vectors (Xw dY pv cv rv nu nun) then the m-vector Uw; vectors only
     // their own knot touches (rd qrd dXs | dUs qu dv) live in the per-problem global workspace, the linearisation
     // point (Xp, Up) is read from the problem's trajectory in HBM/L2
@@ -126,7 +127,7 @@ struct LdsLayout {
 template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     using C = LdsC<MODEL>;
     LdsLayout L;
-    L.total = C::vecs + N * (C::NVN * C::n + C::NVM * C::m);
+    L.total = (N <= 64 ? C::vecs1w : C::vecs) + N * (C::NVN * C::n + C::NVM * C::m);
     L.phicl = -1;
     if (C::PHICL_LDS && N <= 64) { L.phicl = L.total; L.total += N * C::n * C::n; }
     return L;

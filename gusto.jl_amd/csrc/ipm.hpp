@@ -68,7 +68,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         sP = lds + C::sP; sPi = lds + C::sPi; sPG = lds + C::sPG; sT = lds + C::sT; sHh = lds + C::sHh; sZ = lds + C::sZ;
         sK = lds + C::sK; sD = lds + C::sD; sW = lds + C::sW; sV = lds + C::sV; sGd = lds + C::sGd; misc = lds + C::misc;
         lut = reinterpret_cast<int*>(lds + C::lut);
-        double* v = lds + C::vecs;
+        double* v = lds + (ONEWAVE ? C::vecs1w : C::vecs);
         Xw = v; dY = v + N * n; pv = v + 2 * N * n; cv = v + 3 * N * n; rv = v + 4 * N * n; nu = v + 5 * N * n;
         nun = v + 6 * N * n;
         Uw = v + C::NVN * N * n;
