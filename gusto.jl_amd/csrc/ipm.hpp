@@ -704,29 +704,33 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 if (tid < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = s;
             }
         } else {
+            // large models: the same two steps, one round of 64 entries at a time (n^2 operands per lane do not fit
+            // the register file: the one-step form spilled 5-6 KB per lane and cost n^2 + n FMAs per entry)
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                double tp[n], tg[n];
+#pragma unroll
+                for (int q = 0; q < n; q++) { tp[q] = K.sP[tL[r] * n + q]; tg[q] = PGs[q * NZ + tC[r]]; }
+                __builtin_amdgcn_sched_barrier(0);
+                double t = 0;
+#pragma unroll
+                for (int q = 0; q < n; q++) t += tp[q] * tg[q];
+                if (tid + 64 * r < NPG) K.sT[tid + 64 * r] = t;
+            }
+            K.sync();
 #pragma unroll
             for (int r = 0; r < RQ; r++) {
-                if (tid + 64 * r < NQ) {
-                    double pgj[n], pgi[n], pm[n * n];
+                double pgi[n], tj[n];
 #pragma unroll
-                    for (int l = 0; l < n; l++) { pgj[l] = PGs[l * NZ + hJ[r]]; pgi[l] = PGs[l * NZ + hI[r]]; }
+                for (int l = 0; l < n; l++) { pgi[l] = PGs[l * NZ + hI[r]]; tj[l] = K.sT[l * NZ + hJ[r]]; }
+                __builtin_amdgcn_sched_barrier(0);
+                double h = qq[r];
 #pragma unroll
-                    for (int e = 0; e < n * n; e++) pm[e] = K.sP[e];
-                    __builtin_amdgcn_sched_barrier(0);
-                    double s = qq[r];
-#pragma unroll
-                    for (int l = 0; l < n; l++) {
-                        double t = 0;   // (P [Phi Gam])[l][j]
-#pragma unroll
-                        for (int q = 0; q < n; q++) t += pm[l * n + q] * pgj[q];
-                        s += pgi[l] * t;
-                    }
-                    K.sHh[hI[r] * NZ + hJ[r]] = s;
-                    K.sHh[hJ[r] * NZ + hI[r]] = s;
-                    hreg[r] = s;
-                } else hreg[r] = 0.0;
+                for (int l = 0; l < n; l++) h += pgi[l] * tj[l];
+                hreg[r] = h;
+                if (tid + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = h; K.sHh[hJ[r] * NZ + hI[r]] = h; }
             }
-        
+
 #pragma unroll
             for (int r = 0; r < RZ; r++) {
                 if (tid + 64 * r < NZN) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 
 #include "handle.hpp"
@@ -54,6 +55,13 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     // a problem with N <= 64 knots runs as one wave per workgroup (no barriers at all)
     auto kern = (NT == 64) ? &scp_kernel<MODEL, true> : &scp_kernel<MODEL, false>;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (getenv("GUSTO_DEV_DEBUG")) {
+        fprintf(stderr, "ws %p..%p (per problem %zu B)  X %p U %p subX %p subU %p st_i %p st_d %p lds %zu B mode %d\n", (void*)h->d_ws,
+                (void*)(h->d_ws + h->ws_doubles), P.wl.total * 8, (void*)h->d_X, (void*)h->d_U, (void*)h->d_subX, (void*)h->d_subU,
+                (void*)h->d_sti, (void*)h->d_std, lds, mode);
+        fprintf(stderr, "rowstate %zu obs_nh %zu obs_c0 %zu mask %zu PG %zu QQ %zu Paft %zu Piaft %zu KD %zu Phicl %zu pvt %zu total %zu\n",
+                P.wl.rowstate, P.wl.obs_nh, P.wl.obs_c0, P.wl.obs_mask, P.wl.PG, P.wl.QQ, P.wl.Paft, P.wl.Piaft, P.wl.KD, P.wl.Phicl, P.wl.pvt, P.wl.total);
+    }
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     // Longest-first schedule for big batches.  Workgroups are dispatched in index order onto ~4 slots per CU, so a
     // long problem with a high index starts late and the batch ends with a few problems on an empty GPU (44 % of

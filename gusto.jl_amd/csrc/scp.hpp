@@ -86,18 +86,9 @@ scp_kernel(const KParams P) {
     double* Xg = P.X + (size_t)b * N * n;
     double* Ug = P.U + (size_t)b * N * m;
 
-    if (P.mode == 1) {  // one convex subproblem around the stored (Xp,Up): parity hook
-        linearize<MODEL>(K, P.sub_toggle[b]);
-        IpmOut io;
-        ipm_solve<MODEL>(K, P.sub_Delta[b], P.sub_omega[b], 0.0, io, pf);
-        pf.flush(P.prof);
-        store_traj(K, K.Xw, K.Uw, P.sub_X + (size_t)b * N * n, P.sub_U + (size_t)b * N * m);
-        if (tid == 0) {
-            P.sub_obj[b] = io.obj; P.sub_status[b] = io.status; P.sub_iters[b] = io.iters;
-            for (int i = 0; i < n; i++) P.st_d[(size_t)b * SD_ND + SD_DUAL + i] = K.nu[i] * fmax(1.0, P.sub_omega[b]);
-        }
-        return;
-    }
+    // mode 1 = one convex subproblem around the stored (Xp,Up) (parity hook): it takes the first half of one trip of
+    // the loop below, so the interior point code exists once in the kernel
+    const bool hook = P.mode == 1;
 
     const gusto_scp_params& sp = P.sp;
     int* sti = P.st_i + (size_t)b * ST_NI;
@@ -112,24 +103,36 @@ scp_kernel(const KParams P) {
 
     // K.Xp / K.Up are the stored trajectory (SCPS.traj) itself
     // scp_gusto.jl:73-76
-    double Jt = cost_true(K, K.Up);
-    double rho0v = trust_region_ratio<MODEL>(K, K.Xp, K.Up, K.Xp, K.Up);
-    double Delta = P.Delta[hb + n_hist - 1], omega = P.omega[hb + n_hist - 1];
-    if (!P.cont) {
+    double Jt = 0, rho0v = 0;
+    if (!hook) {
+        Jt = cost_true(K, K.Up);
+        rho0v = trust_region_ratio<MODEL>(K, K.Xp, K.Up, K.Xp, K.Up);
+    }
+    double Delta = hook ? P.sub_Delta[b] : P.Delta[hb + n_hist - 1], omega = hook ? P.sub_omega[b] : P.omega[hb + n_hist - 1];
+    if (!P.cont && !hook) {
         if (tid == 0 && nJ < P.hist_cap) { P.J_true[hb + nJ] = Jt; P.J_full[hb + nJ] = Jt; }
         if (tid == 0 && n_rho < P.hist_cap) P.rho[hb + n_rho] = rho0v;
         nJ++; n_rho++;
     }
-    double toggle = Delta / 8 + P.mp.clearance;
+    double toggle = hook ? P.sub_toggle[b] : Delta / 8 + P.mp.clearance;
     double conv_prev = (n_hist >= 1) ? P.conv[hb + n_hist - 1] : 0.0;
 
     bool warm = sti[ST_WARM] != 0;  // the previous subproblem ended OPTIMAL: the next one starts centred at mu_warm
-    while (iterations < iter_cap && n_hist < P.hist_cap && nJ < P.hist_cap && n_rho < P.hist_cap) {
+    while (hook || (iterations < iter_cap && n_hist < P.hist_cap && nJ < P.hist_cap && n_rho < P.hist_cap)) {
         pf.tick(PF_SCP);
         linearize<MODEL>(K, toggle);                       // :95  update_model_params!
         pf.tick(PF_LIN);
         IpmOut io;
-        ipm_solve<MODEL>(K, Delta, omega, warm ? P.io.mu_warm : 0.0, io, pf);  // :96-104
+        ipm_solve<MODEL>(K, Delta, omega, (warm && !hook) ? P.io.mu_warm : 0.0, io, pf);  // :96-104
+        if (hook) {
+            pf.flush(P.prof);
+            store_traj(K, K.Xw, K.Uw, P.sub_X + (size_t)b * N * n, P.sub_U + (size_t)b * N * m);
+            if (tid == 0) {
+                P.sub_obj[b] = io.obj; P.sub_status[b] = io.status; P.sub_iters[b] = io.iters;
+                for (int i = 0; i < n; i++) P.st_d[(size_t)b * SD_ND + SD_DUAL + i] = K.nu[i] * fmax(1.0, omega);
+            }
+            return;
+        }
         warm = io.status == GUSTO_SOLVER_OPTIMAL;
         total_ipm += io.iters;
         const int h = n_hist;
