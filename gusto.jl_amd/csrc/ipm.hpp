@@ -1103,7 +1103,19 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             for (int i = 0; i < n; i++) gx0[i] = 0;
 #pragma unroll
             for (int i = 0; i < m; i++) gu0[i] = 0;
-            OpResidHess<n, m> op{rs, Hx, Hu, rdx, rdu, gx0, gu0, alpha_prev};
+            // (small models only: the 12/13-state kernels are far beyond the register file already -- 5 KB of scratch
+            // per lane and > 1200 spilled SGPRs -- and more live values there have produced wrong code)
+            constexpr int NP = (n <= 8) ? T::NFIX + T::NHU : 0;
+            RowPre<NP> pre;
+            if constexpr (NP > 0) {
+                const int slot_u = T::NFIX + K.P.n_obs + 2 * n;
+                const bool upd = alpha_prev != 0.0;
+                pre.load(rs, T::NFIX, slot_u, [&](int var) {
+                    return var == RS_T || var == RS_LAM || var == RS_S || var == RS_LAMB ||
+                           (upd && (var == RS_DT || var == RS_DL || var == RS_DS));
+                });
+            }
+            OpResidHess<n, m, NP> op{rs, Hx, Hu, rdx, rdu, gx0, gu0, alpha_prev, &pre};
             visit_rows<MODEL>(ctx, xs, us, op);
             // row part of the predictor right-hand side, parked in the (currently free) step arrays
 #pragma unroll

@@ -38,7 +38,7 @@ template <int I, int E, class F> GD void static_for(F&& f) {
     }
 }
 
-template <bool ISU, int I0, int CNT, class Op>
+template <bool ISU, int I0, int CNT, int FX = -1, class Op>
 GD void quad_row(Op& op, int slot, int kind, const double* v, const double* a, const double* v0, double c0,
                  double mul, double off) {
     RowEv<CNT> ev;
@@ -52,9 +52,9 @@ GD void quad_row(Op& op, int slot, int kind, const double* v, const double* a, c
     }
     ev.raw = g;
     ev.g = mul * g - off;
-    op.template row<ISU, I0, CNT>(slot, kind, ev);
+    op.template row<ISU, I0, CNT, FX>(slot, kind, ev);
 }
-template <bool ISU, int I0, int CNT, class Op>
+template <bool ISU, int I0, int CNT, int FX = -1, class Op>
 GD void lin_row(Op& op, int slot, int kind, const double* v, const double* b, double c0, double mul, double off) {
     RowEv<CNT> ev;
     double g = c0;
@@ -66,7 +66,7 @@ GD void lin_row(Op& op, int slot, int kind, const double* v, const double* b, do
     }
     ev.raw = g;
     ev.g = mul * g - off;
-    op.template row<ISU, I0, CNT>(slot, kind, ev);
+    op.template row<ISU, I0, CNT, FX>(slot, kind, ev);
 }
 
 // ---- the row programs ------------------------------------------------------------------------------
@@ -85,7 +85,7 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
         constexpr int nv = is2 ? 2 : 3, iw = is2 ? 5 : (man ? 10 : 9), nw = is2 ? 1 : 3;
         int slot = 0;
         if constexpr (!man) {  // stri_state_trust_region (freeflyer_se2.jl:323-326): w*||x-xp||^2 - Delta <= s
-            quad_row<false, 0, n>(op, slot++, ROW_PEN_TR, xs, one, c.xp, 0.0, kw, c.kappa * c.Delta);
+            quad_row<false, 0, n, 0>(op, slot++, ROW_PEN_TR, xs, one, c.xp, 0.0, kw, c.kappa * c.Delta);
         } else {
             // cse_quaternion_norm (manifold.jl:308-313), penalised as a +-eps pair (scp_gusto.jl:297-311)
             const double* qp = c.xp + 6;
@@ -93,14 +93,14 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
             double bp[4], bm[4], c0 = qn - 1.0;
 #pragma unroll
             for (int j = 0; j < 4; j++) { bp[j] = qp[j] / qn; bm[j] = -bp[j]; c0 -= qp[j] * qp[j] / qn; }
-            lin_row<false, 6, 4>(op, slot++, ROW_HARD_EQ, xs, bm, -c0, kw, c.kappa * c.P->sp.eps);
-            lin_row<false, 6, 4>(op, slot++, ROW_PEN_EQ, xs, bp, c0, kw, c.kappa * c.P->sp.eps);
+            lin_row<false, 6, 4, 0>(op, slot++, ROW_HARD_EQ, xs, bm, -c0, kw, c.kappa * c.P->sp.eps);
+            lin_row<false, 6, 4, 1>(op, slot++, ROW_PEN_EQ, xs, bp, c0, kw, c.kappa * c.P->sp.eps);
             const double m1 = -1.0;  // csi_orientation_sign (manifold.jl:316-319)
-            lin_row<false, 6, 1>(op, slot++, ROW_PEN, xs, &m1, 0.0, kw, 0.0);
+            lin_row<false, 6, 1, 2>(op, slot++, ROW_PEN, xs, &m1, 0.0, kw, 0.0);
         }
         // csi_translational_velocity_bound / csi_angular_velocity_bound (freeflyer_se2.jl:225-233)
-        quad_row<false, 3, nv>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
-        quad_row<false, iw, nw>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_omega * mp.hard_limit_omega, kw, 0.0);
+        quad_row<false, 3, nv, T::NFIX - 2>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
+        quad_row<false, iw, nw, T::NFIX - 1>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_omega * mp.hard_limit_omega, kw, 0.0);
         // ncsi_*_obstacle_avoidance_*_convexified (freeflyer_se2.jl:265-288): clearance - (d + nhat.(r - r0))
         uint64_t mk = c.mask;
         while (mk) {
@@ -118,22 +118,22 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
             for (int j = 0; j < nf; j++) af[j] = 1.0 / (mp.mass * mp.mass);
 #pragma unroll
             for (int j = 0; j < nm; j++) { const double ji = 1.0 / mp.Jdiag[is2 ? 2 : j]; am[j] = ji * ji; }
-            quad_row<true, 0, nf>(op, slot_u, ROW_HARD, us, af, nullptr, -mp.hard_limit_accel * mp.hard_limit_accel,
+            quad_row<true, 0, nf, T::NFIX>(op, slot_u, ROW_HARD, us, af, nullptr, -mp.hard_limit_accel * mp.hard_limit_accel,
                                   1.0 / (mp.hard_limit_accel * mp.hard_limit_accel), 0.0);
-            quad_row<true, im, nm>(op, slot_u + 1, ROW_HARD, us, am, nullptr, -mp.hard_limit_alpha * mp.hard_limit_alpha,
+            quad_row<true, im, nm, T::NFIX + 1>(op, slot_u + 1, ROW_HARD, us, am, nullptr, -mp.hard_limit_alpha * mp.hard_limit_alpha,
                                    1.0 / (mp.hard_limit_alpha * mp.hard_limit_alpha), 0.0);
         }
     } else {  // DubinsCar: csi_max/min_bound_constraints, cci_max/min_bound_constraints (dynamics.jl:56-81)
         static_for<0, n>([&](auto I) {
             constexpr int i = decltype(I)::value;
             const double p1 = 1.0, m1 = -1.0;
-            lin_row<false, i, 1>(op, i, ROW_PEN, xs, &p1, -mp.x_max[i], kw, 0.0);
-            lin_row<false, i, 1>(op, n + i, ROW_PEN, xs, &m1, mp.x_min[i], kw, 0.0);
+            lin_row<false, i, 1, i>(op, i, ROW_PEN, xs, &p1, -mp.x_max[i], kw, 0.0);
+            lin_row<false, i, 1, n + i>(op, n + i, ROW_PEN, xs, &m1, mp.x_min[i], kw, 0.0);
         });
         if (c.k < c.N - 1) {
             const double p1 = 1.0, m1 = -1.0;
-            lin_row<true, 0, 1>(op, slot_u, ROW_HARD, us, &p1, -mp.u_max, 1.0 / fabs(mp.u_max), 0.0);
-            lin_row<true, 0, 1>(op, slot_u + 1, ROW_HARD, us, &m1, mp.u_min, 1.0 / fabs(mp.u_min), 0.0);
+            lin_row<true, 0, 1, T::NFIX>(op, slot_u, ROW_HARD, us, &p1, -mp.u_max, 1.0 / fabs(mp.u_max), 0.0);
+            lin_row<true, 0, 1, T::NFIX + 1>(op, slot_u + 1, ROW_HARD, us, &m1, mp.u_min, 1.0 / fabs(mp.u_min), 0.0);
         }
     }
     if (c.k == c.N - 1) {  // csbci_goal_constraints: BoxGoal rows are hard (dynamics.jl:37-42, scp_gusto.jl:236-245)
@@ -160,6 +160,20 @@ struct RowState {
     GD double& at(int var, int slot) const { return (base + (size_t)(var * nslot + slot) * (size_t)N)[k]; }
 };
 
+// State of the rows every knot has at compile-time positions (the NFIX state rows, then the NHU control rows; template
+// id FX of visit_rows), fetched in ONE batch of loads before a row pass: otherwise each row's loads are issued when
+// the pass reaches it, behind the stores of the row before, and the pass pays one memory round trip per row.
+template <int NP> struct RowPre {
+    double v[RS_NVAR][NP > 0 ? NP : 1];
+    template <class F> GD void load(const RowState& rs, int nfix, int slot_u, F&& want) {
+#pragma unroll
+        for (int var = 0; var < RS_NVAR; var++)
+#pragma unroll
+            for (int i = 0; i < NP; i++)
+                if (want(var)) v[var][i] = rs.at(var, i < nfix ? i : slot_u + (i - nfix));
+    }
+};
+
 // ---- the Ops ---------------------------------------------------------------------------------------
 // Start point.  Cold (muw == 0: the first subproblem of an SCP run, or after a solver failure): slacks just inside (offset 0.01),
 // penalised multipliers lam_a = lam_b = 1/2, hard-row multipliers 0.01/t -- tuned on the freeflyer batch.
@@ -170,7 +184,7 @@ struct OpInit {
     RowState rs;
     double muw;
     int ncomp = 0;
-    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
+    template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
         if (row_is_hard(kind)) {
             const double t = fmax(-ev.g, 1e-2), mu0 = (muw > 0) ? muw : 0.01;
             rs.at(RS_T, slot) = t; rs.at(RS_LAM, slot) = mu0 / t; rs.at(RS_LAMB, slot) = 0.0; rs.at(RS_S, slot) = 0.0;
@@ -193,17 +207,21 @@ struct OpInit {
 // The row update of the previous interior point step (t += alpha dt, ...) is folded into this pass, and so is the
 // row part of the PREDICTOR right-hand side (OpRhs with mu_t = ka = kb = 0 reduces to coef = lam + sigma * g), which
 // saves the predictor its own pass over the rows.
-template <int n, int m> struct OpResidHess {
+template <int n, int m, int NP> struct OpResidHess {
     RowState rs;
     double *Hx, *Hu, *rdx, *rdu, *gx0, *gu0;
     double alpha_prev;  // 0 on the first trip
+    const RowPre<NP>* pre;
     double comp = 0, maxrp = 0;
-    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
-        double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
+    template <int FX> GD double get(int var, int slot) const {
+        if constexpr (FX >= 0 && NP > 0) return pre->v[var][FX]; else return rs.at(var, slot);
+    }
+    template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
+        double t = get<FX>(RS_T, slot), lam = get<FX>(RS_LAM, slot);
         double sig, rp;
         if (alpha_prev != 0.0) {
-            const double dl = rs.at(RS_DL, slot);
-            t += alpha_prev * rs.at(RS_DT, slot);
+            const double dl = get<FX>(RS_DL, slot);
+            t += alpha_prev * get<FX>(RS_DT, slot);
             lam += alpha_prev * dl;
             rs.at(RS_T, slot) = t; rs.at(RS_LAM, slot) = lam;
         }
@@ -212,10 +230,10 @@ template <int n, int m> struct OpResidHess {
             comp += t * lam;
             sig = lam * rcp_nr(t);
         } else {
-            double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
+            double s = get<FX>(RS_S, slot), lamb = get<FX>(RS_LAMB, slot);
             if (alpha_prev != 0.0) {
-                s += alpha_prev * rs.at(RS_DS, slot);
-                lamb -= alpha_prev * rs.at(RS_DL, slot);
+                s += alpha_prev * get<FX>(RS_DS, slot);
+                lamb -= alpha_prev * get<FX>(RS_DL, slot);
                 rs.at(RS_S, slot) = s; rs.at(RS_LAMB, slot) = lamb;
             }
             rp = ev.g - s + t;
@@ -245,7 +263,7 @@ struct OpRhs {
     double *gx, *gu;
     int pass;
     double mu_t;
-    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
+    template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
         const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
         const double ka = pass ? rs.at(RS_KA, slot) : 0.0;
         double coef;
@@ -289,7 +307,7 @@ struct OpStep {
     double mu_t, tau;
     StepFrac amax;
     double c0 = 0, c1 = 0, c2 = 0;
-    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
+    template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
         const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
         const double ka = pass ? rs.at(RS_KA, slot) : 0.0;
         const double* dv = ISU ? dus : dxs;
@@ -326,7 +344,7 @@ struct OpStep {
 struct OpSlackSum {
     RowState rs;
     double sum = 0;
-    template <bool ISU, int I0, int CNT> GD void row(int slot, int kind, const RowEv<CNT>&) {
+    template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>&) {
         if (!row_is_hard(kind)) sum += rs.at(RS_S, slot);   // (the last residual pass already applied every update)
     }
 };
@@ -335,7 +353,7 @@ struct OpSlackSum {
 struct OpCheck {
     double eps;
     bool ok = true;
-    template <bool ISU, int I0, int CNT> GD void row(int, int kind, const RowEv<CNT>& ev) {
+    template <bool ISU, int I0, int CNT, int FX> GD void row(int, int kind, const RowEv<CNT>& ev) {
         if (ISU) return;
         if (kind == ROW_PEN && ev.raw >= eps) ok = false;
         if (kind == ROW_PEN_EQ && (ev.raw <= -eps || ev.raw >= eps)) ok = false;
