@@ -33,6 +33,12 @@ template <> struct MT<GUSTO_FREEFLYER_SE2> {
     static constexpr bool PG2 = true;
     static constexpr int pg_r0(int c) { return c < 3 ? c : (c < 6 ? c - 3 : c - 6); }
     static constexpr int pg_r1(int c) { return c < 3 ? c + 3 : (c < 6 ? c : c - 3); }
+    // the same structure for the stage-parallel products: M = I + dt/2 A, B = [0; diag], Gam = 2 M (dt/2 B).
+    // Unrolled loops test these with compile-time indices, so the structural zeros cost neither a load nor an FMA.
+    static constexpr bool Anz(int i, int j) { return j == i + 3; }
+    static constexpr bool Mnz(int i, int j) { return i == j || j == i + 3; }
+    static constexpr bool Bnz(int i, int j) { return i == j + 3; }
+    static constexpr bool Gnz(int i, int j) { return i == j || i == j + 3; }
 };
 template <> struct MT<GUSTO_DUBINS_CAR> {
     static constexpr int n = 3, m = 1, WS = 2, NFIX = 6, NHU = 2;
@@ -40,6 +46,10 @@ template <> struct MT<GUSTO_DUBINS_CAR> {
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
     static constexpr int pg_r1(int) { return 0; }
+    static constexpr bool Anz(int, int) { return true; }
+    static constexpr bool Mnz(int, int) { return true; }
+    static constexpr bool Bnz(int, int) { return true; }
+    static constexpr bool Gnz(int, int) { return true; }
 };
 template <> struct MT<GUSTO_ASTROBEE_SE3> {
     static constexpr int n = 12, m = 6, WS = 3, NFIX = 3, NHU = 2;
@@ -47,6 +57,10 @@ template <> struct MT<GUSTO_ASTROBEE_SE3> {
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
     static constexpr int pg_r1(int) { return 0; }
+    static constexpr bool Anz(int, int) { return true; }
+    static constexpr bool Mnz(int, int) { return true; }
+    static constexpr bool Bnz(int, int) { return true; }
+    static constexpr bool Gnz(int, int) { return true; }
 };
 template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr int n = 13, m = 6, WS = 3, NFIX = 5, NHU = 2;
@@ -54,6 +68,10 @@ template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
     static constexpr int pg_r1(int) { return 0; }
+    static constexpr bool Anz(int, int) { return true; }
+    static constexpr bool Mnz(int, int) { return true; }
+    static constexpr bool Bnz(int, int) { return true; }
+    static constexpr bool Gnz(int, int) { return true; }
 };
 
 // symmetric packed index (upper triangle, row-major)

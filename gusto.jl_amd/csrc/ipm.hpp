@@ -101,14 +101,15 @@ template <int MODEL, bool ONEWAVE> struct Blk {
 
 // M_k and Gam_k of knot k (k >= 1) from the stored [Phi | Gam] block
 template <class BLK> GD void load_M_Gam(const BLK& K, int k, double* M, double* Gam) {
+    using T = typename BLK::T;
     constexpr int n = BLK::n, m = BLK::m, NZ = n + m;
     const double* pg = K.PGk(k);
 #pragma unroll
     for (int i = 0; i < n; i++) {
 #pragma unroll
-        for (int j = 0; j < n; j++) M[i * n + j] = 0.5 * (pg[i * NZ + j] + (i == j ? 1.0 : 0.0));
+        for (int j = 0; j < n; j++) M[i * n + j] = T::Mnz(i, j) ? 0.5 * (pg[i * NZ + j] + (i == j ? 1.0 : 0.0)) : 0.0;
 #pragma unroll
-        for (int j = 0; j < m; j++) Gam[i * m + j] = pg[i * NZ + n + j];
+        for (int j = 0; j < m; j++) Gam[i * m + j] = T::Gnz(i, j) ? pg[i * NZ + n + j] : 0.0;
     }
 }
 
@@ -1060,9 +1061,9 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             for (int i = 0; i < n; i++) {
                 double s = fp[i];
 #pragma unroll
-                for (int j = 0; j < n; j++) s += Ad[i * n + j] * (xs[j] - xpk[j]);
+                for (int j = 0; j < n; j++) if (T::Anz(i, j)) s += Ad[i * n + j] * (xs[j] - xpk[j]);
 #pragma unroll
-                for (int j = 0; j < m; j++) s += Bd[i * m + j] * (us[j] - upk[j]);
+                for (int j = 0; j < m; j++) if (T::Bnz(i, j)) s += Bd[i * m + j] * (us[j] - upk[j]);
                 K.pv[k * n + i] = s;
             }
         }
@@ -1139,14 +1140,14 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 for (int i = 0; i < n; i++) {
                     double s = vd[i];
 #pragma unroll
-                    for (int j = 0; j < n; j++) s += hdt * Ad[j * n + i] * vs[j];
+                    for (int j = 0; j < n; j++) if (T::Anz(j, i)) s += hdt * Ad[j * n + i] * vs[j];
                     rdx[i] += s;
                 }
 #pragma unroll
                 for (int i = 0; i < m; i++) {
                     double s = 0;
 #pragma unroll
-                    for (int j = 0; j < n; j++) s += hdt * Bd[j * m + i] * vs[j];
+                    for (int j = 0; j < n; j++) if (T::Bnz(j, i)) s += hdt * Bd[j * m + i] * vs[j];
                     rdu[i] += s;
                 }
             }
@@ -1181,14 +1182,14 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                     for (int i = 0; i < n; i++) {
                         double s = 0;
 #pragma unroll
-                        for (int l = 0; l < n; l++) s += Hx[sidx(i, l, n)] * Mk[l * n + j];
+                        for (int l = 0; l < n; l++) if (T::Mnz(l, j)) s += Hx[sidx(i, l, n)] * Mk[l * n + j];
                         tcol[i] = s;
                     }
 #pragma unroll
                     for (int i = 0; i <= j; i++) {
                         double s = 0;
 #pragma unroll
-                        for (int l = 0; l < n; l++) s += Mk[l * n + i] * tcol[l];
+                        for (int l = 0; l < n; l++) if (T::Mnz(l, i)) s += Mk[l * n + i] * tcol[l];
                         Qt[sidx(i, j, n)] = s;
                         qqg[sidx(i, j, NZ)] = s;
                     }
@@ -1199,7 +1200,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                     for (int j = 0; j < m; j++) {
                         double s = 0;
 #pragma unroll
-                        for (int l = 0; l < n; l++) s += Qt[sidx(i, l, n)] * (hdt * Bd[l * m + j]);
+                        for (int l = 0; l < n; l++) if (T::Bnz(l, j)) s += Qt[sidx(i, l, n)] * (hdt * Bd[l * m + j]);
                         Qb[i * m + j] = s;
                         qqg[sidx(i, n + j, NZ)] = s;
                     }
@@ -1209,14 +1210,14 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                     for (int j = i; j < m; j++) {
                         double s = Hu[sidx(i, j, m)];
 #pragma unroll
-                        for (int l = 0; l < n; l++) s += (hdt * Bd[l * m + i]) * Qb[l * m + j];
+                        for (int l = 0; l < n; l++) if (T::Bnz(l, i)) s += (hdt * Bd[l * m + i]) * Qb[l * m + j];
                         qqg[sidx(n + i, n + j, NZ)] = s;
                     }
 #pragma unroll
                 for (int i = 0; i < n; i++) {
                     double s = 0, c = -rdk[i];
 #pragma unroll
-                    for (int l = 0; l < n; l++) { s += Qt[sidx(i, l, n)] * rdk[l]; c += 2.0 * Mk[i * n + l] * rdk[l]; }
+                    for (int l = 0; l < n; l++) { s += Qt[sidx(i, l, n)] * rdk[l]; if (T::Mnz(i, l)) c += 2.0 * Mk[i * n + l] * rdk[l]; }
                     K.qrd[k * n + i] = s;
                     K.cv[k * n + i] = c;
                 }
@@ -1306,7 +1307,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                     for (int i = 0; i < n; i++) {
                         double s = K.qrd[k * n + i];
 #pragma unroll
-                        for (int l = 0; l < n; l++) s += Mk[l * n + i] * gx[l];
+                        for (int l = 0; l < n; l++) if (T::Mnz(l, i)) s += Mk[l * n + i] * gx[l];
                         gy[i] = s;
                     }
                 } else {
@@ -1318,7 +1319,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 for (int i = 0; i < m; i++) {
                     double s = gu[i];
 #pragma unroll
-                    for (int l = 0; l < n; l++) s += (hdt * Bd[l * m + i]) * gy[l];
+                    for (int l = 0; l < n; l++) if (T::Bnz(l, i)) s += (hdt * Bd[l * m + i]) * gy[l];
                     quk[i] = s;
                     K.qu[k * m + i] = s;
                 }
@@ -1349,7 +1350,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
 #pragma unroll
                     for (int i = 0; i < n; i++)
 #pragma unroll
-                        for (int j = 0; j < m; j++) Gamk[i * m + j] = pg[i * NZ + n + j];
+                        for (int j = 0; j < m; j++) Gamk[i * m + j] = T::Gnz(i, j) ? pg[i * NZ + n + j] : 0.0;
                 } else {
                     Dyn<MODEL>::B(K.P.mp, Gamk);
 #pragma unroll
@@ -1361,7 +1362,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 for (int i = 0; i < m; i++) {
                     double s = K.qu[k * m + i];
 #pragma unroll
-                    for (int l = 0; l < n; l++) s += Gamk[l * m + i] * tt[l];
+                    for (int l = 0; l < n; l++) if (T::Gnz(l, i)) s += Gamk[l * m + i] * tt[l];
                     lu[i] = s;
                 }
 #pragma unroll
@@ -1414,7 +1415,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
 #pragma unroll
                     for (int i = 0; i < n; i++)
 #pragma unroll
-                        for (int j = 0; j < m; j++) Gamk[i * m + j] = pg[i * NZ + n + j];
+                        for (int j = 0; j < m; j++) Gamk[i * m + j] = T::Gnz(i, j) ? pg[i * NZ + n + j] : 0.0;
                 } else {
                     Dyn<MODEL>::B(K.P.mp, Gamk);
 #pragma unroll
@@ -1424,7 +1425,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 for (int i = 0; i < n; i++) {
                     double s = K.cv[k * n + i];
 #pragma unroll
-                    for (int l = 0; l < m; l++) s -= Gamk[i * m + l] * dk[l];
+                    for (int l = 0; l < m; l++) if (T::Gnz(i, l)) s -= Gamk[i * m + l] * dk[l];
                     K.dY[k * n + i] = s;
                 }
             }
@@ -1456,14 +1457,14 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                     for (int i = 0; i < n; i++) {
                         double s = dyp[i] + K.rd[k * n + i];
 #pragma unroll
-                        for (int l = 0; l < m; l++) s += (hdt * Bd[i * m + l]) * dus[l];
+                        for (int l = 0; l < m; l++) if (T::Bnz(i, l)) s += (hdt * Bd[i * m + l]) * dus[l];
                         a[i] = s;
                     }
 #pragma unroll
                     for (int i = 0; i < n; i++) {
                         double s = 0;
 #pragma unroll
-                        for (int l = 0; l < n; l++) s += Mk[i * n + l] * a[l];
+                        for (int l = 0; l < n; l++) if (T::Mnz(i, l)) s += Mk[i * n + l] * a[l];
                         dxs[i] = s;
                     }
                 }
@@ -1498,7 +1499,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 for (int i = 0; i < n; i++) {
                     double s = gxs[i] + K.nun[n + i];
 #pragma unroll
-                    for (int j = 0; j < n; j++) s += hdt * Ad[j * n + i] * K.nun[n + j];
+                    for (int j = 0; j < n; j++) if (T::Anz(j, i)) s += hdt * Ad[j * n + i] * K.nun[n + j];
                     K.nun[i] = -s;
                 }
             }
