@@ -206,10 +206,30 @@ struct OpMax { GD double operator()(double a, double b) const { return fmax(a, b
 struct OpMin { GD double operator()(double a, double b) const { return fmin(a, b); } };
 struct OpSum { GD double operator()(double a, double b) const { return a + b; } };
 
+GD double readlane_f64(double v, int lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), lane);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// lane i <- lane (i - N) mod 16 within its row of 16 lanes (DPP row_ror): a VALU move, no trip through the LDS crossbar
+template <int N> GD double row_ror_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = (int)(u & 0xffffffffu), hi = (int)(u >> 32);
+    const unsigned rl = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, 0x120 + N, 0xf, 0xf, false);
+    const unsigned rh = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, 0x120 + N, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)rh << 32) | rl);
+}
+// wave-wide reduction, the same value in every lane: four DPP rotate steps inside each row of 16 lanes, then the four
+// row results through v_readlane (ds_bpermute based __shfl_xor steps cost an LDS round trip each: ~600 cycles per
+// reduction, and an interior point iteration makes two dozen of them)
 template <class Op> GD double wave_reduce(double v, Op op) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off, 64));
-    return v;
+    v = op(v, row_ror_f64<1>(v));
+    v = op(v, row_ror_f64<2>(v));
+    v = op(v, row_ror_f64<4>(v));
+    v = op(v, row_ror_f64<8>(v));
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return op(op(r0, r1), op(r2, r3));
 }
 // NaN-propagating max: used for residuals so that a NaN iterate is detected
 GD double nanmax(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }

@@ -479,12 +479,6 @@ template <int MODEL> struct SweepView {
 };
 
 // ---- one-wave variants: every lane's role and LDS addresses are fixed before the knot loop ---------------
-GD double readlane_f64(double v, int lane) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), lane);
-    const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), lane);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
 
 // LDS buffer holding [Phi Gam] of knot k: knot 0 has its own ([0 | b_0], x_1 is pinned), LTI models one more,
 // time-varying models double-buffer.
