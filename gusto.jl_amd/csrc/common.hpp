@@ -25,6 +25,7 @@ constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5,
 template <int MODEL> struct MT;
 template <> struct MT<GUSTO_FREEFLYER_SE2> {
     static constexpr int n = 6, m = 3, WS = 2, NFIX = 3, NHU = 2;
+    static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool LTI = true, HAS_OBS = true;
     // Double integrator (freeflyer_se2.jl:121,178-179: A = [0 I; 0 0], B = [0; diag]): Phi = I + dt A and
     // Gam = 2 (I + dt/2 A) b have at most TWO nonzeros per column of [Phi Gam], at rows pg_r0(c), pg_r1(c)
@@ -42,6 +43,7 @@ template <> struct MT<GUSTO_FREEFLYER_SE2> {
 };
 template <> struct MT<GUSTO_DUBINS_CAR> {
     static constexpr int n = 3, m = 1, WS = 2, NFIX = 6, NHU = 2;
+    static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool LTI = false, HAS_OBS = false;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
@@ -53,6 +55,7 @@ template <> struct MT<GUSTO_DUBINS_CAR> {
 };
 template <> struct MT<GUSTO_ASTROBEE_SE3> {
     static constexpr int n = 12, m = 6, WS = 3, NFIX = 3, NHU = 2;
+    static constexpr bool SWEEP_CALL = true;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
@@ -66,6 +69,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3> {
 };
 template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr int n = 13, m = 6, WS = 3, NFIX = 5, NHU = 2;
+    static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }

@@ -964,8 +964,18 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
     K.sync();
 }
 
+// MT::SWEEP_CALL (measured per model: astrobeeSE3 +9 %, the manifold model -10 %): the sweep as a real call.  Inlined, its 50-stage loop shares one register allocation with the whole
+// interior point iteration and the allocator spills INSIDE the loop; called, the loop gets the register file to itself
+// and the caller's live values are saved once around the call.
+template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(SweepView<MODEL> K, double* fail, Prof* pf) {
+    factor_sweep_1w<MODEL>(K, fail, *pf);
+}
 template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof& pf) {
-    if constexpr (BLK::ONE) factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail, pf); else factor_sweep_mw<MODEL>(K, fail);
+    if constexpr (!BLK::ONE) factor_sweep_mw<MODEL>(K, fail);
+#ifndef GUSTO_SWEEP_INLINE
+    else if constexpr (MT<MODEL>::SWEEP_CALL) factor_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K), fail, &pf);
+#endif
+    else factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail, pf);
 }
 template <int MODEL, class BLK> GD void backward_sweep(BLK& K) {
     if constexpr (BLK::ONE) backward_sweep_1w(SweepView<MODEL>::make(K)); else backward_sweep_mw(K);
