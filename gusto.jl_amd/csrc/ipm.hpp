@@ -977,11 +977,17 @@ template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof&
 #endif
     else factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail, pf);
 }
+template <int MODEL> __device__ __noinline__ void backward_sweep_1w_call(SweepView<MODEL> K) { backward_sweep_1w(K); }
+template <int MODEL> __device__ __noinline__ void forward_sweep_1w_call(SweepView<MODEL> K) { forward_sweep_1w(K); }
 template <int MODEL, class BLK> GD void backward_sweep(BLK& K) {
-    if constexpr (BLK::ONE) backward_sweep_1w(SweepView<MODEL>::make(K)); else backward_sweep_mw(K);
+    if constexpr (!BLK::ONE) backward_sweep_mw(K);
+    else if constexpr (MT<MODEL>::SWEEP_CALL) backward_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K));
+    else backward_sweep_1w(SweepView<MODEL>::make(K));
 }
 template <int MODEL, class BLK> GD void forward_sweep(BLK& K) {
-    if constexpr (BLK::ONE) forward_sweep_1w(SweepView<MODEL>::make(K)); else forward_sweep_mw(K);
+    if constexpr (!BLK::ONE) forward_sweep_mw(K);
+    else if constexpr (MT<MODEL>::SWEEP_CALL) forward_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K));
+    else forward_sweep_1w(SweepView<MODEL>::make(K));
 }
 
 // ---- the interior point method ---------------------------------------------------------------------
