@@ -990,6 +990,51 @@ template <int MODEL, class BLK> GD void forward_sweep(BLK& K) {
     else forward_sweep_1w(SweepView<MODEL>::make(K));
 }
 
+// Gd^-1 -> sP for the models whose goal system does not fit one lane's registers, by the whole workgroup: in-place
+// right-looking Cholesky of sGd (identity on the coordinates without a point goal), L^-1 one column per lane, then
+// L^-T L^-1 one entry per lane.  Scratch: the n*n doubles behind sGd.
+template <int MODEL, class BLK> GD void inv_spd_block(BLK& K, double* fail) {
+    constexpr int n = BLK::n;
+    const int tid = K.tid, nt = K.nt();
+    double* A = K.sGd;
+    double* Li = K.sGd + n * n;
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e % n;
+        if (i == j && !K.is_goal(i)) A[e] = 1.0;
+        Li[e] = 0.0;
+    }
+    K.sync();
+    for (int j = 0; j < n; j++) {
+        const double ajj = A[j * n + j];
+        if (!(ajj > 0.0)) *fail = 1.0;
+        const double d = rsqrt_nr(ajj);
+        K.sync();
+        if (tid >= j && tid < n) A[tid * n + j] *= d;          // column j of L (row j: a_jj * d = sqrt(a_jj))
+        K.sync();
+        for (int e = tid; e < n * n; e += nt) {                 // trailing update of the lower triangle
+            const int i = e / n, c = e % n;
+            if (c > j && i >= c) A[e] -= A[i * n + j] * A[c * n + j];
+        }
+        K.sync();
+    }
+    if (tid < n) {   // column tid of L^-1 by forward substitution (1 / l_ii by Newton reciprocal)
+        const int c = tid;
+        Li[c * n + c] = rcp_nr(A[c * n + c]);
+        for (int i = c + 1; i < n; i++) {
+            double acc = 0;
+            for (int l = c; l < i; l++) acc -= A[i * n + l] * Li[l * n + c];
+            Li[i * n + c] = acc * rcp_nr(A[i * n + i]);
+        }
+    }
+    K.sync();
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e % n;
+        double acc = 0;
+        for (int l = (i > j ? i : j); l < n; l++) acc += Li[l * n + i] * Li[l * n + j];
+        K.sP[e] = acc;
+    }
+}
+
 // ---- the interior point method ---------------------------------------------------------------------
 // Register discipline: nothing per-thread stays live across a sequential sweep.  Every stage-parallel block
 // re-reads the iterate (Xw/Uw), the linearisation point (Xp/Up) and the stage matrices it needs from LDS / L2
@@ -1277,12 +1322,9 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                         for (int l = 0; l < n; l++) if (l >= i && l >= j) s2 += Li[l * n + i] * Li[l * n + j];
                         K.sP[i * n + j] = s2;
                     }
-            } else {
-                for (int i = 0; i < n; i++)
-                    if (!K.is_goal(i)) K.sGd[i * n + i] = 1.0;
-                if (!inv_spd_rt(K.sGd, K.sP, K.sGd + n * n, n)) *fail = 1.0;
             }
         }
+        if constexpr (n > 8) inv_spd_block<MODEL>(K, fail);   // (the whole workgroup: one lane took 170 k cycles for n = 12)
         K.sync();
         if (*fail != 0.0) break;
         pf.tick(PF_POSTF);
