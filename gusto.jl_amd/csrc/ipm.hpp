@@ -132,7 +132,59 @@ template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
             for (int i = 0; i < n; i++)
 #pragma unroll
                 for (int j = 0; j < n; j++) G[i * n + j] = (i == j ? 1.0 : 0.0) - h * A[i * n + j];
-            inv_gauss_jordan<n>(G, M);
+            if constexpr (MODEL == GUSTO_ASTROBEE_SE3 || MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD) {
+                // x = (r, v, attitude a, w): G = I - hA = [I -hI 0 0; 0 I 0 0; 0 0 P Q; 0 0 0 W] (Anz), so
+                // M = G^-1 = [I hI 0 0; 0 I 0 0; 0 0 P^-1 -P^-1 Q W^-1; 0 0 0 W^-1]: two small inverses instead of a
+                // pivoted 12 x 24 / 13 x 26 elimination in registers (which was most of this phase for these models)
+                constexpr int q = n - 9;   // attitude block: 3 (MRP) or 4 (quaternion)
+                double Pm[q * q], Pi[q * q], Wm[9], Wi[9], Qm[q * 3], T1[q * 3];
+#pragma unroll
+                for (int i = 0; i < q; i++) {
+#pragma unroll
+                    for (int j = 0; j < q; j++) Pm[i * q + j] = G[(6 + i) * n + 6 + j];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) Qm[i * 3 + j] = G[(6 + i) * n + 6 + q + j];
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) Wm[i * 3 + j] = G[(6 + q + i) * n + 6 + q + j];
+                inv_gauss_jordan<q>(Pm, Pi);
+                inv_gauss_jordan<3>(Wm, Wi);
+#pragma unroll
+                for (int i = 0; i < q; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        double t = 0;
+#pragma unroll
+                        for (int l = 0; l < 3; l++) t += Qm[i * 3 + l] * Wi[l * 3 + j];
+                        T1[i * 3 + j] = t;
+                    }
+#pragma unroll
+                for (int i = 0; i < n * n; i++) M[i] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) M[i * n + i] = 1.0;
+#pragma unroll
+                for (int i = 0; i < 3; i++) M[i * n + 3 + i] = h;
+#pragma unroll
+                for (int i = 0; i < q; i++) {
+#pragma unroll
+                    for (int j = 0; j < q; j++) M[(6 + i) * n + 6 + j] = Pi[i * q + j];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        double t = 0;
+#pragma unroll
+                        for (int l = 0; l < q; l++) t -= Pi[i * q + l] * T1[l * 3 + j];
+                        M[(6 + i) * n + 6 + q + j] = t;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) M[(6 + q + i) * n + 6 + q + j] = Wi[i * 3 + j];
+            } else {
+                inv_gauss_jordan<n>(G, M);
+            }
             double* pg = K.PG + (size_t)(T::LTI ? 0 : k) * n * NZ;
 #pragma unroll
             for (int i = 0; i < n; i++) {
