@@ -1087,6 +1087,113 @@ template <int MODEL, class BLK> GD void inv_spd_block(BLK& K, double* fail) {
     }
 }
 
+// The phase between the two vector sweeps of a right-hand side: feed-forward d0 = S^-1 lu, the goal multiplier
+// mu_g = Gd^-1 theta, then d_k = d0 + D_k mu_g and ct_k = c_k - Gam_k d_k.  A function of its own so that the models
+// with MT::SWEEP_CALL can run it as a real call (own register allocation; everything it touches lives in LDS / HBM).
+template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, double hdt, double* red, double* mugn) {
+    using T = MT<MODEL>;
+    using R = Rec<MODEL>;
+    constexpr int n = T::n, m = T::m, NZ = n + m;
+    const int N = K.N;
+    // feed-forward d0 = S^-1 lu and the goal multiplier
+    double th[n], d0[m];
+#pragma unroll
+    for (int i = 0; i < n; i++) th[i] = 0;
+#pragma unroll
+    for (int i = 0; i < m; i++) d0[i] = 0;
+    if (act) {
+        double tt[n], lu[m], Gamk[n * m];
+        if (k >= 1) {
+            const double* pg = K.PGk(k);
+#pragma unroll
+            for (int i = 0; i < n; i++)
+#pragma unroll
+                for (int j = 0; j < m; j++) Gamk[i * m + j] = T::Gnz(i, j) ? pg[i * NZ + n + j] : 0.0;
+        } else {
+            Dyn<MODEL>::B(K.P.mp, Gamk);
+#pragma unroll
+            for (int i = 0; i < n * m; i++) Gamk[i] *= hdt;
+        }
+#pragma unroll
+        for (int i = 0; i < n; i++) tt[i] = K.pv[k * n + i];   // pt_k = p_k + r_k
+#pragma unroll
+        for (int i = 0; i < m; i++) {
+            double s = K.qu[k * m + i];
+#pragma unroll
+            for (int l = 0; l < n; l++) if (T::Gnz(l, i)) s += Gamk[l * m + i] * tt[l];
+            lu[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < m; i++) {
+            double s = 0;
+#pragma unroll
+            for (int l = 0; l < m; l++) s += K.KD[(size_t)k * R::SKD + R::oS + i * m + l] * lu[l];
+            d0[i] = s;
+        }
+        // theta_j = sum_k Pi_k^T c_k - D_k^T lu_k  (+ C M rd_{N-1} - rg at the last knot)
+#pragma unroll
+        for (int j = 0; j < n; j++) {
+            double s = K.nun[k * n + j];   // Pi_k^T c_k from the factor sweep (nun is free until the corrector's costates)
+#pragma unroll
+            for (int i = 0; i < m; i++) s -= K.KD[(size_t)k * R::SKD + R::oD + i * n + j] * lu[i];
+            if (k == N - 1 && K.is_goal(j)) {
+                const double* pg = K.PGk(k);
+#pragma unroll
+                for (int i = 0; i < n; i++) s += 0.5 * (pg[j * NZ + i] + (i == j ? 1.0 : 0.0)) * K.rd[k * n + i];
+                s -= K.goal_lo[j] - K.Xw[k * n + j];
+            }
+            th[j] = s;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < n; j++) th[j] = (K.goalmask != 0) ? block_reduce(th[j], OpSum(), red) : 0.0;
+    if (k == 0) {
+#pragma unroll
+        for (int j = 0; j < n; j++) {
+            double s = 0;
+#pragma unroll
+            for (int l = 0; l < n; l++) s += K.sP[j * n + l] * th[l];
+            mugn[j] = K.is_goal(j) ? s : 0.0;
+        }
+    }
+    K.sync();
+    if (act) {  // d_k = d0 + D_k mu_g ; ct_k = c_k - Gam_k d_k
+        double dk[m];
+#pragma unroll
+        for (int i = 0; i < m; i++) {
+            double s = d0[i];
+#pragma unroll
+            for (int j = 0; j < n; j++) s += K.KD[(size_t)k * R::SKD + R::oD + i * n + j] * mugn[j];
+            dk[i] = s;
+            K.dv[k * m + i] = s;
+        }
+        double Gamk[n * m];
+        if (k >= 1) {
+            const double* pg = K.PGk(k);
+#pragma unroll
+            for (int i = 0; i < n; i++)
+#pragma unroll
+                for (int j = 0; j < m; j++) Gamk[i * m + j] = T::Gnz(i, j) ? pg[i * NZ + n + j] : 0.0;
+        } else {
+            Dyn<MODEL>::B(K.P.mp, Gamk);
+#pragma unroll
+            for (int i = 0; i < n * m; i++) Gamk[i] *= hdt;
+        }
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            double s = K.cv[k * n + i];
+#pragma unroll
+            for (int l = 0; l < m; l++) if (T::Gnz(i, l)) s -= Gamk[i * m + l] * dk[l];
+            K.dY[k * n + i] = s;
+        }
+    }
+    K.sync();
+}
+template <int MODEL, class BLK> __device__ __noinline__ void mid_phase_call(BLK K, int k, bool act, double hdt, double* red,
+                                                                            double* mugn) {
+    mid_phase<MODEL>(K, k, act, hdt, red, mugn);
+}
+
 // ---- the interior point method ---------------------------------------------------------------------
 // Register discipline: nothing per-thread stays live across a sequential sweep.  Every stage-parallel block
 // re-reads the iterate (Xw/Uw), the linearisation point (Xp/Up) and the stage matrices it needs from LDS / L2
@@ -1441,99 +1548,8 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             backward_sweep<MODEL>(K);
             pf.tick(PF_BACK);
             GUSTO_REFRESH_K();
-            // feed-forward d0 = S^-1 lu and the goal multiplier
-            double th[n], d0[m];
-#pragma unroll
-            for (int i = 0; i < n; i++) th[i] = 0;
-#pragma unroll
-            for (int i = 0; i < m; i++) d0[i] = 0;
-            if (act) {
-                double tt[n], lu[m], Gamk[n * m];
-                if (k >= 1) {
-                    const double* pg = K.PGk(k);
-#pragma unroll
-                    for (int i = 0; i < n; i++)
-#pragma unroll
-                        for (int j = 0; j < m; j++) Gamk[i * m + j] = T::Gnz(i, j) ? pg[i * NZ + n + j] : 0.0;
-                } else {
-                    Dyn<MODEL>::B(K.P.mp, Gamk);
-#pragma unroll
-                    for (int i = 0; i < n * m; i++) Gamk[i] *= hdt;
-                }
-#pragma unroll
-                for (int i = 0; i < n; i++) tt[i] = K.pv[k * n + i];   // pt_k = p_k + r_k
-#pragma unroll
-                for (int i = 0; i < m; i++) {
-                    double s = K.qu[k * m + i];
-#pragma unroll
-                    for (int l = 0; l < n; l++) if (T::Gnz(l, i)) s += Gamk[l * m + i] * tt[l];
-                    lu[i] = s;
-                }
-#pragma unroll
-                for (int i = 0; i < m; i++) {
-                    double s = 0;
-#pragma unroll
-                    for (int l = 0; l < m; l++) s += K.KD[(size_t)k * R::SKD + R::oS + i * m + l] * lu[l];
-                    d0[i] = s;
-                }
-                // theta_j = sum_k Pi_k^T c_k - D_k^T lu_k  (+ C M rd_{N-1} - rg at the last knot)
-#pragma unroll
-                for (int j = 0; j < n; j++) {
-                    double s = K.nun[k * n + j];   // Pi_k^T c_k from the factor sweep (nun is free until the corrector's costates)
-#pragma unroll
-                    for (int i = 0; i < m; i++) s -= K.KD[(size_t)k * R::SKD + R::oD + i * n + j] * lu[i];
-                    if (k == N - 1 && K.is_goal(j)) {
-                        const double* pg = K.PGk(k);
-#pragma unroll
-                        for (int i = 0; i < n; i++) s += 0.5 * (pg[j * NZ + i] + (i == j ? 1.0 : 0.0)) * K.rd[k * n + i];
-                        s -= K.goal_lo[j] - K.Xw[k * n + j];
-                    }
-                    th[j] = s;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < n; j++) th[j] = (K.goalmask != 0) ? block_reduce(th[j], OpSum(), red) : 0.0;
-            if (k == 0) {
-#pragma unroll
-                for (int j = 0; j < n; j++) {
-                    double s = 0;
-#pragma unroll
-                    for (int l = 0; l < n; l++) s += K.sP[j * n + l] * th[l];
-                    mugn[j] = K.is_goal(j) ? s : 0.0;
-                }
-            }
-            K.sync();
-            if (act) {  // d_k = d0 + D_k mu_g ; ct_k = c_k - Gam_k d_k
-                double dk[m];
-#pragma unroll
-                for (int i = 0; i < m; i++) {
-                    double s = d0[i];
-#pragma unroll
-                    for (int j = 0; j < n; j++) s += K.KD[(size_t)k * R::SKD + R::oD + i * n + j] * mugn[j];
-                    dk[i] = s;
-                    K.dv[k * m + i] = s;
-                }
-                double Gamk[n * m];
-                if (k >= 1) {
-                    const double* pg = K.PGk(k);
-#pragma unroll
-                    for (int i = 0; i < n; i++)
-#pragma unroll
-                        for (int j = 0; j < m; j++) Gamk[i * m + j] = T::Gnz(i, j) ? pg[i * NZ + n + j] : 0.0;
-                } else {
-                    Dyn<MODEL>::B(K.P.mp, Gamk);
-#pragma unroll
-                    for (int i = 0; i < n * m; i++) Gamk[i] *= hdt;
-                }
-#pragma unroll
-                for (int i = 0; i < n; i++) {
-                    double s = K.cv[k * n + i];
-#pragma unroll
-                    for (int l = 0; l < m; l++) if (T::Gnz(i, l)) s -= Gamk[i * m + l] * dk[l];
-                    K.dY[k * n + i] = s;
-                }
-            }
-            K.sync();
+            if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL>(K, k, act, hdt, red, mugn);
+            else mid_phase<MODEL>(K, k, act, hdt, red, mugn);
             pf.tick(PF_MID);
             forward_sweep<MODEL>(K);
             pf.tick(PF_FWD);
