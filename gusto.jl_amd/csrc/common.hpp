@@ -69,7 +69,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3> {
 };
 template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr int n = 13, m = 6, WS = 3, NFIX = 5, NHU = 2;
-    static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
+    static constexpr bool SWEEP_CALL = true ;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
