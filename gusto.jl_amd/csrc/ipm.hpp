@@ -1194,6 +1194,94 @@ template <int MODEL, class BLK> __device__ __noinline__ void mid_phase_call(BLK 
     mid_phase<MODEL>(K, k, act, hdt, red, mugn);
 }
 
+// The phase after the forward sweep of a right-hand side: primal step of this knot, the new costates, row steps and
+// the fraction to the boundary (before the workgroup reductions).  A function of its own for MT::SWEEP_CALL models.
+struct StepOut { double amax, c0, c1, c2; };
+template <int MODEL, class BLK>
+GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int k, bool act, int pass, int ncomp, double hdt,
+                      double tau, double mu_t, const double* mugn, const double* gxs) {
+    using T = MT<MODEL>;
+    using R = Rec<MODEL>;
+    constexpr int n = T::n, m = T::m;
+    const int N = K.N;
+    double l_amax = 1.0, l_c0 = 0, l_c1 = 0, l_c2 = 0;
+    if (act) {
+        double dxs[n], dus[m], dyp[n];
+#pragma unroll
+        for (int i = 0; i < n; i++) { dyp[i] = (k >= 1) ? K.dY[(k - 1) * n + i] : 0.0; dxs[i] = 0; }
+#pragma unroll
+        for (int i = 0; i < m; i++) {
+            double s = -K.dv[k * m + i];
+#pragma unroll
+            for (int l = 0; l < n; l++) s -= K.KD[(size_t)k * R::SKD + R::oK + i * n + l] * dyp[l];
+            dus[i] = s;
+            K.dUs[k * m + i] = s;
+        }
+        if (k >= 1) {
+            double a[n], Bd[n * m], Mk[n * n], Gamk[n * m];
+            Dyn<MODEL>::B(K.P.mp, Bd);
+            load_M_Gam(K, k, Mk, Gamk);
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                double s = dyp[i] + K.rd[k * n + i];
+#pragma unroll
+                for (int l = 0; l < m; l++) if (T::Bnz(i, l)) s += (hdt * Bd[i * m + l]) * dus[l];
+                a[i] = s;
+            }
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                double s = 0;
+#pragma unroll
+                for (int l = 0; l < n; l++) if (T::Mnz(i, l)) s += Mk[i * n + l] * a[l];
+                dxs[i] = s;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < n; i++) K.dXs[k * n + i] = dxs[i];
+        if (k + 1 < N && (pass == 1 || ncomp == 0)) {  // nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                double s = K.pv[k * n + i] - K.rv[k * n + i];
+#pragma unroll
+                for (int l = 0; l < n; l++)
+                    s += K.Paft[(size_t)k * R::SNN + i * n + l] * K.dY[k * n + l] +
+                         K.Piaft[(size_t)k * R::SNN + i * n + l] * mugn[l];
+                K.nun[(k + 1) * n + i] = s;
+            }
+        }
+        double xs[n], us[m];
+#pragma unroll
+        for (int i = 0; i < n; i++) xs[i] = K.Xw[k * n + i];
+#pragma unroll
+        for (int i = 0; i < m; i++) us[i] = K.Uw[k * m + i];
+        OpStep op{rs, dxs, dus, pass, mu_t, tau};
+        visit_rows<MODEL>(ctx, xs, us, op);
+        l_amax = op.amax.value(); l_c0 = op.c0; l_c1 = op.c1; l_c2 = op.c2;
+    }
+    K.sync();
+    if (k == 0 && (pass == 1 || ncomp == 0)) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0
+        double Ad[n * n], x0[n], u0[m];
+#pragma unroll
+        for (int i = 0; i < n; i++) x0[i] = K.Xp[i];
+#pragma unroll
+        for (int i = 0; i < m; i++) u0[i] = K.Up[i];
+        Dyn<MODEL>::A(K.P.mp, x0, u0, Ad);
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            double s = gxs[i] + K.nun[n + i];
+#pragma unroll
+            for (int j = 0; j < n; j++) if (T::Anz(j, i)) s += hdt * Ad[j * n + i] * K.nun[n + j];
+            K.nun[i] = -s;
+        }
+    }
+    return StepOut{l_amax, l_c0, l_c1, l_c2};
+}
+template <int MODEL, class BLK>
+__device__ __noinline__ StepOut step_phase_call(BLK K, RowCtx<MODEL> ctx, RowState rs, int k, bool act, int pass, int ncomp,
+                                                double hdt, double tau, double mu_t, const double* mugn, const double* gxs) {
+    return step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
+}
+
 // ---- the interior point method ---------------------------------------------------------------------
 // Register discipline: nothing per-thread stays live across a sequential sweep.  Every stage-parallel block
 // re-reads the iterate (Xw/Uw), the linearisation point (Xp/Up) and the stage matrices it needs from LDS / L2
@@ -1556,73 +1644,10 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             GUSTO_REFRESH_K();
             // primal step of this knot, the new costates, row steps + fraction to the boundary
             const double tau = pass ? fmax(0.995, 1.0 - mu) : 1.0;
-            double l_amax = 1.0, l_c0 = 0, l_c1 = 0, l_c2 = 0;
-            if (act) {
-                double dxs[n], dus[m], dyp[n];
-#pragma unroll
-                for (int i = 0; i < n; i++) { dyp[i] = (k >= 1) ? K.dY[(k - 1) * n + i] : 0.0; dxs[i] = 0; }
-#pragma unroll
-                for (int i = 0; i < m; i++) {
-                    double s = -K.dv[k * m + i];
-#pragma unroll
-                    for (int l = 0; l < n; l++) s -= K.KD[(size_t)k * R::SKD + R::oK + i * n + l] * dyp[l];
-                    dus[i] = s;
-                    K.dUs[k * m + i] = s;
-                }
-                if (k >= 1) {
-                    double a[n], Bd[n * m], Mk[n * n], Gamk[n * m];
-                    Dyn<MODEL>::B(K.P.mp, Bd);
-                    load_M_Gam(K, k, Mk, Gamk);
-#pragma unroll
-                    for (int i = 0; i < n; i++) {
-                        double s = dyp[i] + K.rd[k * n + i];
-#pragma unroll
-                        for (int l = 0; l < m; l++) if (T::Bnz(i, l)) s += (hdt * Bd[i * m + l]) * dus[l];
-                        a[i] = s;
-                    }
-#pragma unroll
-                    for (int i = 0; i < n; i++) {
-                        double s = 0;
-#pragma unroll
-                        for (int l = 0; l < n; l++) if (T::Mnz(i, l)) s += Mk[i * n + l] * a[l];
-                        dxs[i] = s;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < n; i++) K.dXs[k * n + i] = dxs[i];
-                if (k + 1 < N && (pass == 1 || ncomp == 0)) {  // nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g
-#pragma unroll
-                    for (int i = 0; i < n; i++) {
-                        double s = K.pv[k * n + i] - K.rv[k * n + i];
-#pragma unroll
-                        for (int l = 0; l < n; l++)
-                            s += K.Paft[(size_t)k * R::SNN + i * n + l] * K.dY[k * n + l] +
-                                 K.Piaft[(size_t)k * R::SNN + i * n + l] * mugn[l];
-                        K.nun[(k + 1) * n + i] = s;
-                    }
-                }
-                double xs[n], us[m];
-                load_iter(xs, us);
-                OpStep op{rs, dxs, dus, pass, mu_t, tau};
-                visit_rows<MODEL>(ctx, xs, us, op);
-                l_amax = op.amax.value(); l_c0 = op.c0; l_c1 = op.c1; l_c2 = op.c2;
-            }
-            K.sync();
-            if (k == 0 && (pass == 1 || ncomp == 0)) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0
-                double Ad[n * n], x0[n], u0[m];
-#pragma unroll
-                for (int i = 0; i < n; i++) x0[i] = K.Xp[i];
-#pragma unroll
-                for (int i = 0; i < m; i++) u0[i] = K.Up[i];
-                Dyn<MODEL>::A(K.P.mp, x0, u0, Ad);
-#pragma unroll
-                for (int i = 0; i < n; i++) {
-                    double s = gxs[i] + K.nun[n + i];
-#pragma unroll
-                    for (int j = 0; j < n; j++) if (T::Anz(j, i)) s += hdt * Ad[j * n + i] * K.nun[n + j];
-                    K.nun[i] = -s;
-                }
-            }
+            StepOut so;
+            if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
+            else so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
+            const double l_amax = so.amax, l_c0 = so.c0, l_c1 = so.c1, l_c2 = so.c2;
             const double a_max = block_reduce(l_amax, OpMin(), red);
             alpha = a_max;
             if (pass == 0) {
