@@ -1282,6 +1282,191 @@ __device__ __noinline__ StepOut step_phase_call(BLK K, RowCtx<MODEL> ctx, RowSta
     return step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
 }
 
+// The residual phase of an interior point iteration: residuals, condensed Hessian blocks, dual residual, the predictor's
+// row sums and the LQR stage cost QQ_k of this knot (before the workgroup reductions).  A function of its own for
+// MT::SWEEP_CALL models.
+struct ResidOut { double resp, resd, comp, numax; };
+template <int MODEL, class BLK>
+GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int k, bool act, double hdt, double wk,
+                        double alpha_prev, const double* mug) {
+    using T = MT<MODEL>;
+    using R = Rec<MODEL>;
+    constexpr int n = T::n, m = T::m, NZ = n + m, NHX = n * (n + 1) / 2, NHU = m * (m + 1) / 2, NQ = NZ * (NZ + 1) / 2;
+    const int N = K.N;
+    double l_resp = 0, l_resd = 0, l_comp = 0, l_numax = 0;
+    if (act) {
+        double xs[n], us[m], Hx[NHX], Hu[NHU], rdx[n], rdu[m], rdk[n], Ad[n * n], Bd[n * m];
+#pragma unroll
+        for (int i = 0; i < n; i++) xs[i] = K.Xw[k * n + i];
+#pragma unroll
+        for (int i = 0; i < m; i++) us[i] = K.Uw[k * m + i];
+#pragma unroll
+        for (int i = 0; i < NHX; i++) Hx[i] = 0;
+#pragma unroll
+        for (int i = 0; i < NHU; i++) Hu[i] = 0;
+#pragma unroll
+        for (int i = 0; i < n; i++) { rdx[i] = 0; rdk[i] = 0; }
+#pragma unroll
+        for (int i = 0; i < m; i++) rdu[i] = 0;
+        {
+            double xpk[n], upk[m];
+#pragma unroll
+            for (int i = 0; i < n; i++) xpk[i] = K.Xp[k * n + i];
+#pragma unroll
+            for (int i = 0; i < m; i++) upk[i] = K.Up[k * m + i];
+            Dyn<MODEL>::A(K.P.mp, xpk, upk, Ad);
+            Dyn<MODEL>::B(K.P.mp, Bd);
+        }
+        if (k >= 1) {
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                rdk[i] = K.Xw[(k - 1) * n + i] - xs[i] + hdt * (K.pv[(k - 1) * n + i] + K.pv[k * n + i]);
+                l_resp = nanmax(l_resp, fabs(rdk[i]));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < n; i++) K.rd[k * n + i] = rdk[i];
+        double gx0[n], gu0[m];
+#pragma unroll
+        for (int i = 0; i < n; i++) gx0[i] = 0;
+#pragma unroll
+        for (int i = 0; i < m; i++) gu0[i] = 0;
+        // (small models only: the 12/13-state kernels are far beyond the register file already -- 5 KB of scratch
+        // per lane and > 1200 spilled SGPRs -- and more live values there have produced wrong code)
+        constexpr int NP = (n <= 8) ? T::NFIX + T::NHU : 0;
+        RowPre<NP> pre;
+        if constexpr (NP > 0) {
+            const int slot_u = T::NFIX + K.P.n_obs + 2 * n;
+            const bool upd = alpha_prev != 0.0;
+            pre.load(rs, T::NFIX, slot_u, [&](int var) {
+                return var == RS_T || var == RS_LAM || var == RS_S || var == RS_LAMB ||
+                       (upd && (var == RS_DT || var == RS_DL || var == RS_DS));
+            });
+        }
+        OpResidHess<n, m, NP> op{rs, Hx, Hu, rdx, rdu, gx0, gu0, alpha_prev, &pre};
+        visit_rows<MODEL>(ctx, xs, us, op);
+        // row part of the predictor right-hand side, parked in the (currently free) step arrays
+#pragma unroll
+        for (int i = 0; i < n; i++) K.dXs[k * n + i] = gx0[i];
+#pragma unroll
+        for (int i = 0; i < m; i++) K.dUs[k * m + i] = gu0[i];
+        l_comp = op.comp;
+        l_resp = nanmax(l_resp, op.maxrp);
+#pragma unroll
+        for (int i = 0; i < m; i++) { Hu[sidx(i, i, m)] += 2 * wk; rdu[i] += 2 * wk * us[i]; }
+        // + E^T nu: F_k^T nu_{k+1} - G_k^T nu_k on x, b_k^T (nu_{k+1} + nu_k) on u
+        {
+            double vs[n], vd[n];
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                const double n1 = (k + 1 < N) ? K.nu[(k + 1) * n + i] : 0.0, n0 = (k >= 1) ? K.nu[k * n + i] : 0.0;
+                vs[i] = n1 + n0; vd[i] = n1 - n0;
+                l_numax = fmax(l_numax, fabs(K.nu[k * n + i]));
+            }
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                double s = vd[i];
+#pragma unroll
+                for (int j = 0; j < n; j++) if (T::Anz(j, i)) s += hdt * Ad[j * n + i] * vs[j];
+                rdx[i] += s;
+            }
+#pragma unroll
+            for (int i = 0; i < m; i++) {
+                double s = 0;
+#pragma unroll
+                for (int j = 0; j < n; j++) if (T::Bnz(j, i)) s += hdt * Bd[j * m + i] * vs[j];
+                rdu[i] += s;
+            }
+        }
+        if (k == N - 1) {
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                if (K.is_goal(i)) {
+                    rdx[i] += mug[i];
+                    l_resp = nanmax(l_resp, fabs(K.goal_lo[i] - xs[i]));
+                }
+            }
+        }
+        if (k >= 1) {
+#pragma unroll
+            for (int i = 0; i < n; i++) l_resd = nanmax(l_resd, fabs(rdx[i]));
+        }
+#pragma unroll
+        for (int i = 0; i < m; i++) l_resd = nanmax(l_resd, fabs(rdu[i]));
+
+        // (3) QQ = [Qt, Qt b; ., Hu + b^T Qt b], Qt = M^T Hx M (built even on the last trip: cheap)
+        double* qqg = K.QQ + (size_t)k * R::SQQ;
+        if (k >= 1) {
+            double Mk[n * n], Qt[NHX], Qb[n * m];
+            {
+                double Gamk[n * m];
+                load_M_Gam(K, k, Mk, Gamk);
+            }
+#pragma unroll
+            for (int j = 0; j < n; j++) {  // column j of Hx M, then column j of the upper triangle of M^T (Hx M)
+                double tcol[n];
+#pragma unroll
+                for (int i = 0; i < n; i++) {
+                    double s = 0;
+#pragma unroll
+                    for (int l = 0; l < n; l++) if (T::Mnz(l, j)) s += Hx[sidx(i, l, n)] * Mk[l * n + j];
+                    tcol[i] = s;
+                }
+#pragma unroll
+                for (int i = 0; i <= j; i++) {
+                    double s = 0;
+#pragma unroll
+                    for (int l = 0; l < n; l++) if (T::Mnz(l, i)) s += Mk[l * n + i] * tcol[l];
+                    Qt[sidx(i, j, n)] = s;
+                    qqg[sidx(i, j, NZ)] = s;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < n; i++)
+#pragma unroll
+                for (int j = 0; j < m; j++) {
+                    double s = 0;
+#pragma unroll
+                    for (int l = 0; l < n; l++) if (T::Bnz(l, j)) s += Qt[sidx(i, l, n)] * (hdt * Bd[l * m + j]);
+                    Qb[i * m + j] = s;
+                    qqg[sidx(i, n + j, NZ)] = s;
+                }
+#pragma unroll
+            for (int i = 0; i < m; i++)
+#pragma unroll
+                for (int j = i; j < m; j++) {
+                    double s = Hu[sidx(i, j, m)];
+#pragma unroll
+                    for (int l = 0; l < n; l++) if (T::Bnz(l, i)) s += (hdt * Bd[l * m + i]) * Qb[l * m + j];
+                    qqg[sidx(n + i, n + j, NZ)] = s;
+                }
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                double s = 0, c = -rdk[i];
+#pragma unroll
+                for (int l = 0; l < n; l++) { s += Qt[sidx(i, l, n)] * rdk[l]; if (T::Mnz(i, l)) c += 2.0 * Mk[i * n + l] * rdk[l]; }
+                K.qrd[k * n + i] = s;
+                K.cv[k * n + i] = c;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NQ; e++) qqg[e] = 0.0;
+#pragma unroll
+            for (int i = 0; i < m; i++)
+#pragma unroll
+                for (int j = i; j < m; j++) qqg[sidx(n + i, n + j, NZ)] = Hu[sidx(i, j, m)];
+#pragma unroll
+            for (int i = 0; i < n; i++) { K.qrd[i] = 0; K.cv[i] = 0; }
+        }
+    }
+    return ResidOut{l_resp, l_resd, l_comp, l_numax};
+}
+template <int MODEL, class BLK>
+__device__ __noinline__ ResidOut resid_phase_call(BLK K, RowCtx<MODEL> ctx, RowState rs, int k, bool act, double hdt, double wk,
+                                                  double alpha_prev, const double* mug) {
+    return resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
+}
+
 // ---- the interior point method ---------------------------------------------------------------------
 // Register discipline: nothing per-thread stays live across a sequential sweep.  Every stage-parallel block
 // re-reads the iterate (Xw/Uw), the linearisation point (Xp/Up) and the stage matrices it needs from LDS / L2
@@ -1371,169 +1556,11 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         }
         K.sync();
         // (2) residuals, condensed Hessian blocks, dual residual; (3) the LQR stage cost of this knot
-        double l_resp = 0, l_resd = 0, l_comp = 0, l_numax = 0;
-        if (act) {
-            double xs[n], us[m], Hx[NHX], Hu[NHU], rdx[n], rdu[m], rdk[n], Ad[n * n], Bd[n * m];
-            load_iter(xs, us);
-#pragma unroll
-            for (int i = 0; i < NHX; i++) Hx[i] = 0;
-#pragma unroll
-            for (int i = 0; i < NHU; i++) Hu[i] = 0;
-#pragma unroll
-            for (int i = 0; i < n; i++) { rdx[i] = 0; rdk[i] = 0; }
-#pragma unroll
-            for (int i = 0; i < m; i++) rdu[i] = 0;
-            {
-                double xpk[n], upk[m];
-#pragma unroll
-                for (int i = 0; i < n; i++) xpk[i] = K.Xp[k * n + i];
-#pragma unroll
-                for (int i = 0; i < m; i++) upk[i] = K.Up[k * m + i];
-                Dyn<MODEL>::A(K.P.mp, xpk, upk, Ad);
-                Dyn<MODEL>::B(K.P.mp, Bd);
-            }
-            if (k >= 1) {
-#pragma unroll
-                for (int i = 0; i < n; i++) {
-                    rdk[i] = K.Xw[(k - 1) * n + i] - xs[i] + hdt * (K.pv[(k - 1) * n + i] + K.pv[k * n + i]);
-                    l_resp = nanmax(l_resp, fabs(rdk[i]));
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < n; i++) K.rd[k * n + i] = rdk[i];
-            double gx0[n], gu0[m];
-#pragma unroll
-            for (int i = 0; i < n; i++) gx0[i] = 0;
-#pragma unroll
-            for (int i = 0; i < m; i++) gu0[i] = 0;
-            // (small models only: the 12/13-state kernels are far beyond the register file already -- 5 KB of scratch
-            // per lane and > 1200 spilled SGPRs -- and more live values there have produced wrong code)
-            constexpr int NP = (n <= 8) ? T::NFIX + T::NHU : 0;
-            RowPre<NP> pre;
-            if constexpr (NP > 0) {
-                const int slot_u = T::NFIX + K.P.n_obs + 2 * n;
-                const bool upd = alpha_prev != 0.0;
-                pre.load(rs, T::NFIX, slot_u, [&](int var) {
-                    return var == RS_T || var == RS_LAM || var == RS_S || var == RS_LAMB ||
-                           (upd && (var == RS_DT || var == RS_DL || var == RS_DS));
-                });
-            }
-            OpResidHess<n, m, NP> op{rs, Hx, Hu, rdx, rdu, gx0, gu0, alpha_prev, &pre};
-            visit_rows<MODEL>(ctx, xs, us, op);
-            // row part of the predictor right-hand side, parked in the (currently free) step arrays
-#pragma unroll
-            for (int i = 0; i < n; i++) K.dXs[k * n + i] = gx0[i];
-#pragma unroll
-            for (int i = 0; i < m; i++) K.dUs[k * m + i] = gu0[i];
-            l_comp = op.comp;
-            l_resp = nanmax(l_resp, op.maxrp);
-#pragma unroll
-            for (int i = 0; i < m; i++) { Hu[sidx(i, i, m)] += 2 * wk; rdu[i] += 2 * wk * us[i]; }
-            // + E^T nu: F_k^T nu_{k+1} - G_k^T nu_k on x, b_k^T (nu_{k+1} + nu_k) on u
-            {
-                double vs[n], vd[n];
-#pragma unroll
-                for (int i = 0; i < n; i++) {
-                    const double n1 = (k + 1 < N) ? K.nu[(k + 1) * n + i] : 0.0, n0 = (k >= 1) ? K.nu[k * n + i] : 0.0;
-                    vs[i] = n1 + n0; vd[i] = n1 - n0;
-                    l_numax = fmax(l_numax, fabs(K.nu[k * n + i]));
-                }
-#pragma unroll
-                for (int i = 0; i < n; i++) {
-                    double s = vd[i];
-#pragma unroll
-                    for (int j = 0; j < n; j++) if (T::Anz(j, i)) s += hdt * Ad[j * n + i] * vs[j];
-                    rdx[i] += s;
-                }
-#pragma unroll
-                for (int i = 0; i < m; i++) {
-                    double s = 0;
-#pragma unroll
-                    for (int j = 0; j < n; j++) if (T::Bnz(j, i)) s += hdt * Bd[j * m + i] * vs[j];
-                    rdu[i] += s;
-                }
-            }
-            if (k == N - 1) {
-#pragma unroll
-                for (int i = 0; i < n; i++) {
-                    if (K.is_goal(i)) {
-                        rdx[i] += mug[i];
-                        l_resp = nanmax(l_resp, fabs(K.goal_lo[i] - xs[i]));
-                    }
-                }
-            }
-            if (k >= 1) {
-#pragma unroll
-                for (int i = 0; i < n; i++) l_resd = nanmax(l_resd, fabs(rdx[i]));
-            }
-#pragma unroll
-            for (int i = 0; i < m; i++) l_resd = nanmax(l_resd, fabs(rdu[i]));
-
-            // (3) QQ = [Qt, Qt b; ., Hu + b^T Qt b], Qt = M^T Hx M (built even on the last trip: cheap)
-            double* qqg = K.QQ + (size_t)k * R::SQQ;
-            if (k >= 1) {
-                double Mk[n * n], Qt[NHX], Qb[n * m];
-                {
-                    double Gamk[n * m];
-                    load_M_Gam(K, k, Mk, Gamk);
-                }
-#pragma unroll
-                for (int j = 0; j < n; j++) {  // column j of Hx M, then column j of the upper triangle of M^T (Hx M)
-                    double tcol[n];
-#pragma unroll
-                    for (int i = 0; i < n; i++) {
-                        double s = 0;
-#pragma unroll
-                        for (int l = 0; l < n; l++) if (T::Mnz(l, j)) s += Hx[sidx(i, l, n)] * Mk[l * n + j];
-                        tcol[i] = s;
-                    }
-#pragma unroll
-                    for (int i = 0; i <= j; i++) {
-                        double s = 0;
-#pragma unroll
-                        for (int l = 0; l < n; l++) if (T::Mnz(l, i)) s += Mk[l * n + i] * tcol[l];
-                        Qt[sidx(i, j, n)] = s;
-                        qqg[sidx(i, j, NZ)] = s;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < n; i++)
-#pragma unroll
-                    for (int j = 0; j < m; j++) {
-                        double s = 0;
-#pragma unroll
-                        for (int l = 0; l < n; l++) if (T::Bnz(l, j)) s += Qt[sidx(i, l, n)] * (hdt * Bd[l * m + j]);
-                        Qb[i * m + j] = s;
-                        qqg[sidx(i, n + j, NZ)] = s;
-                    }
-#pragma unroll
-                for (int i = 0; i < m; i++)
-#pragma unroll
-                    for (int j = i; j < m; j++) {
-                        double s = Hu[sidx(i, j, m)];
-#pragma unroll
-                        for (int l = 0; l < n; l++) if (T::Bnz(l, i)) s += (hdt * Bd[l * m + i]) * Qb[l * m + j];
-                        qqg[sidx(n + i, n + j, NZ)] = s;
-                    }
-#pragma unroll
-                for (int i = 0; i < n; i++) {
-                    double s = 0, c = -rdk[i];
-#pragma unroll
-                    for (int l = 0; l < n; l++) { s += Qt[sidx(i, l, n)] * rdk[l]; if (T::Mnz(i, l)) c += 2.0 * Mk[i * n + l] * rdk[l]; }
-                    K.qrd[k * n + i] = s;
-                    K.cv[k * n + i] = c;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < NQ; e++) qqg[e] = 0.0;
-#pragma unroll
-                for (int i = 0; i < m; i++)
-#pragma unroll
-                    for (int j = i; j < m; j++) qqg[sidx(n + i, n + j, NZ)] = Hu[sidx(i, j, m)];
-#pragma unroll
-                for (int i = 0; i < n; i++) { K.qrd[i] = 0; K.cv[i] = 0; }
-            }
-        }
+        ResidOut ro;
+        // (inlined for every model: as a call it was 2 % slower for astrobeeSE3 -- this phase alone wants more than the
+        // register file, isolating it does not help)
+        ro = resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
+        const double l_resp = ro.resp, l_resd = ro.resd, l_comp = ro.comp, l_numax = ro.numax;
         res_p = block_reduce(l_resp, OpNanMax(), red);
         res_d = block_reduce(l_resd, OpNanMax(), red);
         const double comp = block_reduce(l_comp, OpSum(), red);
