@@ -22,9 +22,14 @@ GD bool row_is_hard(int kind) { return kind == ROW_HARD || kind == ROW_HARD_EQ; 
 constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5, RS_DS = 6, RS_KA = 7, RS_KB = 8,
               RS_NVAR = 9;
 
+#ifndef GUSTO_WAVES_PER_EU
+#define GUSTO_WAVES_PER_EU 1
+#endif
+
 template <int MODEL> struct MT;
 template <> struct MT<GUSTO_FREEFLYER_SE2> {
     static constexpr int n = 6, m = 3, WS = 2, NFIX = 3, NHU = 2;
+    static constexpr int WAVES_PER_EU = GUSTO_WAVES_PER_EU;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool LTI = true, HAS_OBS = true;
     // Double integrator (freeflyer_se2.jl:121,178-179: A = [0 I; 0 0], B = [0; diag]): Phi = I + dt A and
@@ -43,6 +48,7 @@ template <> struct MT<GUSTO_FREEFLYER_SE2> {
 };
 template <> struct MT<GUSTO_DUBINS_CAR> {
     static constexpr int n = 3, m = 1, WS = 2, NFIX = 6, NHU = 2;
+    static constexpr int WAVES_PER_EU = 2;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool LTI = false, HAS_OBS = false;
     static constexpr bool PG2 = false;
@@ -55,6 +61,7 @@ template <> struct MT<GUSTO_DUBINS_CAR> {
 };
 template <> struct MT<GUSTO_ASTROBEE_SE3> {
     static constexpr int n = 12, m = 6, WS = 3, NFIX = 3, NHU = 2;
+    static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
@@ -69,6 +76,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3> {
 };
 template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr int n = 13, m = 6, WS = 3, NFIX = 5, NHU = 2;
+    static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true ;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
@@ -144,7 +152,11 @@ template <int MODEL> struct LdsC {
     // One-wave problems of the small models also keep the closed-loop matrices Phicl_k (written once by the factor
     // sweep, read by the four vector sweeps of an iteration) in LDS, behind the vectors: [N][n*n].  4 problems per
     // CU are register-limited anyway, so up to 40 KB of LDS per problem are free.
+#ifdef GUSTO_NO_PHICL_LDS
+    static constexpr bool PHICL_LDS = false;
+#else
     static constexpr bool PHICL_LDS = n <= 8;
+#endif
 };
 struct LdsLayout {
     int total;

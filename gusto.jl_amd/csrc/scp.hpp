@@ -75,7 +75,7 @@ template <class BLK> GD void store_traj(BLK& K, const double* Xs, const double* 
     for (int e = K.tid; e < K.N * m; e += K.nt()) Ug[e] = Us[e];
 }
 
-template <int MODEL, bool ONEWAVE> __global__ void __launch_bounds__(ONEWAVE ? 64 : 256, GUSTO_WAVES_PER_EU)
+template <int MODEL, bool ONEWAVE> __global__ void __launch_bounds__(ONEWAVE ? 64 : 256, ONEWAVE ? MT<MODEL>::WAVES_PER_EU : 1)
 scp_kernel(const KParams P) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m;
