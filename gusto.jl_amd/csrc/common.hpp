@@ -137,14 +137,21 @@ template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
 
 // LDS layout, offsets in doubles.  The cooperative working set of the sweeps sits first at compile-time offsets
 // (so its addresses are instruction immediates, not SGPRs); the per-knot vectors follow, `vec(i)` = i-th vector.
-template <int MODEL> struct LdsC {
+// ONE = one wave per problem (N <= 64): no multi-wave sweep buffers (sK sD sW sV); time-varying models keep two
+// [Phi Gam] buffers (the knot-0 operand comes from block 0 of the global PG array, linearize()); the large models, whose
+// sweep forms T, then H, then Z, let T share the memory of Z, and their goal-system inverse borrows sHh as scratch.
+// That is what fits 3 problems of the 12/13-state models into the 160 KB of a CU.
+template <int MODEL, bool ONE> struct LdsC {
     using T = MT<MODEL>;
     static constexpr int n = T::n, m = T::m, NZ = n + m;
-    // (sK sD sW sV are used by the multi-wave sweeps only: one-wave problems start their vectors at vecs1w)
-    static constexpr int sP = 0, sPi = sP + n * n, sPG = sPi + n * n, sT = sPG + 3 * n * NZ, sHh = sT + n * NZ,
-                         sZ = sHh + NZ * NZ, sGd = sZ + NZ * n, misc = sGd + 2 * n * n, lut = misc + 64,
+    static constexpr bool BIG = n > 8;
+    static constexpr int NPGB = (ONE && !T::LTI) ? 2 : 3;
+    static constexpr int sP = 0, sPi = sP + n * n, sPG = sPi + n * n, sT0 = sPG + NPGB * n * NZ,
+                         sHh = sT0 + ((ONE && BIG) ? 0 : n * NZ), sZ = sHh + NZ * NZ, sT = (ONE && BIG) ? sZ : sT0,
+                         sGd = sZ + NZ * n, misc = sGd + ((ONE && BIG) ? 1 : 2) * n * n, lut = misc + 64,
                          vecs1w = lut + (NZ * (NZ + 1) / 2 + 1) / 2 + 1,
-                         sK = vecs1w, sD = sK + m * n, sW = sD + m * n, sV = sW + m * n, vecs = sV + m * n;
+                         sK = vecs1w, sD = sK + m * n, sW = sD + m * n, sV = sW + m * n, vecsmw = sV + m * n,
+                         vecs = ONE ? vecs1w : vecsmw;
     // per-knot vectors shared between lanes: n-vectors (Xw dY pv cv rv nu nun) then the m-vector Uw; vectors only
     // their own knot touches (rd qrd dXs | dUs qu dv) live in the per-problem global workspace, the linearisation
     // point (Xp, Up) is read from the problem's trajectory in HBM/L2
@@ -163,11 +170,12 @@ struct LdsLayout {
     int phicl;  // offset of the LDS copy of Phicl (doubles), -1 if it lives in the global workspace
 };
 template <int MODEL> inline LdsLayout make_lds_layout(int N) {
-    using C = LdsC<MODEL>;
+    using C1 = LdsC<MODEL, true>;
+    using CM = LdsC<MODEL, false>;
     LdsLayout L;
-    L.total = (N <= 64 ? C::vecs1w : C::vecs) + N * (C::NVN * C::n + C::NVM * C::m);
+    L.total = (N <= 64 ? C1::vecs : CM::vecs) + N * (C1::NVN * C1::n + C1::NVM * C1::m);
     L.phicl = -1;
-    if (C::PHICL_LDS && N <= 64) { L.phicl = L.total; L.total += N * C::n * C::n; }
+    if (C1::PHICL_LDS && N <= 64) { L.phicl = L.total; L.total += N * C1::n * C1::n; }
     return L;
 }
 

@@ -41,7 +41,7 @@ template <bool ONEWAVE> GD void blk_sync() {
 
 template <int MODEL, bool ONEWAVE> struct Blk {
     using T = MT<MODEL>;
-    using C = LdsC<MODEL>;
+    using C = LdsC<MODEL, ONEWAVE>;
     using R = Rec<MODEL>;
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr bool ONE = ONEWAVE;
@@ -68,7 +68,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         sP = lds + C::sP; sPi = lds + C::sPi; sPG = lds + C::sPG; sT = lds + C::sT; sHh = lds + C::sHh; sZ = lds + C::sZ;
         sK = lds + C::sK; sD = lds + C::sD; sW = lds + C::sW; sV = lds + C::sV; sGd = lds + C::sGd; misc = lds + C::misc;
         lut = reinterpret_cast<int*>(lds + C::lut);
-        double* v = lds + (ONEWAVE ? C::vecs1w : C::vecs);
+        double* v = lds + C::vecs;
         Xw = v; dY = v + N * n; pv = v + 2 * N * n; cv = v + 3 * N * n; rv = v + 4 * N * n; nu = v + 5 * N * n;
         nun = v + 6 * N * n;
         Uw = v + C::NVN * N * n;
@@ -186,16 +186,17 @@ template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
                 inv_gauss_jordan<n>(G, M);
             }
             double* pg = K.PG + (size_t)(T::LTI ? 0 : k) * n * NZ;
+            const bool knot0 = !T::LTI && k == 0;   // x_1 is pinned: the sweep's operand of knot 0 is [0 | b_0], b_0 = dt/2 B
 #pragma unroll
             for (int i = 0; i < n; i++) {
 #pragma unroll
-                for (int j = 0; j < n; j++) pg[i * NZ + j] = 2.0 * M[i * n + j] - (i == j ? 1.0 : 0.0);
+                for (int j = 0; j < n; j++) pg[i * NZ + j] = knot0 ? 0.0 : 2.0 * M[i * n + j] - (i == j ? 1.0 : 0.0);
 #pragma unroll
                 for (int j = 0; j < m; j++) {
                     double s = 0;
 #pragma unroll
                     for (int l = 0; l < n; l++) s += M[i * n + l] * (h * B[l * m + j]);
-                    pg[i * NZ + n + j] = 2.0 * s;
+                    pg[i * NZ + n + j] = knot0 ? h * B[i * m + j] : 2.0 * s;
                 }
             }
         }
@@ -499,7 +500,7 @@ template <class BLK> GD void forward_sweep_mw(BLK& K) {
 // (noinline) sweeps were measured and are slower on gfx950: the calls force ABI spills in the caller.
 template <int MODEL> struct SweepView {
     using T = MT<MODEL>;
-    using C = LdsC<MODEL>;
+    using C = LdsC<MODEL, true>;
     using R = Rec<MODEL>;
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr bool ONE = true;
@@ -538,7 +539,8 @@ template <int MODEL, class BLK> GD double* pg_buf(const BLK& K, int k) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int NPG = T::n * (T::n + T::m);
-    return K.sPG + (k == 0 ? 2 * NPG : (T::LTI ? 0 : (k & 1) * NPG));
+    if constexpr (T::LTI) return K.sPG + (k == 0 ? 2 * NPG : 0);
+    else return K.sPG + (k & 1) * NPG;
 }
 
 // Two LDS phases per knot (the dependency chain is P_k -> H -> P_{k-1}):
@@ -550,7 +552,7 @@ template <int MODEL, class BLK> GD double* pg_buf(const BLK& K, int k) {
 template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, Prof& pf) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
-    using C = LdsC<MODEL>;
+    using C = LdsC<MODEL, true>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n, NZN = NZ * n;
     constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64, RZ = (NZN + 63) / 64, RKD = R::SKD / 64;
     const int tid = K.tid, N = K.N;
@@ -563,7 +565,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
     for (int r = 0; r < RQ; r++) { const int e = tid + 64 * r, ij = (e < NQ) ? K.lut[e] : 0; hI[r] = ij >> 8; hJ[r] = ij & 255; }
 #pragma unroll
     for (int r = 0; r < RN; r++) { const int e = tid + 64 * r; nI[r] = (e < NN) ? e / n : 0; nJ[r] = (e < NN) ? e % n : 0; }
-    {   // knot-0 operands [0 | b_0] and the [Phi Gam] block of knot N-1
+    if constexpr (T::LTI) {   // knot-0 operands [0 | b_0] (third buffer) and the one [Phi Gam] block of an LTI model
         double B[n * m];
         Dyn<MODEL>::B(*K.mpp, B);
 #pragma unroll
@@ -575,8 +577,14 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
 #pragma unroll
                 for (int q = 0; q < n * m; q++) if (j >= n && q == i * m + (j - n)) v = 0.5 * K.dt * B[q];
                 K.sPG[2 * NPG + e] = v;
-                K.sPG[((T::LTI ? 0 : (N - 1)) & 1) * NPG + e] = K.PGk(N - 1)[e];
+                K.sPG[e] = K.PGk(N - 1)[e];
             }
+        }
+    } else {   // time-varying: block N-1 now, the others one knot ahead; block 0 of the global array IS [0 | b_0]
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const int e = tid + 64 * r;
+            if (e < NPG) K.sPG[((N - 1) & 1) * NPG + e] = K.PGk(N - 1)[e];
         }
     }
     double qq[RQ], pgn[RT];
@@ -603,7 +611,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             qqn[r] = K.QQ[(size_t)((k > 0) ? k - 1 : 0) * R::SQQ + e];   // (padded record: every lane has an entry)
         }
         if (!T::LTI) {
-            const double* pg = K.PGk((k > 1) ? k - 1 : 0);
+            const double* pg = K.PGk((k > 0) ? k - 1 : 0);
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
         }
@@ -777,6 +785,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 hreg[r] = h;
                 if (tid + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = h; K.sHh[hJ[r] * NZ + hI[r]] = h; }
             }
+            K.sync();   // T is dead from here: Z (below) is written into the same LDS words (LdsC: sT == sZ)
 
 #pragma unroll
             for (int r = 0; r < RZ; r++) {
@@ -920,7 +929,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 }
             }
         }
-        if (!T::LTI && k > 1) {
+        if (!T::LTI && k > 0) {
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; if (e < NPG) K.sPG[((k - 1) & 1) * NPG + e] = pgn[r]; }
         }
@@ -1044,12 +1053,12 @@ template <int MODEL, class BLK> GD void forward_sweep(BLK& K) {
 
 // Gd^-1 -> sP for the models whose goal system does not fit one lane's registers, by the whole workgroup: in-place
 // right-looking Cholesky of sGd (identity on the coordinates without a point goal), L^-1 one column per lane, then
-// L^-T L^-1 one entry per lane.  Scratch: the n*n doubles behind sGd.
+// L^-T L^-1 one entry per lane.  Scratch: sHh.
 template <int MODEL, class BLK> GD void inv_spd_block(BLK& K, double* fail) {
     constexpr int n = BLK::n;
     const int tid = K.tid, nt = K.nt();
     double* A = K.sGd;
-    double* Li = K.sGd + n * n;
+    double* Li = K.sHh;   // (free between the factor sweep and the next one; NZ^2 >= n^2 doubles)
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e % n;
         if (i == j && !K.is_goal(i)) A[e] = 1.0;
