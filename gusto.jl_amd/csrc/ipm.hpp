@@ -21,6 +21,9 @@
 
 namespace gusto {
 
+// the dynamic LDS of the workgroup (the same memory as the `extern __shared__` array of scp_kernel)
+extern __shared__ double gusto_dyn_lds[];
+
 struct IpmOut {
     int status, iters;
     double obj, res_p, res_d, mu;
@@ -63,8 +66,11 @@ template <int MODEL, bool ONEWAVE> struct Blk {
 
     GD int nt() const { return ONEWAVE ? 64 : NTr; }
 
-    GD Blk(const KParams& P_, double* lds_) : P(P_), lds(lds_) {
-        b = P.order ? P.order[blockIdx.x] : (int)blockIdx.x; tid = threadIdx.x; NTr = blockDim.x; N = P.N;
+    // every LDS pointer from the base of the dynamic LDS.  Also called at the top of the phases that run as real calls
+    // (MT::SWEEP_CALL) with the __shared__ symbol itself: a pointer that crosses a call is generic to the compiler and
+    // its accesses become flat_load/flat_store; re-derived from the symbol inside the callee they are ds_ operations.
+    GD void rebind_lds(double* l) {
+        lds = l;
         sP = lds + C::sP; sPi = lds + C::sPi; sPG = lds + C::sPG; sT = lds + C::sT; sHh = lds + C::sHh; sZ = lds + C::sZ;
         sK = lds + C::sK; sD = lds + C::sD; sW = lds + C::sW; sV = lds + C::sV; sGd = lds + C::sGd; misc = lds + C::misc;
         lut = reinterpret_cast<int*>(lds + C::lut);
@@ -72,6 +78,11 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         Xw = v; dY = v + N * n; pv = v + 2 * N * n; cv = v + 3 * N * n; rv = v + 4 * N * n; nu = v + 5 * N * n;
         nun = v + 6 * N * n;
         Uw = v + C::NVN * N * n;
+    }
+
+    GD Blk(const KParams& P_, double* lds_) : P(P_), lds(lds_) {
+        b = P.order ? P.order[blockIdx.x] : (int)blockIdx.x; tid = threadIdx.x; NTr = blockDim.x; N = P.N;
+        rebind_lds(lds_);
         double* w = P.ws + (size_t)b * P.wl.total;
         const WsLayout& W = P.wl;
         rowstate = w + W.rowstate; obs_nh = w + W.obs_nh; obs_c0 = w + W.obs_c0;
@@ -517,16 +528,24 @@ template <int MODEL> struct SweepView {
     GD void sync() const { blk_sync<true>(); }
     GD const double* PGk(int k) const { return PG + (size_t)(T::LTI ? 0 : k) * n * NZ; }
     GD bool is_goal(int i) const { return (goalmask >> i) & 1u; }
+    int phicl_off;   // LdsLayout::phicl
+    GD void rebind_lds(double* l) {   // see Blk::rebind_lds
+        lds = l;
+        sP = lds + C::sP; sPi = lds + C::sPi; sPG = lds + C::sPG; sT = lds + C::sT; sHh = lds + C::sHh;
+        sZ = lds + C::sZ; sK = lds + C::sK; sD = lds + C::sD; sW = lds + C::sW; sV = lds + C::sV;
+        sGd = lds + C::sGd; lut = reinterpret_cast<int*>(lds + C::lut);
+        double* v = lds + C::vecs;
+        dY = v + N * n; pv = v + 2 * N * n; cv = v + 3 * N * n; rv = v + 4 * N * n; nun = v + 6 * N * n;
+        // (one-wave problems of the small models: Phicl lives in LDS, stride n*n; otherwise padded global records)
+        if constexpr (C::PHICL_LDS) Phicl = lds + phicl_off;
+    }
     template <class BLK> GD static SweepView make(const BLK& K) {
         SweepView v;
-        v.lds = K.lds;
-        v.sP = K.lds + C::sP; v.sPi = K.lds + C::sPi; v.sPG = K.lds + C::sPG; v.sT = K.lds + C::sT; v.sHh = K.lds + C::sHh;
-        v.sZ = K.lds + C::sZ; v.sK = K.lds + C::sK; v.sD = K.lds + C::sD; v.sW = K.lds + C::sW; v.sV = K.lds + C::sV;
-        v.sGd = K.lds + C::sGd; v.lut = K.lut;
-        v.cv = K.cv; v.rv = K.rv; v.nun = K.nun; v.pv = K.pv; v.dY = K.dY;
+        v.N = K.N; v.phicl_off = K.P.ll.phicl;
+        v.Phicl = K.Phicl;
+        v.rebind_lds(K.lds);
         v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.KD = K.KD;
-        // (one-wave problems of the small models: Phicl lives in LDS, stride n*n; otherwise padded global records)
-        v.Phicl = C::PHICL_LDS ? K.lds + K.P.ll.phicl : K.Phicl; v.mpp = &K.P.mp; v.tid = K.tid; v.N = K.N; v.dt = K.dt; v.goalmask = K.goalmask;
+        v.mpp = &K.P.mp; v.tid = K.tid; v.dt = K.dt; v.goalmask = K.goalmask;
         return v;
     }
 };
@@ -1028,18 +1047,25 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
 // MT::SWEEP_CALL (measured per model: astrobeeSE3 +9 %, the manifold model -10 %): the sweep as a real call.  Inlined, its 50-stage loop shares one register allocation with the whole
 // interior point iteration and the allocator spills INSIDE the loop; called, the loop gets the register file to itself
 // and the caller's live values are saved once around the call.
-template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(SweepView<MODEL> K, double* fail, Prof* pf) {
-    factor_sweep_1w<MODEL>(K, fail, *pf);
+template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(SweepView<MODEL> K, Prof* pf) {
+    K.rebind_lds(gusto_dyn_lds);
+    factor_sweep_1w<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
 }
 template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof& pf) {
     if constexpr (!BLK::ONE) factor_sweep_mw<MODEL>(K, fail);
 #ifndef GUSTO_SWEEP_INLINE
-    else if constexpr (MT<MODEL>::SWEEP_CALL) factor_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K), fail, &pf);
+    else if constexpr (MT<MODEL>::SWEEP_CALL) factor_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K), &pf);
 #endif
     else factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail, pf);
 }
-template <int MODEL> __device__ __noinline__ void backward_sweep_1w_call(SweepView<MODEL> K) { backward_sweep_1w(K); }
-template <int MODEL> __device__ __noinline__ void forward_sweep_1w_call(SweepView<MODEL> K) { forward_sweep_1w(K); }
+template <int MODEL> __device__ __noinline__ void backward_sweep_1w_call(SweepView<MODEL> K) {
+    K.rebind_lds(gusto_dyn_lds);
+    backward_sweep_1w(K);
+}
+template <int MODEL> __device__ __noinline__ void forward_sweep_1w_call(SweepView<MODEL> K) {
+    K.rebind_lds(gusto_dyn_lds);
+    forward_sweep_1w(K);
+}
 template <int MODEL, class BLK> GD void backward_sweep(BLK& K) {
     if constexpr (!BLK::ONE) backward_sweep_mw(K);
     else if constexpr (MT<MODEL>::SWEEP_CALL) backward_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K));
@@ -1200,7 +1226,9 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
 }
 template <int MODEL, class BLK> __device__ __noinline__ void mid_phase_call(BLK K, int k, bool act, double hdt, double* red,
                                                                             double* mugn) {
-    mid_phase<MODEL>(K, k, act, hdt, red, mugn);
+    K.rebind_lds(gusto_dyn_lds);
+    using C = typename BLK::C;
+    mid_phase<MODEL>(K, k, act, hdt, gusto_dyn_lds + C::misc, gusto_dyn_lds + C::misc + 48);
 }
 
 // The phase after the forward sweep of a right-hand side: primal step of this knot, the new costates, row steps and
@@ -1288,7 +1316,10 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
 template <int MODEL, class BLK>
 __device__ __noinline__ StepOut step_phase_call(BLK K, RowCtx<MODEL> ctx, RowState rs, int k, bool act, int pass, int ncomp,
                                                 double hdt, double tau, double mu_t, const double* mugn, const double* gxs) {
-    return step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
+    K.rebind_lds(gusto_dyn_lds);
+    using C = typename BLK::C;
+    return step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, gusto_dyn_lds + C::misc + 48,
+                             gusto_dyn_lds + C::misc + 16);
 }
 
 // The residual phase of an interior point iteration: residuals, condensed Hessian blocks, dual residual, the predictor's
