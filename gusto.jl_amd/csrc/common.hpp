@@ -319,6 +319,13 @@ template <int n> GD bool inv_gauss_jordan(const double* A, double* Ainv) {
 // 1/sqrt(d) to double precision: v_rsq_f64 seed (~2^-26) + two Newton-Raphson steps, ~14 dependent flops
 // instead of the ~40 of sqrt() followed by a division -- the Cholesky of the m x m block sits on the critical
 // path of every knot of the factor sweep.
+// Marks a pointer that crossed a function call as pointing to global memory (generic -> addrspace(1) -> generic): the
+// accesses through it compile to global_load/global_store instead of flat_load/flat_store.
+template <class Tp> GD Tp* as_global(Tp* p) {
+    typedef __attribute__((address_space(1))) Tp G;
+    return (Tp*)(G*)p;
+}
+
 // 1/d from the hardware seed + two Newton steps (the inner part of the IEEE division sequence, without its scaling
 // and final correction: <= 2 ulp for the normal-range, finite operands of the row algebra): ~6 instructions against
 // ~14 for `a / b`.  The row algebra of one knot holds ~250 divisions per interior point iteration.

@@ -80,6 +80,15 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         Uw = v + C::NVN * N * n;
     }
 
+    GD void rebind_global() {   // (see rebind_lds)
+        rowstate = as_global(rowstate); obs_nh = as_global(obs_nh); obs_c0 = as_global(obs_c0); obs_mask = as_global(obs_mask);
+        PG = as_global(PG); QQ = as_global(QQ); Paft = as_global(Paft); Piaft = as_global(Piaft); KD = as_global(KD);
+        Phicl = as_global(Phicl);
+        rd = as_global(rd); qrd = as_global(qrd); dXs = as_global(dXs); dUs = as_global(dUs); qu = as_global(qu); dv = as_global(dv);
+        Xp = as_global(Xp); Up = as_global(Up);
+        x_init = as_global(x_init); goal_lo = as_global(goal_lo); goal_hi = as_global(goal_hi);
+    }
+
     GD Blk(const KParams& P_, double* lds_) : P(P_), lds(lds_) {
         b = P.order ? P.order[blockIdx.x] : (int)blockIdx.x; tid = threadIdx.x; NTr = blockDim.x; N = P.N;
         rebind_lds(lds_);
@@ -538,6 +547,10 @@ template <int MODEL> struct SweepView {
         dY = v + N * n; pv = v + 2 * N * n; cv = v + 3 * N * n; rv = v + 4 * N * n; nun = v + 6 * N * n;
         // (one-wave problems of the small models: Phicl lives in LDS, stride n*n; otherwise padded global records)
         if constexpr (C::PHICL_LDS) Phicl = lds + phicl_off;
+    }
+    GD void rebind_global() {
+        PG = as_global(PG); QQ = as_global(QQ); Paft = as_global(Paft); Piaft = as_global(Piaft); KD = as_global(KD);
+        if constexpr (!C::PHICL_LDS) Phicl = as_global(Phicl);
     }
     template <class BLK> GD static SweepView make(const BLK& K) {
         SweepView v;
@@ -1049,6 +1062,7 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
 // and the caller's live values are saved once around the call.
 template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(SweepView<MODEL> K, Prof* pf) {
     K.rebind_lds(gusto_dyn_lds);
+    K.rebind_global();
     factor_sweep_1w<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
 }
 template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof& pf) {
@@ -1060,10 +1074,12 @@ template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof&
 }
 template <int MODEL> __device__ __noinline__ void backward_sweep_1w_call(SweepView<MODEL> K) {
     K.rebind_lds(gusto_dyn_lds);
+    K.rebind_global();
     backward_sweep_1w(K);
 }
 template <int MODEL> __device__ __noinline__ void forward_sweep_1w_call(SweepView<MODEL> K) {
     K.rebind_lds(gusto_dyn_lds);
+    K.rebind_global();
     forward_sweep_1w(K);
 }
 template <int MODEL, class BLK> GD void backward_sweep(BLK& K) {
@@ -1227,6 +1243,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
 template <int MODEL, class BLK> __device__ __noinline__ void mid_phase_call(BLK K, int k, bool act, double hdt, double* red,
                                                                             double* mugn) {
     K.rebind_lds(gusto_dyn_lds);
+    K.rebind_global();
     using C = typename BLK::C;
     mid_phase<MODEL>(K, k, act, hdt, gusto_dyn_lds + C::misc, gusto_dyn_lds + C::misc + 48);
 }
@@ -1317,6 +1334,10 @@ template <int MODEL, class BLK>
 __device__ __noinline__ StepOut step_phase_call(BLK K, RowCtx<MODEL> ctx, RowState rs, int k, bool act, int pass, int ncomp,
                                                 double hdt, double tau, double mu_t, const double* mugn, const double* gxs) {
     K.rebind_lds(gusto_dyn_lds);
+    K.rebind_global();
+    rs.base = as_global(rs.base);
+    ctx.xp = as_global(ctx.xp); ctx.obs_nh = as_global(ctx.obs_nh); ctx.obs_c0 = as_global(ctx.obs_c0);
+    ctx.goal_lo = as_global(ctx.goal_lo); ctx.goal_hi = as_global(ctx.goal_hi);
     using C = typename BLK::C;
     return step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, gusto_dyn_lds + C::misc + 48,
                              gusto_dyn_lds + C::misc + 16);
