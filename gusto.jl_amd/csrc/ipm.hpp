@@ -1525,7 +1525,13 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
 template <int MODEL, class BLK>
 __device__ __noinline__ ResidOut resid_phase_call(BLK K, RowCtx<MODEL> ctx, RowState rs, int k, bool act, double hdt, double wk,
                                                   double alpha_prev, const double* mug) {
-    return resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
+    K.rebind_lds(gusto_dyn_lds);
+    K.rebind_global();
+    rs.base = as_global(rs.base);
+    ctx.xp = as_global(ctx.xp); ctx.obs_nh = as_global(ctx.obs_nh); ctx.obs_c0 = as_global(ctx.obs_c0);
+    ctx.goal_lo = as_global(ctx.goal_lo); ctx.goal_hi = as_global(ctx.goal_hi);
+    using C = typename BLK::C;
+    return resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, gusto_dyn_lds + C::misc + 32);
 }
 
 // ---- the interior point method ---------------------------------------------------------------------
@@ -1618,9 +1624,8 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         K.sync();
         // (2) residuals, condensed Hessian blocks, dual residual; (3) the LQR stage cost of this knot
         ResidOut ro;
-        // (inlined for every model: as a call it was 2 % slower for astrobeeSE3 -- this phase alone wants more than the
-        // register file, isolating it does not help)
-        ro = resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
+        if constexpr (T::SWEEP_CALL) ro = resid_phase_call<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
+        else ro = resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
         const double l_resp = ro.resp, l_resd = ro.resd, l_comp = ro.comp, l_numax = ro.numax;
         res_p = block_reduce(l_resp, OpNanMax(), red);
         res_d = block_reduce(l_resd, OpNanMax(), red);
