@@ -516,8 +516,9 @@ template <class BLK> GD void forward_sweep_mw(BLK& K) {
 }
 
 
-// Compact by-value view of a problem for the one-wave sweeps (only what their knot loops touch).  Out-of-line
-// (noinline) sweeps were measured and are slower on gfx950: the calls force ABI spills in the caller.
+// Compact by-value view of a problem for the one-wave sweeps (only what their knot loops touch).  Whether a sweep runs
+// inlined or as a real call is a per-model choice (MT::SWEEP_CALL): for freeflyerSE2 the call costs 40 % (its frame
+// goes to scratch), for the 12/13-state models it is what keeps the knot loop out of scratch.
 template <int MODEL> struct SweepView {
     using T = MT<MODEL>;
     using C = LdsC<MODEL, true>;
