@@ -239,15 +239,18 @@ def shard_bounds(B, world_size, rank):
 
 
 def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straightline, solver="hip", max_iter=30,
-                    force=False, device=0):
-    """All TOPs must share model, N and environment; one gusto_solve covers the whole list."""
+                    force=False, device=0, devices=None):
+    """All TOPs must share model, N and environment; one gusto_solve covers the whole list.
+
+    `devices` = list of GPU ordinals: the problems are sharded in contiguous blocks (shard_bounds) over
+    one handle per entry, every shard is enqueued with gusto_solve_async and the shards run concurrently -- the
+    single-process form of the multi-GPU path (an ordinal may repeat: two shards on one GPU overlap like two batches)."""
     TOP0 = TOPs[0]
     model, N = TOP0.PD.model, TOP0.N
     n = model.x_dim
     B = len(TOPs)
+    devs = list(devices) if devices else [device]
     sp, mp = _capi.default_params(model.model_id)
-    bs = BatchSolver(model.model_id, N, B, hist_cap=max(64, 2 * max_iter + 8), device=device, boxes=TOP0.PD.env.boxes,
-                     spheres=TOP0.PD.env.spheres, scp_params=sp, model_params=mp)
     x0 = np.stack([t.PD.x_init for t in TOPs])
     bounds = [_goal_bounds(t.PD.goal_set, n, t.tf_guess) for t in TOPs]
     lo, hi = np.stack([b[0] for b in bounds]), np.stack([b[1] for b in bounds])
@@ -255,15 +258,25 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
     inits = [init_method(t) if callable(init_method) else init_method for t in TOPs]
     X0 = np.stack([t.X.T for t in inits])
     U0 = np.stack([t.U.T for t in inits])
-    bs.set_problems(x0, lo, hi, tf, X0, U0)
-    bs.solve(max_iter, force)
-    out = []
-    for b, (TOS, TOP) in enumerate(zip(TOSs, TOPs)):
-        SCPP = SCPProblem(TOP)
-        SCPS = SCPSolution(SCPP, inits[b])
-        _fill_solution(SCPS, SCPP, bs, b, bs.last_solve_ms() * 1e-3 / B)
-        TOS.traj, TOS.SCPS = SCPS.traj, SCPS
-        out.append(SCPS)
+    shards = []
+    for r, dv in enumerate(devs):
+        b0, b1 = shard_bounds(B, len(devs), r)
+        if b1 <= b0:
+            continue
+        bs = BatchSolver(model.model_id, N, b1 - b0, hist_cap=max(64, 2 * max_iter + 8), device=dv,
+                         boxes=TOP0.PD.env.boxes, spheres=TOP0.PD.env.spheres, scp_params=sp, model_params=mp)
+        bs.set_problems(x0[b0:b1], lo[b0:b1], hi[b0:b1], tf[b0:b1], X0[b0:b1], U0[b0:b1])
+        bs.solve_async(max_iter, force)
+        shards.append((b0, b1, bs))
+    out = [None] * B
+    for b0, b1, bs in shards:
+        bs.wait()
+        for b in range(b0, b1):
+            SCPP = SCPProblem(TOPs[b])
+            SCPS = SCPSolution(SCPP, inits[b])
+            _fill_solution(SCPS, SCPP, bs, b - b0, bs.last_solve_ms() * 1e-3 / (b1 - b0))
+            TOSs[b].traj, TOSs[b].SCPS = SCPS.traj, SCPS
+            out[b] = SCPS
     return out
 
 

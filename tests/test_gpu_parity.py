@@ -395,6 +395,12 @@ def test_host_mirror_solve_SCP_through_the_seam():
     for S in outs:
         assert S.converged and np.array_equal(S.traj.X, outs[0].traj.X)
     assert np.abs(outs[0].traj.X.T - r["X"]).max() < TRAJ_ATOL
+    # sharded form (devices=...): five copies over two handles, enqueued asynchronously -- the same trajectories
+    TOSs = [H.TrajectoryOptimizationSolution(TOP) for _ in range(5)]
+    sh = H.solve_SCP_batch(TOSs, [TOP] * 5, H.solve_gusto_hip, H.init_traj_straightline, "hip", max_iter=30, devices=[0, 0])
+    assert len(sh) == 5
+    for S, T_ in zip(sh, TOSs):
+        assert S.converged and T_.SCPS is S and np.array_equal(S.traj.X, outs[0].traj.X)
 
 
 @pytest.mark.parametrize("N", [5, 33, 64, 65, 130])
