@@ -62,6 +62,10 @@ def test_bad_arguments_are_rejected():
     assert L.gusto_create(C.byref(h), 0, 2, 4, 16, 0) == -1       # N < 3
     assert L.gusto_create(C.byref(h), 9, 50, 4, 16, 0) == -1      # unknown model
     assert L.gusto_create(None, 0, 50, 4, 16, 0) == -1
+    # entry points added on top of the reference's interface reject a null handle the same way
+    assert L.gusto_solve_async(None, 30, 0) == -1
+    assert L.gusto_wait(None) == -1
+    assert L.gusto_set_schedule(None, 2, 2048) == -1
 
 
 def test_product_never_imports_the_oracle():
