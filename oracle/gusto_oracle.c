@@ -41,6 +41,7 @@ struct go_problem {
     go_scp_params sp;
     go_model_params mp;
     go_ipm_opts io;
+    go_dist_model dm;
     int n_box, n_sph, n_obs;
     double *box, *sph;
     double x_init[NX], goal_lo[NX], goal_hi[NX], tf, dt;
@@ -385,12 +386,89 @@ static double sdf_box(const double* q, const double* lo, const double* hi, int d
     nh[bi] = bs;
     return -best;
 }
+/* ---- study model of what a 3-D collision library returns for the freeflyer --------------
+ * The robot body is an upright prism over a regular n-gon (n_poly vertices on the circle of radius r; 0 = the
+ * exact disc) spanning z in [z_lo, z_hi]; obstacles are 3-D AABBs.  Separated: Euclidean distance (z ranges of
+ * every freeflyer obstacle overlap the robot's, so it is the planar distance).  Penetrating: the minimum
+ * translation that separates the two bodies, which may be VERTICAL (lifting the robot over a low box) -- then
+ * the normal has no planar component.  `margin` is subtracted from every distance (collision margins).     */
+static double poly_rect_2d(const double* c, double rad, int np, double phase, const double* lo, const double* hi,
+                           double* nh) {
+    double V[64][2], W[4][2] = {{lo[0], lo[1]}, {hi[0], lo[1]}, {hi[0], hi[1]}, {lo[0], hi[1]}};
+    if (np > 64) np = 64;
+    for (int a = 0; a < np; a++) {
+        double t = phase + 2.0 * M_PI * a / np;
+        V[a][0] = c[0] + rad * cos(t); V[a][1] = c[1] + rad * sin(t);
+    }
+    /* separating axis test over the edge normals of both polygons: overlap on every axis <=> intersecting */
+    double best_ov = 1e300, bax[2] = {0, 0};
+    int sep = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        int ne = pass ? 4 : np;
+        for (int e = 0; e < ne; e++) {
+            const double *a = pass ? W[e] : V[e], *b = pass ? W[(e + 1) % 4] : V[(e + 1) % np];
+            double ax[2] = {b[1] - a[1], -(b[0] - a[0])}, l = hypot(ax[0], ax[1]);
+            ax[0] /= l; ax[1] /= l;
+            double vmin = 1e300, vmax = -1e300, wmin = 1e300, wmax = -1e300;
+            for (int j = 0; j < np; j++) { double t = V[j][0] * ax[0] + V[j][1] * ax[1]; if (t < vmin) vmin = t; if (t > vmax) vmax = t; }
+            for (int j = 0; j < 4; j++) { double t = W[j][0] * ax[0] + W[j][1] * ax[1]; if (t < wmin) wmin = t; if (t > wmax) wmax = t; }
+            /* translation of the robot along +ax by (wmax - vmin) or along -ax by (vmax - wmin) separates */
+            double o1 = wmax - vmin, o2 = vmax - wmin;
+            if (o1 <= 0 || o2 <= 0) { sep = 1; break; }
+            if (o1 < best_ov) { best_ov = o1; bax[0] = ax[0]; bax[1] = ax[1]; }
+            if (o2 < best_ov) { best_ov = o2; bax[0] = -ax[0]; bax[1] = -ax[1]; }
+        }
+        if (sep) break;
+    }
+    if (!sep) { nh[0] = bax[0]; nh[1] = bax[1]; return -best_ov; }
+    /* disjoint convex polygons: closest vertex-edge pair, both ways */
+    double best = 1e300;
+    for (int pass = 0; pass < 2; pass++) {
+        int nv = pass ? 4 : np, ne = pass ? np : 4;
+        for (int j = 0; j < nv; j++) {
+            const double* q = pass ? W[j] : V[j];
+            for (int e = 0; e < ne; e++) {
+                const double *a = pass ? V[e] : W[e], *b = pass ? V[(e + 1) % np] : W[(e + 1) % 4];
+                double ab[2] = {b[0] - a[0], b[1] - a[1]}, aq[2] = {q[0] - a[0], q[1] - a[1]};
+                double t = (aq[0] * ab[0] + aq[1] * ab[1]) / (ab[0] * ab[0] + ab[1] * ab[1]);
+                t = t < 0 ? 0 : (t > 1 ? 1 : t);
+                double cx = a[0] + t * ab[0], cy = a[1] + t * ab[1], dx = q[0] - cx, dy = q[1] - cy, dd = hypot(dx, dy);
+                if (dd < best) {
+                    best = dd; /* normal points from the obstacle to the robot */
+                    if (pass) { nh[0] = -dx / dd; nh[1] = -dy / dd; } else { nh[0] = dx / dd; nh[1] = dy / dd; }
+                }
+            }
+        }
+    }
+    return best;
+}
+static double dist_study_freeflyer(const go_problem* p, int comp, const double* q, const double* lo, const double* hi,
+                                   double* nh) {
+    const go_dist_model* dm = &p->dm;
+    double dist;
+    nh[0] = nh[1] = nh[2] = 0;
+    if (dm->n_poly > 0) dist = poly_rect_2d(q, p->mp.radius, dm->n_poly, dm->poly_phase, lo, hi, nh);
+    else dist = sdf_box(q, lo, hi, 2, nh) - p->mp.radius;
+    if (dist < 0 && dm->vertical_escape) {
+        double up = hi[2] - dm->z_lo, down = dm->z_hi - lo[2], v = up < down ? up : down;
+        if (v < -dist) { dist = -v; nh[0] = nh[1] = 0; nh[2] = up < down ? 1.0 : -1.0; }
+    }
+    if (dist < 0 && (dm->pen_mode == 1 || (dm->pen_mode == 2 && comp > 0))) return dm->pen_value; /* "no result" from a detector without penetration solver */
+    if (dm->pen_mode == 3 && fabs(dist) < dm->pen_band) return dm->pen_value; /* degenerate near-contact band */
+    if (dm->pen_mode == 4 && dist < 0 && dist > -dm->pen_band) return dm->pen_value; /* shallow penetration  */
+    return dist - dm->margin;
+}
+void go_set_distance_model(go_problem* p, const go_dist_model* dm) { p->dm = *dm; }
+
 /* obstacle i: boxes first (keepout_zones then obstacle_set boxes), then spheres (types.jl:19) */
 double go_signed_distance(const go_problem* p, int comp, const double* r, int i, double* nhat) {
     const int d = ws_dim(p);
     double q[3] = {0, 0, 0}, nh[3] = {0, 0, 0}, dist;
     for (int j = 0; j < d; j++) q[j] = r[j] + p->mp.comp_off[comp][j];
-    if (i < p->n_box) {
+    if (p->dm.kind == 1 && p->model == GO_FREEFLYER_SE2 && i < p->n_box) {
+        const double* bx = p->box + 6 * i;
+        dist = dist_study_freeflyer(p, comp, q, bx, bx + 3, nh);
+    } else if (i < p->n_box) {
         const double* bx = p->box + 6 * i;
         dist = sdf_box(q, bx, bx + 3, d, nh) - p->mp.radius;
     } else {

@@ -66,6 +66,17 @@ typedef struct {
     int max_iter;
 } go_ipm_opts;
 
+/* Study knob (tests/test_oracle_scp.py): alternative models of what the reference's external
+ * collision library returns for the freeflyer.  kind 0 = the analytic planar distance the product uses. */
+typedef struct {
+    int kind;             /* 0 analytic (default), 1 prism-vs-AABB study model (freeflyer only)          */
+    int n_poly;           /* >0: body is a regular n-gon prism with vertices on the circle; 0: exact disc  */
+    int vertical_escape;  /* penetration depth may be the vertical separation (3-D minimum translation)    */
+    double poly_phase, margin, z_lo, z_hi;
+    int pen_mode;         /* 1: a penetrating pair returns pen_value instead of a depth                   */
+    double pen_value, pen_band; /* pen_mode 3: |d| < pen_band, 4: -pen_band < d < 0 return pen_value     */
+} go_dist_model;
+
 typedef struct {
     double obj;        /* JuMP.objective_value: cost + all slacks (unscaled)     */
     double res_p, res_d, mu;
@@ -82,6 +93,7 @@ go_problem* go_create(int model, int N, const go_scp_params* sp, const go_model_
                       int n_box, const double* box_min_max, int n_sph, const double* sph_c_r);
 void go_destroy(go_problem* p);
 void go_set_ipm_opts(go_problem* p, const go_ipm_opts* o);
+void go_set_distance_model(go_problem* p, const go_dist_model* dm);
 
 /* goal_lo==goal_hi -> hard equality, +-inf -> free, else hard box (BoxGoal).
  * X0/U0 NULL -> straight line init (freeflyer_se2.jl:97-111). Resets histories. */

@@ -39,6 +39,13 @@ class IpmOpts(C.Structure):
                 ("mu_warm", C.c_double), ("max_iter", C.c_int)]
 
 
+class DistModel(C.Structure):
+    """Study knob for the freeflyer signed distance (oracle/gusto_oracle.h go_dist_model)."""
+    _fields_ = [("kind", C.c_int), ("n_poly", C.c_int), ("vertical_escape", C.c_int), ("poly_phase", C.c_double),
+                ("margin", C.c_double), ("z_lo", C.c_double), ("z_hi", C.c_double), ("pen_mode", C.c_int),
+                ("pen_value", C.c_double), ("pen_band", C.c_double)]
+
+
 class SubInfo(C.Structure):
     _fields_ = [("obj", C.c_double), ("res_p", C.c_double), ("res_d", C.c_double), ("mu", C.c_double),
                 ("iters", C.c_int), ("status", C.c_int)]
@@ -67,6 +74,7 @@ def lib():
                                 C.c_int, C.c_void_p]
         L.go_destroy.argtypes = [C.c_void_p]
         L.go_set_ipm_opts.argtypes = [C.c_void_p, C.POINTER(IpmOpts)]
+        L.go_set_distance_model.argtypes = [C.c_void_p, C.POINTER(DistModel)]
         L.go_set_problem.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, C.c_void_p, C.c_void_p]
         L.go_solve.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.go_get_traj.argtypes = [C.c_void_p, _dp, _dp]
@@ -129,6 +137,13 @@ class Oracle:
         if getattr(self, "h", None):
             self.L.go_destroy(self.h)
             self.h = None
+
+    def set_distance_model(self, **kw):
+        """Study knob: kind=1 selects the prism-vs-AABB model (n_poly, vertical_escape, margin, z_lo, z_hi)."""
+        dm = DistModel(kind=1, n_poly=0, vertical_escape=0, poly_phase=0.0, margin=0.0, z_lo=0.0, z_hi=1.0)
+        for k, v in kw.items():
+            setattr(dm, k, v)
+        self.L.go_set_distance_model(self.h, C.byref(dm))
 
     # -- problem / solve ---------------------------------------------------------------------
     def set_problem(self, x_init, goal_lo, goal_hi, tf, X0=None, U0=None):

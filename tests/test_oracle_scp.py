@@ -80,17 +80,94 @@ def test_resume_semantics():
     assert len(r2["J_true"]) == len(ra["J_true"]) + 1        # one extra leading entry per call (scp_gusto.jl:73)
 
 
-def test_notebook_run_soft_pin():
-    """examples/freeflyerSE2.ipynb:87-97 (N=200, Gurobi, Bullet): converged, omega ends <= 1e3, final J_true O(0.1),
-    first accepted J_true ~0.15 then ~0.087.  Soft: the recorded run depends on Bullet's tessellated distances and
-    Gurobi's QCP tolerances, neither available here."""
-    d = _load("freeflyer_se2_n200_notebook")
-    assert bool(d["converged"][0])
-    J = d["J_true"][0][~np.isnan(d["J_true"][0])]
-    assert abs(J[1] - 0.152419) < 0.01 and abs(J[2] - 0.0865004) < 0.01     # notebook: 0.152419, 0.0865004
-    assert 0.03 < J[-1] < 0.2                                               # notebook final: 0.111656
-    om = d["omega"][0][~np.isnan(d["omega"][0])]
-    assert om.max() <= 1e3
+def _notebook_run(dist_model=None, max_iter=40):
+    o = go.Oracle(go.FREEFLYER_SE2, 200, boxes=P.freeflyer_env())
+    if dist_model:
+        o.set_distance_model(**dist_model)
+    o.set_problem(P.FREEFLYER_X_INIT, P.FREEFLYER_X_GOAL, P.FREEFLYER_X_GOAL, P.FREEFLYER_TF)
+    return o, o.solve(max_iter)
+
+
+def _trace():
+    import json
+    with open(os.path.join(GOLD, "freeflyer_se2_notebook_trace.json")) as f:
+        t = json.load(f)
+    code = {v: k for k, v in go.SCP_STATUS.items()}
+    t["scp_status"] = [code[x] for x in t["scp_status"]]
+    return t
+
+
+def _head_matches(r, t, n=7):
+    """entries 0..n-1 of the recorded histories: the run-up before the reference's first rejection"""
+    assert list(r["accept"][:n]) == t["accept_solution"][:n]
+    assert list(r["scp_status"][:n]) == t["scp_status"][:n]
+    np.testing.assert_array_equal(r["Delta"][:n], t["Delta_vec"][:n])
+    np.testing.assert_array_equal(r["omega"][:n], t["omega_vec"][:n])
+
+
+def test_notebook_trace_head_analytic_distance():
+    """The only run the reference records (examples/freeflyerSE2.ipynb:87-97, N=200, Gurobi + BulletCollision;
+    committed as tests/golden/freeflyer_se2_notebook_trace.json) against the oracle with the product's analytic
+    planar distance.  Iterations 1-6 (all accepted, Delta = 3, omega = 1): identical decisions; J_true within 4 %
+    (measured -2.3 ... -3.8 %), convergence_measure[1] within 1 %.  DESIGN section 8 has the account."""
+    t = _trace()
+    _, r = _notebook_run(max_iter=8)
+    _head_matches(r, t)
+    J = np.array(t["J_true"])
+    err = (r["J_true"][1:7] - J[1:7]) / J[1:7]
+    assert np.abs(err).max() < 0.04 and (err < 0).all()     # uniformly a little cheaper than the recorded run
+    assert abs(r["conv"][1] / t["convergence_measure"][1] - 1) < 0.01
+    assert np.abs(r["conv"][2:4] / np.array(t["convergence_measure"][2:4]) - 1).max() < 0.06
+
+
+@pytest.mark.parametrize("dm,tol", [
+    (dict(n_poly=32), 0.013),                       # 32-gon prism, vertices on the circle, no margin
+    (dict(margin=0.00125), 0.0125),                 # exact disc, every distance 1.25 mm smaller
+    (dict(n_poly=64, margin=0.00075), 0.0065),      # best of the scan (scratch study, DESIGN section 8)
+])
+def test_notebook_trace_head_distance_study(dm, tol):
+    """One-parameter study of the unpinned external distance (BulletCollision: tessellated hull, margins unknown):
+    sub-millimetre changes of the distance model move J_true[1..6] by whole per cents, and several physically
+    plausible ones bring all six within ~1 % of the recorded values while keeping every recorded decision."""
+    t = _trace()
+    _, r = _notebook_run(dm, max_iter=8)
+    _head_matches(r, t)
+    J = np.array(t["J_true"])
+    assert np.abs((r["J_true"][1:7] - J[1:7]) / J[1:7]).max() < tol
+
+
+def test_notebook_trace_start_state_sits_on_the_acceptance_threshold():
+    """Why the run is so sensitive: x_init = (0.2, 2.4) puts the body 0.043 m from the x = 0 table slab, i.e. the
+    k = 1 obstacle row is violated by 0.007 for ever (x_1 is fixed) with eps = 0.01 as the acceptance threshold
+    (scp_gusto.jl:321).  3 mm less distance and every iterate 'violates constraints': omega escalates to omega_max."""
+    o, _ = _notebook_run(max_iter=1)
+    d, _n = o.signed_distance(0, P.FREEFLYER_X_INIT[:2], 1)
+    assert abs(d - 0.043) < 1e-12 and 0 < 0.05 - d < 0.01
+    _, r = _notebook_run(dict(margin=0.004), max_iter=8)
+    assert (r["scp_status"][1:] == 3).all() and r["omega"][-1] >= 1e5
+
+
+def test_notebook_trace_tail_needs_a_discontinuous_distance():
+    """Entries 7-9 and 13-19 of the recorded run are :InaccurateModel, i.e. rho > rho1 = 0.3, for steps of ~1 % of
+    the trajectory scale.  rho's denominator (freeflyer_se2.jl:403-421) sums |clearance - d - n.(r - r0)| over
+    200 knots x 2 robot components x 14 obstacles ~ 6e3 m, so rho > 0.3 needs ~2e3 m of linearisation error:
+    no distance function with bounded error can produce it (ours: rho < 1e-2 over the whole run, with or without
+    tessellation), and returning 'no result' sentinels for penetrating / touching pairs breaks iteration 1, which
+    the reference accepted.  The tail of the recorded trace is therefore not reproducible from the repository
+    (DESIGN section 8); what we pin is that the oracle's own run converges with omega = 1."""
+    t = _trace()
+    for dm in (None, dict(n_poly=25), dict(n_poly=32)):
+        o, r = _notebook_run(dm)
+        assert r["converged"] and r["omega"][-1] == 1.0 and (r["scp_status"][1:] == 1).all()
+        assert np.nanmax(r["rho"][2:]) < 1e-2
+        Xp, Up = o.traj()
+        den = sum(abs(0.05 - o.signed_distance(c, Xp[k, :2], i)[0]) for k in range(200) for c in range(2)
+                  for i in range(14))
+        assert den > 5e3
+    assert t["scp_status"].count(2) == 10 and max(t["omega_vec"]) == 100.0
+    for pen_mode, kw in ((1, {}), (2, {}), (3, dict(pen_band=1e-3))):        # sentinel hypotheses
+        _, r = _notebook_run(dict(pen_mode=pen_mode, pen_value=1e18, **kw), max_iter=2)
+        assert r["accept"][1] == 0                                           # the reference accepted iteration 1
 
 
 def test_infeasible_subproblem_is_reported_not_raised():
