@@ -15,7 +15,7 @@ FREEFLYER_SE2, DUBINS_CAR, ASTROBEE_SE3, ASTROBEE_SE3_MANIFOLD = 0, 1, 2, 3
 MODEL_DIMS = {0: (6, 3), 1: (3, 1), 2: (12, 6), 3: (13, 6)}
 SCP_STATUS = {0: "NA", 1: "OK", 2: "InaccurateModel", 3: "ViolatesConstraints", 4: "TrustRegionViolated"}
 SOLVER_STATUS = {0: "NA", 1: "OPTIMAL", 2: "ALMOST_LOCALLY_SOLVED", 3: "FAILED"}
-STOP_REASON = {0: "MaxIter", 1: "Converged", 2: "SubproblemFailed", 3: "OmegaMaxExceeded"}
+STOP_REASON = {0: "MaxIter", 1: "Converged", 2: "SubproblemFailed", 3: "OmegaMaxExceeded", 4: "HistoryFull"}
 
 # every symbol include/gusto_hip.h declares
 SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims", "gusto_create", "gusto_destroy",
@@ -23,7 +23,8 @@ SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims",
            "gusto_set_stream",
            "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_solve_async", "gusto_wait",
            "gusto_last_solve_ms", "gusto_get_traj",
-           "gusto_get_traj_dev", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_subproblem"]
+           "gusto_get_traj_dev", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_get_hist_cap",
+           "gusto_set_trust_state", "gusto_subproblem"]
 
 
 class ScpParams(C.Structure):
@@ -120,6 +121,8 @@ def lib():
         L.gusto_get_status.argtypes = [vp, vp, vp, vp, vp, vp]
         L.gusto_get_dual.argtypes = [vp, vp]
         L.gusto_get_history.argtypes = [vp, C.POINTER(History)]
+        L.gusto_get_hist_cap.argtypes = [vp, C.POINTER(ci)]
+        L.gusto_set_trust_state.argtypes = [vp, vp, vp]
         L.gusto_subproblem.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
@@ -153,7 +156,7 @@ class BatchSolver:
     def __init__(self, model, N, batch_cap, hist_cap=64, device=0, boxes=None, spheres=None, scp_params=None,
                  model_params=None, ipm_opts=None):
         self.L = lib()
-        self.model, self.N, self.batch_cap, self.hist_cap = model, N, batch_cap, hist_cap
+        self.model, self.N, self.batch_cap, self.hist_cap, self.device = model, N, batch_cap, hist_cap, device
         self.n, self.m = MODEL_DIMS[model]
         self.h = C.c_void_p()
         rc = self.L.gusto_create(C.byref(self.h), model, N, batch_cap, hist_cap, device)
@@ -202,6 +205,13 @@ class BatchSolver:
                                             None if U0 is None else self._keep[5].ctypes.data), "set_problems")
         self.B = B
 
+    def set_trust_state(self, Delta=None, omega=None):
+        """gusto_set_trust_state: the caller's own Delta_vec[end] / omega_vec[end] for the next trip of every problem."""
+        D = None if Delta is None else _arr(np.broadcast_to(np.asarray(Delta, dtype=np.float64), (self.B,)))
+        W = None if omega is None else _arr(np.broadcast_to(np.asarray(omega, dtype=np.float64), (self.B,)))
+        self._chk(self.L.gusto_set_trust_state(self.h, None if D is None else D.ctypes.data,
+                                               None if W is None else W.ctypes.data), "set_trust_state")
+
     def set_schedule(self, probe_iters=2, min_batch=2048):
         self._chk(self.L.gusto_set_schedule(self.h, int(probe_iters), int(min_batch)), "set_schedule")
 
@@ -230,6 +240,21 @@ class BatchSolver:
         X, U = np.zeros((self.B, self.N, self.n)), np.zeros((self.B, self.N, self.m))
         self._chk(self.L.gusto_get_traj(self.h, X.ctypes.data, U.ctypes.data), "get_traj")
         return X, U
+
+    def traj_dev(self):
+        """gusto_get_traj_dev as zero-copy torch views of the handle's HBM buffers: X [B,N,n], U [B,N,m] (valid until
+        the next set_problems / solve on this handle).  For device-side consumers, e.g. the RCCL gather."""
+        import torch
+        px, pu = C.c_void_p(), C.c_void_p()
+        self._chk(self.L.gusto_get_traj_dev(self.h, C.byref(px), C.byref(pu)), "get_traj_dev")
+
+        class _View:       # __cuda_array_interface__ v2: lets torch wrap a raw device pointer without a copy
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = dict(shape=shape, typestr="<f8", data=(int(ptr), False), version=2)
+
+        dev = torch.device("cuda", self.device)
+        return (torch.as_tensor(_View(px.value, (self.B, self.N, self.n)), device=dev),
+                torch.as_tensor(_View(pu.value, (self.B, self.N, self.m)), device=dev))
 
     def status(self):
         a = [np.zeros(self.B, dtype=np.int32) for _ in range(5)]

@@ -137,35 +137,48 @@ int gusto_destroy(gusto_handle h) {
     return GUSTO_OK;
 }
 
+// every setter first completes an enqueued solve (gusto_solve_async) on the handle's own device
+static int setter_enter(gusto_handle h) {
+    HIPCHK(h, hipSetDevice(h->device));
+    return gusto_finish(h);
+}
+
 int gusto_set_params(gusto_handle h, const gusto_scp_params* sp, const gusto_model_params* mp) {
     if (!h) return GUSTO_ERR_ARG;
+    { int rc = setter_enter(h); if (rc) return rc; }
     if (sp) h->sp = *sp;
     if (mp) h->mp = *mp;
     return GUSTO_OK;
 }
 int gusto_set_ipm_opts(gusto_handle h, const gusto_ipm_opts* o) {
     if (!h || !o) return GUSTO_ERR_ARG;
+    { int rc = setter_enter(h); if (rc) return rc; }
     h->io = *o;
     return GUSTO_OK;
 }
 int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch) {
     if (!h || probe_iters < 0 || min_batch < 1) return GUSTO_ERR_ARG;
+    { int rc = setter_enter(h); if (rc) return rc; }
     h->probe_iters = probe_iters; h->probe_min_batch = min_batch;
     return GUSTO_OK;
 }
 
 int gusto_set_stream(gusto_handle h, void* s) {
     if (!h) return GUSTO_ERR_ARG;
-    if (h->own_stream && h->stream) { hipStreamDestroy(h->stream); h->own_stream = false; }
-    if (s) { h->stream = (hipStream_t)s; }
-    else { HIPCHK(h, hipStreamCreate(&h->stream)); h->own_stream = true; }
+    { int rc = setter_enter(h); if (rc) return rc; }   // a pending solve is synchronised on the stream it runs on
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    h->stream = nullptr; h->own_stream = false;
+    if (s) { h->stream = (hipStream_t)s; return GUSTO_OK; }
+    hipStream_t ns = nullptr;
+    HIPCHK(h, hipStreamCreate(&ns));
+    h->stream = ns; h->own_stream = true;
     return GUSTO_OK;
 }
 
 int gusto_set_env(gusto_handle h, int n_box, const double* box, int n_sph, const double* sph) {
     if (!h || n_box < 0 || n_sph < 0 || (n_box && !box) || (n_sph && !sph)) return GUSTO_ERR_ARG;
     if (n_box + n_sph > 64) { h->err = "gusto_set_env: at most 64 keep-out components"; return GUSTO_ERR_ARG; }
-    HIPCHK(h, hipSetDevice(h->device));
+    { int rc = setter_enter(h); if (rc) return rc; }
     hipFree(h->d_box); hipFree(h->d_sph);
     h->d_box = h->d_sph = nullptr;
     HIPCHK(h, dalloc(&h->d_box, (size_t)6 * n_box)); HIPCHK(h, dalloc(&h->d_sph, (size_t)4 * n_sph));
@@ -313,12 +326,21 @@ int gusto_get_dual(gusto_handle h, double* dual) {
     return GUSTO_OK;
 }
 
+int gusto_get_hist_cap(gusto_handle h, int* hist_cap) {
+    if (!h || !hist_cap) return GUSTO_ERR_ARG;
+    *hist_cap = h->hist_cap;
+    return GUSTO_OK;
+}
+
 int gusto_get_history(gusto_handle h, gusto_history* o) {
     if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
     if (!h || !o || !h->have_problems) return GUSTO_ERR_STATE;
+    // o->hist_cap is the row capacity of the CALLER's arrays; rows are written with that pitch
+    if (o->hist_cap < h->hist_cap) {
+        h->err = "gusto_get_history: hist_cap of the output arrays is smaller than the handle's (gusto_get_hist_cap)";
+        return GUSTO_ERR_ARG;
+    }
     HIPCHK(h, hipSetDevice(h->device));
-    o->hist_cap = h->hist_cap;
-    const size_t cnt = (size_t)h->B * h->hist_cap;
     std::vector<int> st((size_t)h->B * ST_NI);
     HIPCHK(h, hipMemcpy(st.data(), h->d_sti, sizeof(int) * st.size(), hipMemcpyDeviceToHost));
     for (int b = 0; b < h->B; b++) {
@@ -326,12 +348,29 @@ int gusto_get_history(gusto_handle h, gusto_history* o) {
         if (o->nJ) o->nJ[b] = st[(size_t)b * ST_NI + ST_NJ];
         if (o->n_rho) o->n_rho[b] = st[(size_t)b * ST_NI + ST_NRHO];
     }
-#define CPD(dst, src) if (dst) HIPCHK(h, hipMemcpy(dst, src, sizeof(*(dst)) * cnt, hipMemcpyDeviceToHost))
+    const size_t H = h->hist_cap, Ho = o->hist_cap;
+#define CPD(dst, src) if (dst) HIPCHK(h, hipMemcpy2D(dst, sizeof(*(dst)) * Ho, src, sizeof(*(dst)) * H, sizeof(*(dst)) * H, h->B, hipMemcpyDeviceToHost))
     CPD(o->J_true, h->d_Jt); CPD(o->J_full, h->d_Jf); CPD(o->convergence_measure, h->d_conv); CPD(o->Delta, h->d_Delta);
     CPD(o->omega, h->d_omega); CPD(o->rho, h->d_rho); CPD(o->accept_solution, h->d_acc); CPD(o->scp_status, h->d_scp);
     CPD(o->solver_status, h->d_sol); CPD(o->trust_region_satisfied, h->d_tr); CPD(o->convex_ineq_satisfied, h->d_cvx);
     CPD(o->ipm_iters, h->d_ipm);
 #undef CPD
+    return GUSTO_OK;
+}
+
+// SCPParam_GuSTO supplied by the caller (scp_gusto.jl:60 keeps a param.alg that is already defined): overwrite the
+// LAST entries of Delta_vec / omega_vec of every problem, i.e. the trust region and penalty the next trip uses
+int gusto_set_trust_state(gusto_handle h, const double* Delta, const double* omega) {
+    if (!h || (!Delta && !omega)) return GUSTO_ERR_ARG;
+    if (!h->have_problems) { h->err = "gusto_set_trust_state: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
+    { int rc = setter_enter(h); if (rc) return rc; }
+    std::vector<int> st((size_t)h->B * ST_NI);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_sti, sizeof(int) * st.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->B; b++) {
+        const size_t at = (size_t)b * h->hist_cap + st[(size_t)b * ST_NI + ST_NHIST] - 1;
+        if (Delta) HIPCHK(h, hipMemcpy(h->d_Delta + at, Delta + b, sizeof(double), hipMemcpyHostToDevice));
+        if (omega) HIPCHK(h, hipMemcpy(h->d_omega + at, omega + b, sizeof(double), hipMemcpyHostToDevice));
+    }
     return GUSTO_OK;
 }
 

@@ -215,6 +215,8 @@ scp_kernel(const KParams P) {
             if (!P.force) { stop = GUSTO_STOP_CONVERGED; break; }
         }
     }
+    // a history vector is full although iterations remain: say so instead of posing as MaxIter
+    if (stop == GUSTO_STOP_MAXITER && iterations < iter_cap) stop = GUSTO_STOP_HIST_FULL;
     pf.tick(PF_SCP);
     pf.flush(P.prof);
     if (tid == 0) {

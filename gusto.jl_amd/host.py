@@ -180,19 +180,31 @@ def init_traj_straightline(TOP):
 
 
 # ---- the plug-in: solve_method!(SCPS, SCPP, solver, max_iter, force; kw...) ---------------------------------------
-def _fill_solution(SCPS, SCPP, bs, b, elapsed):
+def _fetch(bs):
+    """Everything a solution needs from one handle, copied device -> host ONCE per solve (not once per problem)."""
     X, U = bs.traj()
-    st, h = bs.status(), bs.history()
-    SCPS.traj.X, SCPS.traj.U = X[b].T.copy(), U[b].T.copy()
+    return dict(X=X, U=U, st=bs.status(), h=bs.history(), dual=bs.dual())
+
+
+def _fill_solution(SCPS, SCPP, snap, b, elapsed):
+    st, h = snap["st"], snap["h"]
+    stop = int(st["stop_reason"][b])
+    if stop == 4:
+        raise _capi.GustoError("history capacity of the handle reached before iter_cap (GUSTO_STOP_HIST_FULL): the "
+                               "solver would silently stop iterating; create the solution with a larger hist_cap")
+    SCPS.traj.X, SCPS.traj.U = snap["X"][b].T.copy(), snap["U"][b].T.copy()
     nh, nJ, nr = h["n_hist"][b], h["nJ"][b], h["n_rho"][b]
     SCPS.J_true, SCPS.J_full = list(h["J_true"][b, :nJ]), list(h["J_full"][b, :nJ])
-    SCPS.solver_status = [SOLVER_STATUS[int(v)] for v in h["solver_status"][b, :nh]]
+    # a failed subproblem pushes its status and nothing else before the early return (scp_gusto.jl:106-111)
+    ns = nh + 1 if stop == 2 else nh
+    SCPS.solver_status = [SOLVER_STATUS[int(v)] for v in h["solver_status"][b, :ns]]
     SCPS.scp_status = [SCP_STATUS[int(v)] for v in h["scp_status"][b, :nh]]
     SCPS.accept_solution = [bool(v) for v in h["accept_solution"][b, :nh]]
     SCPS.convergence_measure = list(h["convergence_measure"][b, :nh])
     SCPS.iterations = int(st["iterations"][b])
     SCPS.converged, SCPS.successful = bool(st["converged"][b]), bool(st["successful"][b])
-    SCPS.dual = bs.dual()[b]
+    SCPS.stop_reason = _capi.STOP_REASON[stop]
+    SCPS.dual = snap["dual"][b].copy()
     SCPS.total_time += elapsed
     SCPS.iter_elapsed_times = [0.0] + [SCPS.total_time / max(1, SCPS.iterations)] * SCPS.iterations
     SCPP.Delta_vec, SCPP.omega_vec = list(h["Delta"][b, :nh]), list(h["omega"][b, :nh])
@@ -200,6 +212,11 @@ def _fill_solution(SCPS, SCPP, bs, b, elapsed):
     SCPP.trust_region_satisfied_vec = [bool(v) for v in h["trust_region_satisfied"][b, :nh]]
     SCPP.convex_ineq_satisfied_vec = [bool(v) for v in h["convex_ineq_satisfied"][b, :nh]]
     SCPP.obstacle_toggle_distance = SCPP.Delta_vec[-1] / 8 + SCPP.model_params.clearance
+
+
+def _hist_cap(max_iter):
+    """Every call adds its iterations plus one leading J_true/rho entry; room for a few resumed calls."""
+    return max(64, 4 * max_iter + 16)
 
 
 def solve_gusto_hip(SCPS, SCPP, solver="hip", max_iter=30, force=False, device=0, **kwarg):
@@ -210,14 +227,14 @@ def solve_gusto_hip(SCPS, SCPP, solver="hip", max_iter=30, force=False, device=0
     bs = SCPS._solver
     if bs is None:
         env = SCPP.PD.env
-        bs = BatchSolver(model.model_id, N, 1, hist_cap=max(64, 2 * max_iter + 8), device=device, boxes=env.boxes,
+        bs = BatchSolver(model.model_id, N, 1, hist_cap=_hist_cap(max_iter), device=device, boxes=env.boxes,
                          spheres=env.spheres, scp_params=SCPP.scp_params, model_params=SCPP.model_params)
         lo, hi = _goal_bounds(SCPP.PD.goal_set, n, SCPP.tf_guess)
         bs.set_problems(SCPP.PD.x_init[None], lo[None], hi[None], [SCPP.tf_guess],
                         SCPS.traj.X.T[None].copy(), SCPS.traj.U.T[None].copy())
         SCPS._solver = bs
     bs.solve(max_iter, force)
-    _fill_solution(SCPS, SCPP, bs, 0, bs.last_solve_ms() * 1e-3)
+    _fill_solution(SCPS, SCPP, _fetch(bs), 0, bs.last_solve_ms() * 1e-3)
 
 
 def solve_SCP(TOS, TOP, solve_method, init_method, solver="hip", max_iter=30, force=False, **kwarg):
@@ -245,17 +262,28 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
     `devices` = list of GPU ordinals: the problems are sharded in contiguous blocks (shard_bounds) over
     one handle per entry, every shard is enqueued with gusto_solve_async and the shards run concurrently -- the
     single-process form of the multi-GPU path (an ordinal may repeat: two shards on one GPU overlap like two batches)."""
+    if solve_method not in (None, solve_gusto_hip):
+        raise NotImplementedError("solve_SCP_batch! runs the batched GuSTO kernels: solve_method must be solve_gusto_hip")
+    if len(TOSs) != len(TOPs) or not TOPs:
+        raise ValueError("solve_SCP_batch!: need as many solutions as problems, at least one")
     TOP0 = TOPs[0]
     model, N = TOP0.PD.model, TOP0.N
     n = model.x_dim
     B = len(TOPs)
+    for t in TOPs[1:]:      # one gusto_handle = one model, one horizon, one Workspace
+        if type(t.PD.model) is not type(model) or t.N != N:
+            raise ValueError("solve_SCP_batch!: all problems must share the model type and N")
+        if not (np.array_equal(t.PD.env.boxes, TOP0.PD.env.boxes) and np.array_equal(t.PD.env.spheres, TOP0.PD.env.spheres)):
+            raise ValueError("solve_SCP_batch!: all problems must share the environment")
     devs = list(devices) if devices else [device]
     sp, mp = _capi.default_params(model.model_id)
     x0 = np.stack([t.PD.x_init for t in TOPs])
     bounds = [_goal_bounds(t.PD.goal_set, n, t.tf_guess) for t in TOPs]
     lo, hi = np.stack([b[0] for b in bounds]), np.stack([b[1] for b in bounds])
     tf = np.array([t.tf_guess for t in TOPs])
-    inits = [init_method(t) if callable(init_method) else init_method for t in TOPs]
+    # every problem owns its initial trajectory (a Trajectory passed for all of them is copied, never aliased)
+    inits = [init_method(t) if callable(init_method) else Trajectory(init_method.X.copy(), init_method.U.copy(), init_method.Tf)
+             for t in TOPs]
     X0 = np.stack([t.X.T for t in inits])
     U0 = np.stack([t.U.T for t in inits])
     shards = []
@@ -263,7 +291,7 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
         b0, b1 = shard_bounds(B, len(devs), r)
         if b1 <= b0:
             continue
-        bs = BatchSolver(model.model_id, N, b1 - b0, hist_cap=max(64, 2 * max_iter + 8), device=dv,
+        bs = BatchSolver(model.model_id, N, b1 - b0, hist_cap=_hist_cap(max_iter), device=dv,
                          boxes=TOP0.PD.env.boxes, spheres=TOP0.PD.env.spheres, scp_params=sp, model_params=mp)
         bs.set_problems(x0[b0:b1], lo[b0:b1], hi[b0:b1], tf[b0:b1], X0[b0:b1], U0[b0:b1])
         bs.solve_async(max_iter, force)
@@ -271,10 +299,12 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
     out = [None] * B
     for b0, b1, bs in shards:
         bs.wait()
+        snap = _fetch(bs)                    # one device -> host copy per shard
+        per = bs.last_solve_ms() * 1e-3 / (b1 - b0)
         for b in range(b0, b1):
             SCPP = SCPProblem(TOPs[b])
             SCPS = SCPSolution(SCPP, inits[b])
-            _fill_solution(SCPS, SCPP, bs, b - b0, bs.last_solve_ms() * 1e-3 / (b1 - b0))
+            _fill_solution(SCPS, SCPP, snap, b - b0, per)
             TOSs[b].traj, TOSs[b].SCPS = SCPS.traj, SCPS
             out[b] = SCPS
     return out
@@ -282,8 +312,10 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
 
 def gather_batch_results(local, world_size, rank, group=None):
     """Final gather of per-rank results to rank 0: the only communication of a multi-GPU run.
-    `local` is a dict of numpy arrays with the problem index leading.  Uses torch.distributed (RCCL when the
-    tensors live on GPUs under the nccl backend, gloo on CPU); returns the concatenated dict on rank 0."""
+    `local` maps names to arrays with the problem index leading: torch tensors ALREADY ON THE GPU (the views
+    BatchSolver.traj_dev() returns -- they go to RCCL as they are, no host staging) or numpy arrays (gloo on CPU, or
+    small host-side vectors, moved once).  Ranks may hold different numbers of problems.  Rank 0 gets the concatenated
+    dict in the type it passed in, the other ranks None."""
     import torch
     import torch.distributed as dist
     if world_size == 1:
@@ -291,16 +323,21 @@ def gather_batch_results(local, world_size, rank, group=None):
     out = {}
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    count = torch.tensor([next(iter(local.values())).shape[0]], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world_size)]
+    dist.all_gather(sizes, count, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
     for k, v in local.items():
-        t = torch.from_numpy(np.ascontiguousarray(v)).to(dev)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world_size)]
-        dist.all_gather(sizes, torch.tensor([t.shape[0]], dtype=torch.int64, device=dev), group=group)
-        sizes = [int(s.item()) for s in sizes]
-        mx = max(sizes)
-        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-        pad[:t.shape[0]] = t
-        bufs = [torch.zeros_like(pad) for _ in range(world_size)] if rank == 0 else None
-        dist.gather(pad, bufs, dst=0, group=group)
+        as_numpy = not torch.is_tensor(v)
+        t = (torch.from_numpy(np.ascontiguousarray(v)) if as_numpy else v).to(dev)
+        if t.shape[0] != mx:                   # ragged tail rank: pad to the common block size
+            pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+            pad[:t.shape[0]] = t
+            t = pad
+        bufs = [torch.empty_like(t) for _ in range(world_size)] if rank == 0 else None
+        dist.gather(t.contiguous(), bufs, dst=0, group=group)
         if rank == 0:
-            out[k] = np.concatenate([b[:s].cpu().numpy() for b, s in zip(bufs, sizes)], axis=0)
+            cat = torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+            out[k] = cat.cpu().numpy() if as_numpy else cat
     return out if rank == 0 else None

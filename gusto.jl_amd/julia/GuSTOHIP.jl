@@ -64,6 +64,9 @@ function gusto_goal_bounds(goal_set, x_dim, tf_guess)
   lo, hi
 end
 
+# every call adds its iterations plus one leading J_true / rho entry: room for a few resumed calls
+gusto_hist_cap(max_iter) = max(64, 4max_iter + 16)
+
 const GUSTO_HANDLES = IdDict{SCPSolution,Ptr{Cvoid}}()   # device-side state per solution: resume (scp_gusto.jl:67)
 
 function solve_gusto_hip!(SCPS::SCPSolution, SCPP::SCPProblem, solver="hip", max_iter=30, force=false; device=0, kwarg...)
@@ -74,9 +77,8 @@ function solve_gusto_hip!(SCPS::SCPSolution, SCPP::SCPProblem, solver="hip", max
   h = get(GUSTO_HANDLES, SCPS, C_NULL)
   if h == C_NULL
     href = Ref{Ptr{Cvoid}}(C_NULL)
-    cap = max(64, 2max_iter + 8)
     gusto_check(ccall((:gusto_create, libgusto_hip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint),
-                      href, gusto_model_id(model), N, 1, cap, device), href[], "create")
+                      href, gusto_model_id(model), N, 1, gusto_hist_cap(max_iter), device), href[], "create")
     h = href[]
     sp = GustoScpParams(alg.Δ0, alg.ω0, alg.ω_max, alg.ε, alg.ρ0, alg.ρ1, alg.β_succ, alg.β_fail, alg.γ_fail,
                         SCPP.param.convergence_threshold)
@@ -101,8 +103,10 @@ function solve_gusto_hip!(SCPS::SCPSolution, SCPP::SCPProblem, solver="hip", max
   its, conv, succ, stop, ipm = (zeros(Cint, 1) for _ in 1:5)
   gusto_check(ccall((:gusto_get_status, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}),
                     h, its, conv, succ, stop, ipm), h, "get_status")
-  cap = max(64, 2max_iter + 8)
-  d() = zeros(Cdouble, cap); i() = zeros(Cint, cap)
+  capref = Ref{Cint}(0)    # the capacity fixed when the handle was created, NOT a function of this call's max_iter
+  gusto_check(ccall((:gusto_get_hist_cap, libgusto_hip), Cint, (Ptr{Cvoid}, Ref{Cint}), h, capref), h, "get_hist_cap")
+  cap = Int(capref[])
+  d() = zeros(Cdouble, cap + 1); i() = zeros(Cint, cap + 1)
   nh, nJ, nr = zeros(Cint, 1), zeros(Cint, 1), zeros(Cint, 1)
   Jt, Jf, cm, Dv, wv, rv = d(), d(), d(), d(), d(), d()
   acc, scp, sol, trs, cvx, ipi = i(), i(), i(), i(), i(), i()
@@ -112,8 +116,11 @@ function solve_gusto_hip!(SCPS::SCPSolution, SCPP::SCPProblem, solver="hip", max
     gusto_check(ccall((:gusto_get_history, libgusto_hip), Cint, (Ptr{Cvoid}, Ref{GustoHistory}), h, hist), h, "get_history")
   end
   H, J, R = nh[1], nJ[1], nr[1]
+  stop[1] == 4 && error("gusto_hip: history capacity ($cap) reached before iter_cap; release the handle " *
+                        "(gusto_release!) and solve again with a larger max_iter on the first call")
   SCPS.J_true, SCPS.J_full = Jt[1:J], Jf[1:J]
-  SCPS.solver_status = [GUSTO_SOLVER_STATUS[s+1] for s in sol[1:H]]
+  # a failed subproblem pushes its status and nothing else before the early return (scp_gusto.jl:106-111)
+  SCPS.solver_status = [GUSTO_SOLVER_STATUS[s+1] for s in sol[1:(stop[1] == 2 ? H + 1 : H)]]
   SCPS.scp_status = [GUSTO_SCP_STATUS[s+1] for s in scp[1:H]]
   SCPS.accept_solution = Bool.(acc[1:H])
   SCPS.convergence_measure = cm[1:H]
@@ -132,38 +139,54 @@ end
 
 gusto_release!(SCPS::SCPSolution) = (h = pop!(GUSTO_HANDLES, SCPS, C_NULL); h != C_NULL && ccall((:gusto_destroy, libgusto_hip), Cint, (Ptr{Cvoid},), h); nothing)
 
-# Batch entry point (the reference has none): every TOP must share model, N and environment.
-function solve_SCP_batch!(TOSs::Vector, TOPs::Vector, init_method=init_traj_straightline; max_iter=30, force=false, device=0)
+# Batch entry point (the reference has none): every TOP must share model, N and environment.  `devices` = GPU ordinals:
+# the problems are split in contiguous blocks of ceil(B/G) (SURVEY.md 8(e)), one handle per entry, every block enqueued
+# with gusto_solve_async so the GPUs run concurrently; the results come back in problem order.
+function solve_SCP_batch!(TOSs::Vector, TOPs::Vector, init_method=init_traj_straightline; max_iter=30, force=false, device=0, devices=nothing)
   TOP0 = TOPs[1]; model, N = TOP0.PD.model, TOP0.N
   n, m, B = model.x_dim, model.u_dim, length(TOPs)
-  href = Ref{Ptr{Cvoid}}(C_NULL)
-  cap = max(64, 2max_iter + 8)
-  gusto_check(ccall((:gusto_create, libgusto_hip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint),
-                    href, gusto_model_id(model), N, B, cap, device), href[], "create")
-  h = href[]
+  all(T -> typeof(T.PD.model) == typeof(model) && T.N == N && T.PD.env === TOP0.PD.env, TOPs) ||
+    error("solve_SCP_batch!: all problems must share the model type, N and the environment")
+  devs = devices === nothing ? [device] : collect(devices)
+  G = length(devs); per = cld(B, G)
   boxes, spheres = gusto_env_tables(TOP0.PD.env)
-  gusto_check(ccall((:gusto_set_env, libgusto_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}),
-                    h, length(boxes) ÷ 6, boxes, length(spheres) ÷ 4, spheres), h, "set_env")
   x0 = hcat((Float64.(T.PD.x_init) for T in TOPs)...)
   bounds = [gusto_goal_bounds(T.PD.goal_set, n, T.tf_guess) for T in TOPs]
   lo, hi = hcat(first.(bounds)...), hcat(last.(bounds)...)
+  tf = Float64[T.tf_guess for T in TOPs]
   inits = [init_method(T) for T in TOPs]
   X0, U0 = cat((t.X for t in inits)..., dims=3), cat((t.U for t in inits)..., dims=3)   # [n,N,B]: problem slowest
-  gusto_check(ccall((:gusto_set_problems, libgusto_hip), Cint,
-                    (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-                    h, B, x0, lo, hi, Float64[T.tf_guess for T in TOPs], X0, U0), h, "set_problems")
-  gusto_check(ccall((:gusto_solve, libgusto_hip), Cint, (Ptr{Cvoid}, Cint, Cint), h, max_iter, force), h, "solve")
-  X, U = zeros(n, N, B), zeros(m, N, B)
-  gusto_check(ccall((:gusto_get_traj, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), h, X, U), h, "get_traj")
-  its, conv, succ = zeros(Cint, B), zeros(Cint, B), zeros(Cint, B)
-  gusto_check(ccall((:gusto_get_status, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cvoid}, Ptr{Cvoid}),
-                    h, its, conv, succ, C_NULL, C_NULL), h, "get_status")
-  for b in 1:B
-    SCPP = SCPProblem(TOPs[b])
-    SCPS = SCPSolution(SCPP, Trajectory(X[:, :, b], U[:, :, b], TOPs[b].tf_guess))
-    SCPS.iterations, SCPS.converged, SCPS.successful = its[b], conv[b] != 0, succ[b] != 0
-    TOSs[b].traj, TOSs[b].SCPS = SCPS.traj, SCPS
+  shards = Tuple{Int,Int,Ptr{Cvoid}}[]
+  for (r, dv) in enumerate(devs)
+    b0, b1 = min(B, (r - 1) * per) + 1, min(B, r * per)
+    b1 < b0 && continue
+    href = Ref{Ptr{Cvoid}}(C_NULL)
+    gusto_check(ccall((:gusto_create, libgusto_hip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint),
+                      href, gusto_model_id(model), N, b1 - b0 + 1, gusto_hist_cap(max_iter), dv), href[], "create")
+    h = href[]
+    gusto_check(ccall((:gusto_set_env, libgusto_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}),
+                      h, length(boxes) ÷ 6, boxes, length(spheres) ÷ 4, spheres), h, "set_env")
+    gusto_check(ccall((:gusto_set_problems, libgusto_hip), Cint,
+                      (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                      h, b1 - b0 + 1, x0[:, b0:b1], lo[:, b0:b1], hi[:, b0:b1], tf[b0:b1], X0[:, :, b0:b1], U0[:, :, b0:b1]), h, "set_problems")
+    gusto_check(ccall((:gusto_solve_async, libgusto_hip), Cint, (Ptr{Cvoid}, Cint, Cint), h, max_iter, force), h, "solve_async")
+    push!(shards, (b0, b1, h))
   end
-  ccall((:gusto_destroy, libgusto_hip), Cint, (Ptr{Cvoid},), h)
+  for (b0, b1, h) in shards
+    Bs = b1 - b0 + 1
+    gusto_check(ccall((:gusto_wait, libgusto_hip), Cint, (Ptr{Cvoid},), h), h, "wait")
+    X, U = zeros(n, N, Bs), zeros(m, N, Bs)
+    gusto_check(ccall((:gusto_get_traj, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), h, X, U), h, "get_traj")
+    its, conv, succ = zeros(Cint, Bs), zeros(Cint, Bs), zeros(Cint, Bs)
+    gusto_check(ccall((:gusto_get_status, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cvoid}, Ptr{Cvoid}),
+                      h, its, conv, succ, C_NULL, C_NULL), h, "get_status")
+    for b in b0:b1
+      SCPP = SCPProblem(TOPs[b])
+      SCPS = SCPSolution(SCPP, Trajectory(X[:, :, b-b0+1], U[:, :, b-b0+1], TOPs[b].tf_guess))
+      SCPS.iterations, SCPS.converged, SCPS.successful = its[b-b0+1], conv[b-b0+1] != 0, succ[b-b0+1] != 0
+      TOSs[b].traj, TOSs[b].SCPS = SCPS.traj, SCPS
+    end
+    ccall((:gusto_destroy, libgusto_hip), Cint, (Ptr{Cvoid},), h)
+  end
   nothing
 end

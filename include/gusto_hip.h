@@ -44,7 +44,8 @@ enum { GUSTO_SCP_NA = 0, GUSTO_SCP_OK = 1, GUSTO_SCP_INACCURATE_MODEL = 2, GUSTO
 /* SCPS.solver_status entries (MOI termination codes accepted/rejected at scp_gusto.jl:106-111) */
 enum { GUSTO_SOLVER_NA = 0, GUSTO_SOLVER_OPTIMAL = 1, GUSTO_SOLVER_ALMOST = 2, GUSTO_SOLVER_FAILED = 3 };
 /* why the outer loop of a problem stopped */
-enum { GUSTO_STOP_MAXITER = 0, GUSTO_STOP_CONVERGED = 1, GUSTO_STOP_SUBPROBLEM_FAILED = 2, GUSTO_STOP_OMEGA_MAX = 3 };
+enum { GUSTO_STOP_MAXITER = 0, GUSTO_STOP_CONVERGED = 1, GUSTO_STOP_SUBPROBLEM_FAILED = 2, GUSTO_STOP_OMEGA_MAX = 3,
+       GUSTO_STOP_HIST_FULL = 4 /* a history vector reached hist_cap before iter_cap: create the handle with more */ };
 
 /* SCPParam + SCPParam_GuSTO (types.jl:65-73, scp_gusto.jl:4-24; per-model values e.g. freeflyer_se2.jl:22-39) */
 typedef struct {
@@ -93,7 +94,8 @@ int gusto_set_env(gusto_handle h, int n_box, const double* box_min_max, int n_sp
  * order of decreasing penalty weight omega -- the problems whose omega was raised early are the long ones.
  * probe_iters = 0 disables it.  Default (2, 2048). */
 int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch);
-/* run on a caller-owned hipStream_t (NULL = the handle's own stream) */
+/* run on a caller-owned hipStream_t (NULL = a new stream owned by the handle).  Like every setter it first completes
+ * a pending gusto_solve_async on the stream that solve was enqueued on. */
 int gusto_set_stream(gusto_handle h, void* hip_stream);
 
 /* ProblemDefinition + init trajectory + SCPSolution(SCPP, traj_init) for B problems (types.jl:32-39,233):
@@ -130,12 +132,20 @@ int gusto_get_dual(gusto_handle h, double* dual);
  * arrays; n_hist[b] entries are valid in the per-iteration vectors, nJ[b] in J_true/J_full and n_rho[b] in
  * rho (those get one extra leading entry per gusto_solve call, scp_gusto.jl:73-75).  Any pointer may be NULL. */
 typedef struct {
-    int hist_cap;
+    int hist_cap; /* IN: row capacity of the arrays below, >= the handle's (gusto_get_hist_cap); else GUSTO_ERR_ARG */
     int *n_hist, *nJ, *n_rho;
     double *J_true, *J_full, *convergence_measure, *Delta, *omega, *rho;
     int *accept_solution, *scp_status, *solver_status, *trust_region_satisfied, *convex_ineq_satisfied, *ipm_iters;
 } gusto_history;
 int gusto_get_history(gusto_handle h, gusto_history* out);
+int gusto_get_hist_cap(gusto_handle h, int* hist_cap);
+/* When a problem stops with GUSTO_STOP_SUBPROBLEM_FAILED the reference has pushed one more solver_status entry than
+ * any other vector (scp_gusto.jl:106): it is solver_status[b][n_hist[b]]. */
+
+/* SCPParam_GuSTO supplied by the caller -- scp_gusto.jl:60 keeps a `param.alg` that is already defined, so a user
+ * can start from her own Delta_vec[end] / omega_vec[end].  Overwrites the last Delta / omega history entry of every
+ * problem (after gusto_set_problems: the initial Delta0 / omega0).  Either pointer may be NULL.  [B] each. */
+int gusto_set_trust_state(gusto_handle h, const double* Delta, const double* omega);
 
 /* One convex subproblem per problem (what scp_gusto.jl:82-104 builds and solves in one trip), linearised at
  * (Xp,Up)[b] with the given Delta/omega/obstacle_toggle_distance[b].  Used by the parity tests.

@@ -42,6 +42,8 @@ struct go_problem {
     go_model_params mp;
     go_ipm_opts io;
     go_dist_model dm;
+    int trace_cap, n_trace;      /* go_set_trace: (traj_prev, subproblem optimum) of every trip, for lock-step tests */
+    double *trXp, *trUp, *trXn, *trUn;
     int n_box, n_sph, n_obs;
     double *box, *sph;
     double x_init[NX], goal_lo[NX], goal_hi[NX], tf, dt;
@@ -1281,9 +1283,24 @@ void go_destroy(go_problem* p) {
     free(p->Hx); free(p->Hu); free(p->gx); free(p->gu); free(p->rd); free(p->QQ); free(p->qq); free(p->cc);
     free(p->Ps); free(p->ps); free(p->Pis); free(p->Ks); free(p->Sinv); free(p->Ds); free(p->d0s);
     free(p->dX); free(p->dU); free(p->nun); free(p->nu); free(p->Xw); free(p->Uw);
+    free(p->trXp); free(p->trUp); free(p->trXn); free(p->trUn);
     free(p);
 }
 void go_set_ipm_opts(go_problem* p, const go_ipm_opts* o) { p->io = *o; }
+void go_set_trace(go_problem* p, int cap) {
+    free(p->trXp); free(p->trUp); free(p->trXn); free(p->trUn);
+    p->trace_cap = cap; p->n_trace = 0;
+    p->trXp = malloc(sizeof(double) * (size_t)(cap ? cap : 1) * p->n * p->N); p->trXn = malloc(sizeof(double) * (size_t)(cap ? cap : 1) * p->n * p->N);
+    p->trUp = malloc(sizeof(double) * (size_t)(cap ? cap : 1) * p->m * p->N); p->trUn = malloc(sizeof(double) * (size_t)(cap ? cap : 1) * p->m * p->N);
+}
+int go_get_trace(const go_problem* p, int t, double* Xp, double* Up, double* Xn, double* Un) {
+    if (t < 0 || t >= p->n_trace) return -1;
+    const size_t nx = (size_t)p->n * p->N, nu = (size_t)p->m * p->N;
+    memcpy(Xp, p->trXp + t * nx, sizeof(double) * nx); memcpy(Up, p->trUp + t * nu, sizeof(double) * nu);
+    memcpy(Xn, p->trXn + t * nx, sizeof(double) * nx); memcpy(Un, p->trUn + t * nu, sizeof(double) * nu);
+    return 0;
+}
+int go_trace_len(const go_problem* p) { return p->n_trace; }
 
 static void grow_hist(go_problem* p, int need) {
     if (need <= p->cap) return;
@@ -1307,7 +1324,7 @@ int go_set_problem(go_problem* p, const double* x_init, const double* goal_lo, c
     free_hist(p);
     grow_hist(p, 8);
     p->iterations = 0; p->converged = 0; p->successful = 0; p->stop_reason = GO_STOP_MAXITER; p->total_ipm = 0; p->warm = 0;
-    p->nJ_true = 0; p->nJ_full = 0;
+    p->nJ_true = 0; p->nJ_full = 0; p->n_trace = 0;
     p->n_hist = 1;
     p->solver_status[0] = GO_SOLVER_NA; p->scp_status[0] = GO_SCP_NA; p->accept[0] = 1; p->conv[0] = 0.0; p->ipm_it[0] = 0;
     p->Delta[0] = p->sp.Delta0; p->omega[0] = p->sp.omega0; p->tr_sat[0] = 0; p->cvx_sat[0] = 0;
@@ -1342,6 +1359,11 @@ int go_solve(go_problem* p, int max_iter, int force) {
         }
         memcpy(Xn, p->Xw, sizeof(double) * n * N);
         memcpy(Un, p->Uw, sizeof(double) * m * N);
+        if (p->n_trace < p->trace_cap) {
+            const size_t t = (size_t)p->n_trace++;
+            memcpy(p->trXp + t * n * N, p->X, sizeof(double) * n * N); memcpy(p->trUp + t * m * N, p->U, sizeof(double) * m * N);
+            memcpy(p->trXn + t * n * N, Xn, sizeof(double) * n * N); memcpy(p->trUn + t * m * N, Un, sizeof(double) * m * N);
+        }
         p->conv[h] = go_convergence_metric(p, Xn, p->X);                 /* :115 */
         p->J_full[p->nJ_full++] = info.obj;                               /* :116 */
         p->tr_sat[h] = trust_region_satisfied(p, Xn, p->X, Delta);        /* :120 */

@@ -94,6 +94,10 @@ go_problem* go_create(int model, int N, const go_scp_params* sp, const go_model_
 void go_destroy(go_problem* p);
 void go_set_ipm_opts(go_problem* p, const go_ipm_opts* o);
 void go_set_distance_model(go_problem* p, const go_dist_model* dm);
+/* record (traj_prev, subproblem optimum) of up to `cap` trips of the following go_solve calls (lock-step parity tests) */
+void go_set_trace(go_problem* p, int cap);
+int go_trace_len(const go_problem* p);
+int go_get_trace(const go_problem* p, int t, double* Xp, double* Up, double* Xn, double* Un);
 
 /* goal_lo==goal_hi -> hard equality, +-inf -> free, else hard box (BoxGoal).
  * X0/U0 NULL -> straight line init (freeflyer_se2.jl:97-111). Resets histories. */

@@ -75,6 +75,9 @@ def lib():
         L.go_destroy.argtypes = [C.c_void_p]
         L.go_set_ipm_opts.argtypes = [C.c_void_p, C.POINTER(IpmOpts)]
         L.go_set_distance_model.argtypes = [C.c_void_p, C.POINTER(DistModel)]
+        L.go_set_trace.argtypes = [C.c_void_p, C.c_int]
+        L.go_trace_len.argtypes = [C.c_void_p]
+        L.go_get_trace.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
         L.go_set_problem.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, C.c_void_p, C.c_void_p]
         L.go_solve.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.go_get_traj.argtypes = [C.c_void_p, _dp, _dp]
@@ -144,6 +147,19 @@ class Oracle:
         for k, v in kw.items():
             setattr(dm, k, v)
         self.L.go_set_distance_model(self.h, C.byref(dm))
+
+    def set_trace(self, cap):
+        """Record (traj_prev, subproblem optimum) of every trip of the following solves: trace()."""
+        self.L.go_set_trace(self.h, int(cap))
+
+    def trace(self):
+        """Per trip t (history index t + 1): dict(Xp, Up, Xn, Un); Delta/omega of the trip are r["Delta"][t], r["omega"][t]."""
+        out = []
+        for t in range(self.L.go_trace_len(self.h)):
+            a = [np.zeros((self.N, self.n)), np.zeros((self.N, self.m)), np.zeros((self.N, self.n)), np.zeros((self.N, self.m))]
+            self.L.go_get_trace(self.h, t, *a)
+            out.append(dict(Xp=a[0], Up=a[1], Xn=a[2], Un=a[3]))
+        return out
 
     # -- problem / solve ---------------------------------------------------------------------
     def set_problem(self, x_init, goal_lo, goal_hi, tf, X0=None, U0=None):

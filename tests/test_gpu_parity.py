@@ -6,9 +6,11 @@ Tolerances (fp64, BASELINE.json "stated fp64 tolerance"):
                       the problem scaled by 1/max(1,omega); the horizon amplifies a control error by ~tf^2/2m),
                       objective within 1e-8*max(1, omega) rel (the solve is scaled by 1/max(1, omega))
   trajectory level  : same `converged` flag, final X within 1e-3 abs, J_true within 1e-4 rel
+  lock-step level   : every trip of every problem from the oracle's own (traj_prev, Delta, omega): see
+                      _lockstep_parity (convergence_measure 1e-8, rho 1e-6 rel, verdicts exact)
 Both sides run the same interior point algorithm, so typical differences are 1e-10..1e-13; the stated
-tolerances are what the suite gates on.  Problems whose penalty weight omega climbed above 1e3 are compared
-with a tolerance scaled by omega (the subproblem is then lexicographically scaled)."""
+tolerances are what the suite gates on.  No problem is skipped: where the penalty weight omega is large the
+subproblem is solved scaled by 1/omega, and the tolerances carry that factor explicitly."""
 import numpy as np
 import pytest
 
@@ -91,7 +93,98 @@ def test_subproblem_parity_astrobee_manifold():
     _sub_parity(g.ASTROBEE_SE3_MANIFOLD, 50, boxes, sph, x0, glo, ghi, tf, 1e3, 1.0, 1e3 / 8 + 0.03, atol=1e-5)
 
 
-def _scp_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30):
+def _oracle_runs(model, N, env, spheres, x0, glo, ghi, tf, max_iter, cold=True):
+    """Oracle solve of every problem with its per-trip trace (traj_prev, subproblem optimum).  The run itself warm-
+    starts every interior point solve after the first; the device's lock-step trips start cold, so each traced trip
+    is ALSO re-solved cold through the oracle's pieces (same start on both sides): keys Xc, Uc, conv_c, rho_c, J_c, obj_c."""
+    g, go = _mods()
+    clr = g.default_params(model)[1].clearance
+    o = go.Oracle(model, N, boxes=env, spheres=spheres)
+    runs = []
+    for b in range(len(x0)):
+        o.set_trace(max_iter + 2)
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        r = o.solve(max_iter)
+        tr = o.trace()
+        for t, e in enumerate(tr if cold else []):
+            c = o.subproblem(e["Xp"], e["Up"], r["Delta"][t], r["omega"][t], r["Delta"][t] / 8 + clr)
+            e.update(Xc=c["X"], Uc=c["U"], obj_c=c["obj"], conv_c=o.convergence_metric(c["X"], e["Xp"]),
+                     rho_c=o.trust_region_ratio(c["X"], c["U"], e["Xp"], e["Up"]), J_c=o.cost_true(c["U"]))
+        runs.append((r, tr))
+    return runs
+
+
+def _lockstep_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30, sub_atol=SUB_ATOL, max_flag_mismatch=0.005):
+    """EVERY trip of EVERY problem (no omega cut-off): the oracle's (traj_prev, Delta, omega) of the trip is fed to
+    the device, first through gusto_subproblem (the convex solve alone), then as ONE GuSTO trip of the real state
+    machine (gusto_set_trust_state + gusto_solve(1)), whose post-solve quantities -- convergence_measure, rho, the
+    trust-region / convex-row verdicts, accept, scp_status, the Delta/omega update, J_true, J_full -- must equal the
+    oracle's entries for that trip.  A flipped branch can therefore not hide drift: both sides always start a trip
+    from the same point.  Tolerances: X, U sub_atol*max(1,omega); convergence_measure 1e-8*max(1,omega) abs;
+    rho 1e-6 rel; J_true 1e-7 rel; J_full 1e-8*max(1,omega) rel; verdicts and updates exact on all but
+    `max_flag_mismatch` of the trips (a verdict whose margin is below the solver tolerance may flip)."""
+    g, go = _mods()
+    runs = _oracle_runs(model, N, env, spheres, x0, glo, ghi, tf, max_iter)
+    trips = [(b, t) for b, (r, tr) in enumerate(runs) for t in range(len(tr))]
+    T = len(trips)
+    assert T >= len(x0)
+    bi = np.array([b for b, _ in trips])
+    Xp = np.stack([runs[b][1][t]["Xp"] for b, t in trips])
+    Up = np.stack([runs[b][1][t]["Up"] for b, t in trips])
+    Xn = np.stack([runs[b][1][t]["Xc"] for b, t in trips])
+    Un = np.stack([runs[b][1][t]["Uc"] for b, t in trips])
+    C_ = lambda k: np.array([runs[b][1][t][k] for b, t in trips])      # cold oracle pieces of the trip
+    Delta = np.array([runs[b][0]["Delta"][t] for b, t in trips])
+    omega = np.array([runs[b][0]["omega"][t] for b, t in trips])
+    sp, mp = g.default_params(model)
+    s = g.BatchSolver(model, N, T, hist_cap=8, boxes=env, spheres=spheres)
+    s.set_schedule(0, 1)
+    # (1) the convex subproblem of every trip
+    s.set_problems(x0[bi], glo[bi], ghi[bi], tf[bi])
+    sub = s.subproblem(Xp, Up, Delta, omega, Delta / 8 + mp.clearance)
+    w = np.maximum(1.0, omega)
+    ok = np.isin(sub["status"], (1, 2))
+    assert ok.all(), np.nonzero(~ok)[0][:8]          # the oracle solved every traced trip
+    ex = np.abs(sub["X"] - Xn).reshape(T, -1).max(1) / w
+    eu = np.abs(sub["U"] - Un).reshape(T, -1).max(1) / w
+    assert ex.max() < sub_atol and eu.max() < sub_atol, (ex.max(), eu.max(), trips[int(ex.argmax())])
+    # (2) one trip of the device state machine from the same point
+    s.set_problems(x0[bi], glo[bi], ghi[bi], tf[bi], Xp, Up)
+    s.set_trust_state(Delta, omega)
+    s.solve(1)
+    h, st = s.history(), s.status()
+    assert (h["n_hist"] == 2).all() and (st["iterations"] == 1).all()
+    R = lambda k: np.array([runs[b][0][k][t + 1] for b, t in trips])
+    ec = np.abs(h["convergence_measure"][:, 1] - C_("conv_c")) / w
+    assert ec.max() < 1e-8, (ec.max(), trips[int(ec.argmax())])
+    eJf = np.abs(h["J_full"][:, 1] - C_("obj_c")) / (w * np.maximum(1.0, np.abs(C_("obj_c"))))
+    assert eJf.max() < 1e-8, eJf.max()
+    flags = dict(trust_region_satisfied="tr_sat", convex_ineq_satisfied="cvx_sat", accept_solution="accept",
+                 scp_status="scp_status")
+    same = np.ones(T, bool)
+    for kd, ko in flags.items():
+        same &= h[kd][:, 1] == R(ko)
+    same &= (h["Delta"][:, 1] == R("Delta")) & (h["omega"][:, 1] == R("omega"))
+    assert (~same).sum() <= max(1, int(max_flag_mismatch * T)), ((~same).sum(), T, [trips[i] for i in np.nonzero(~same)[0][:8]])
+    acc = same & (R("accept") == 1)
+    eJ = np.abs(h["J_true"][acc, 1] - C_("J_c")[acc]) / np.maximum(1e-12, np.abs(C_("J_c")[acc]))
+    assert eJ.max() < 1e-7, eJ.max()
+    # rho of the trip (device: [0] = the constructor's 0, [1] = ratio(traj, traj) of this call, [2] = this trip)
+    tr_ok = same & (h["trust_region_satisfied"][:, 1] == 1)
+    assert (h["n_rho"][tr_ok] == 3).all()
+    rd, ro = h["rho"][tr_ok, 2], C_("rho_c")[tr_ok]
+    erho = np.abs(rd - ro) / np.maximum(np.abs(ro), 1e-300)
+    assert (np.abs(rd - ro) <= 1e-6 * np.abs(ro) + 1e-13 * w[tr_ok]).all(), (erho.max(),)
+    worst_rho = float(erho.max()) if len(erho) else 0.0
+    return dict(trips=T, max_omega=float(omega.max()), ex=float(ex.max()), eu=float(eu.max()), conv=float(ec.max()),
+                rho=worst_rho, flag_mismatch=int((~same).sum()))
+
+
+def _scp_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30, max_diverged=0):
+    """Whole solves, every problem compared (no omega cut-off).  Two implementations of the same algorithm amplify
+    their rounding differences along 10-30 trips, so a problem may legitimately take a different branch late in its
+    run; such problems are COUNTED (at most `max_diverged`), and up to the first differing entry their histories must
+    still agree.  The lock-step test above is the one that proves no trip hides drift."""
     g, go = _mods()
     B = len(x0)
     s = g.BatchSolver(model, N, B, hist_cap=max_iter + 8, boxes=env, spheres=spheres)
@@ -100,33 +193,89 @@ def _scp_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30):
     X, U = s.traj()
     st, h = s.status(), s.history()
     o = go.Oracle(model, N, boxes=env, spheres=spheres)
-    n_checked = 0
+    diverged = []
     for b in range(B):
         o.set_problem(x0[b], glo[b], ghi[b], tf[b])
         r = o.solve(max_iter)
-        w = r["omega"].max()
-        if w > 1e3:  # lexicographically scaled subproblems: branch decisions may legitimately differ
+        nh = int(h["n_hist"][b])
+        c = min(nh, len(r["omega"]))
+        agree = (np.array_equal(h["scp_status"][b, :c], r["scp_status"][:c]) and np.array_equal(h["omega"][b, :c], r["omega"][:c])
+                 and np.array_equal(h["Delta"][b, :c], r["Delta"][:c]))
+        if not (agree and nh == len(r["omega"])):
+            diverged.append(b)
+            # common prefix: identical decisions up to the first differing entry, values close before it
+            first = next((i for i in range(c) if h["scp_status"][b, i] != r["scp_status"][i] or h["omega"][b, i] != r["omega"][i]
+                          or h["Delta"][b, i] != r["Delta"][i]), c)
+            assert first >= 3, (b, first)          # never in the first trips
+            np.testing.assert_allclose(h["convergence_measure"][b, :first - 1], r["conv"][:first - 1], rtol=1e-3, atol=1e-6)
             continue
-        n_checked += 1
         assert bool(st["converged"][b]) == r["converged"], b
         assert bool(st["successful"][b]) == r["successful"], b
         assert int(st["iterations"][b]) == r["iterations"], (b, st["iterations"][b], r["iterations"])
         assert int(st["stop_reason"][b]) == r["stop_reason"], b
-        assert np.abs(X[b] - r["X"]).max() < TRAJ_ATOL and np.abs(U[b] - r["U"]).max() < TRAJ_ATOL, b
-        nh = h["n_hist"][b]
-        assert nh == len(r["omega"])
-        np.testing.assert_array_equal(h["scp_status"][b, :nh], r["scp_status"])
+        w = max(1.0, r["omega"].max() / 1e3)       # problems driven to huge penalty weights are scaled by it
+        assert np.abs(X[b] - r["X"]).max() < TRAJ_ATOL * w and np.abs(U[b] - r["U"]).max() < TRAJ_ATOL * w, b
         np.testing.assert_array_equal(h["accept_solution"][b, :nh], r["accept"])
-        np.testing.assert_allclose(h["omega"][b, :nh], r["omega"], rtol=0, atol=0)
-        np.testing.assert_allclose(h["Delta"][b, :nh], r["Delta"], rtol=0, atol=0)
         nJ = h["nJ"][b]
         assert nJ == len(r["J_true"])
-        np.testing.assert_allclose(h["J_true"][b, :nJ], r["J_true"], rtol=1e-4, atol=1e-9)
-        np.testing.assert_allclose(h["J_full"][b, :nJ], r["J_full"], rtol=1e-4, atol=1e-9)
-        np.testing.assert_allclose(h["convergence_measure"][b, :nh], r["conv"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(h["J_true"][b, :nJ], r["J_true"], rtol=1e-4 * w, atol=1e-9)
+        np.testing.assert_allclose(h["J_full"][b, :nJ], r["J_full"], rtol=1e-4 * w, atol=1e-9)
+        np.testing.assert_allclose(h["convergence_measure"][b, :nh], r["conv"], rtol=1e-4 * w, atol=1e-7 * w)
         nr = h["n_rho"][b]
-        np.testing.assert_allclose(h["rho"][b, :nr], r["rho"], rtol=1e-2, atol=1e-6)
-    assert n_checked >= B // 2
+        np.testing.assert_allclose(h["rho"][b, :nr], r["rho"], rtol=1e-4 * w, atol=1e-9)
+    assert len(diverged) <= max_diverged, diverged
+    return diverged
+
+
+@pytest.mark.parametrize("first", [0, 7000])
+def test_lockstep_parity_freeflyer(first):
+    g, _ = _mods()
+    P = g.problems
+    x0, glo, ghi, tf = P.freeflyer_batch(64, first=first)
+    if first == 0:
+        x0[0] = P.FREEFLYER_X_INIT
+    info = _lockstep_parity(g.FREEFLYER_SE2, 50, P.freeflyer_env(), None, x0, glo, ghi, tf)
+    print("lockstep freeflyer", info)
+    assert info["trips"] > 500
+
+
+def test_lockstep_parity_freeflyer_hard_problems():
+    """The problems the round-1 tests skipped: penalty weight driven above 1e3 (long, ill-conditioned solves)."""
+    g, go = _mods()
+    P = g.problems
+    env = P.freeflyer_env()
+    x0, glo, ghi, tf = P.freeflyer_batch(512, first=20000)
+    runs = _oracle_runs(g.FREEFLYER_SE2, 50, env, None, x0, glo, ghi, tf, 30, cold=False)
+    hard = [b for b, (r, _) in enumerate(runs) if r["omega"].max() > 1e3][:12]
+    assert len(hard) >= 3
+    hard = np.array(hard)
+    info = _lockstep_parity(g.FREEFLYER_SE2, 50, env, None, x0[hard], glo[hard], ghi[hard], tf[hard], max_flag_mismatch=0.02)
+    print("lockstep freeflyer hard", info)
+    assert info["max_omega"] > 1e3
+
+
+def test_lockstep_parity_dubins():
+    g, _ = _mods()
+    x0, glo, ghi, tf = g.problems.dubins_batch(64)
+    x0[0] = [2.0, 2.0, 2.0]
+    print("lockstep dubins", _lockstep_parity(g.DUBINS_CAR, 30, None, None, x0, glo, ghi, tf))
+
+
+def test_lockstep_parity_astrobee_se3():
+    g, _ = _mods()
+    P = g.problems
+    boxes, sph = P.iss_corner_env(True)
+    x0, glo, ghi, tf = P.astrobee_se3_batch(8)
+    print("lockstep se3", _lockstep_parity(g.ASTROBEE_SE3, 50, boxes, sph, x0, glo, ghi, tf, max_iter=10, max_flag_mismatch=0.02))
+
+
+def test_lockstep_parity_astrobee_manifold():
+    g, _ = _mods()
+    P = g.problems
+    boxes, sph = P.iss_corner_env(True)
+    x0, glo, ghi, tf = P.astrobee_manifold_batch(8)
+    print("lockstep manifold", _lockstep_parity(g.ASTROBEE_SE3_MANIFOLD, 50, boxes, sph, x0, glo, ghi, tf, max_iter=10, sub_atol=1e-5,
+                                                max_flag_mismatch=0.02))
 
 
 def test_scp_parity_freeflyer():
@@ -134,14 +283,14 @@ def test_scp_parity_freeflyer():
     P = g.problems
     x0, glo, ghi, tf = P.freeflyer_batch(64)
     x0[0] = P.FREEFLYER_X_INIT
-    _scp_parity(g.FREEFLYER_SE2, 50, P.freeflyer_env(), None, x0, glo, ghi, tf)
+    _scp_parity(g.FREEFLYER_SE2, 50, P.freeflyer_env(), None, x0, glo, ghi, tf, max_diverged=1)
 
 
 def test_scp_parity_dubins():
     g, _ = _mods()
     x0, glo, ghi, tf = g.problems.dubins_batch(64)
     x0[0] = [2.0, 2.0, 2.0]
-    _scp_parity(g.DUBINS_CAR, 30, None, None, x0, glo, ghi, tf)
+    _scp_parity(g.DUBINS_CAR, 30, None, None, x0, glo, ghi, tf, max_diverged=1)
 
 
 def test_scp_parity_astrobee_se3():
@@ -359,9 +508,6 @@ def test_gpu_matches_golden_vectors(name):
     X, U = s.traj()
     st = s.status()
     for b in range(B):
-        om = d["omega"][b][~np.isnan(d["omega"][b])]
-        if om.max() > 1e3:
-            continue
         assert bool(st["converged"][b]) == bool(d["converged"][b]) and int(st["iterations"][b]) == int(d["iterations"][b])
         assert int(st["stop_reason"][b]) == int(d["stop_reason"][b])
         assert np.abs(X[b] - d["X"][b]).max() < TRAJ_ATOL and np.abs(U[b] - d["U"][b]).max() < TRAJ_ATOL
@@ -430,8 +576,6 @@ def test_horizon_edge_cases(N):
         if ro["status"] == 1 and int(sub["status"][b]) == 1:
             assert np.abs(sub["X"][b] - ro["X"]).max() < SUB_ATOL and np.abs(sub["U"][b] - ro["U"]).max() < SUB_ATOL
         r = o.solve(12)
-        if r["omega"].max() > 1e3:
-            continue
         assert int(st["iterations"][b]) == r["iterations"] and bool(st["converged"][b]) == r["converged"]
         assert np.abs(X[b] - r["X"]).max() < TRAJ_ATOL
 
@@ -460,3 +604,106 @@ def test_partial_goal_and_box_goal_freeflyer():
         assert np.abs(sub["X"][b] - ro["X"]).max() < SUB_ATOL and np.abs(sub["U"][b] - ro["U"]).max() < SUB_ATOL
         if b < 4:
             assert glo[b, 0] - 1e-7 <= sub["X"][b, -1, 0] <= ghi[b, 0] + 1e-7
+
+
+def test_history_capacity_contract():
+    """gusto_get_history writes rows with the CALLER's pitch and refuses arrays smaller than the handle's capacity;
+    a handle whose history fills up before iter_cap stops with GUSTO_STOP_HIST_FULL (never silently as MaxIter), and
+    the host mirror raises on it."""
+    import ctypes as C
+    g, _ = _mods()
+    P = g.problems
+    x0, glo, ghi, tf = P.freeflyer_batch(4)
+    s = g.BatchSolver(g.FREEFLYER_SE2, 50, 4, hist_cap=12, boxes=P.freeflyer_env())
+    s.set_problems(x0, glo, ghi, tf)
+    s.solve(5)
+    cap = C.c_int()
+    assert s.L.gusto_get_hist_cap(s.h, C.byref(cap)) == 0 and cap.value == 12
+    h12 = s.history()
+    s.hist_cap = 20                     # caller arrays wider than the handle's rows: same entries, caller pitch
+    h20 = s.history()
+    for k in ("Delta", "omega", "scp_status", "J_true"):
+        assert h20[k].shape == (4, 20) and np.array_equal(h20[k][:, :12], h12[k])
+    s.hist_cap = 8                      # too small: refused, nothing is overrun
+    with pytest.raises(g.GustoError):
+        s.history()
+    s.hist_cap = 12
+    s.solve(30)                         # 5 + 30 trips cannot fit 12 entries
+    st = s.status()
+    assert (st["stop_reason"][~st["converged"]] == 4).all() and (st["stop_reason"] == 4).any()
+    assert (st["iterations"] <= 11).all()
+
+
+def test_trust_state_is_the_callers():
+    """gusto_set_trust_state: the next trip runs with the caller's Delta_vec[end] / omega_vec[end] (scp_gusto.jl:60)."""
+    g, go = _mods()
+    P = g.problems
+    env = P.freeflyer_env()
+    x0, glo, ghi, tf = P.freeflyer_batch(6)
+    s = g.BatchSolver(g.FREEFLYER_SE2, 50, 6, hist_cap=8, boxes=env)
+    s.set_problems(x0, glo, ghi, tf)
+    D, W = np.array([3.0, 1.5, 0.75, 3.0, 0.1, 0.02]), np.array([1.0, 1.0, 10.0, 100.0, 1.0, 1.0])
+    s.set_trust_state(D, W)
+    s.solve(1)
+    h = s.history()
+    assert np.array_equal(h["Delta"][:, 0], D) and np.array_equal(h["omega"][:, 0], W)
+    o = go.Oracle(go.FREEFLYER_SE2, 50, boxes=env)
+    for b in range(6):
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        Xi, Ui = o.init_straightline()
+        c = o.subproblem(Xi, Ui, D[b], W[b], D[b] / 8 + 0.05)
+        assert abs(h["convergence_measure"][b, 1] - o.convergence_metric(c["X"], Xi)) < 1e-8 * W[b]
+
+
+def test_batch_seam_with_distinct_problems_and_shared_init():
+    """solve_SCP_batch! over DIFFERENT problems: results land at their own index (also across shards), a Trajectory
+    passed as the common initial guess is copied per problem (never aliased or clobbered), mixed batches are refused."""
+    g, go = _mods()
+    H, P = g.host, g.problems
+    env = H.Environment(P.freeflyer_env())
+    model = H.FreeflyerSE2()
+    x0, glo, ghi, tf = P.freeflyer_batch(5, first=300)
+    TOPs = []
+    for b in range(5):
+        gs = H.GoalSet()
+        H.add_goal(gs, H.Goal(H.PointGoal(glo[b]), tf[b], model))
+        TOPs.append(H.TrajectoryOptimizationProblem(H.ProblemDefinition(H.Robot(), model, env, x0[b], gs), 50, tf[b], True))
+    o = go.Oracle(go.FREEFLYER_SE2, 50, boxes=P.freeflyer_env())
+    ref = []
+    for b in range(5):
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        ref.append(o.solve(30))
+    for devices in (None, [0, 0]):
+        TOSs = [H.TrajectoryOptimizationSolution(t) for t in TOPs]
+        out = H.solve_SCP_batch(TOSs, TOPs, H.solve_gusto_hip, H.init_traj_straightline, "hip", max_iter=30, devices=devices)
+        for b in range(5):
+            assert out[b].iterations == ref[b]["iterations"] and out[b].converged == ref[b]["converged"]
+            assert np.abs(out[b].traj.X.T - ref[b]["X"]).max() < TRAJ_ATOL and TOSs[b].traj is out[b].traj
+            assert np.abs(out[b].traj.X[:, 0] - x0[b]).max() < 1e-9
+    # one Trajectory as the initial guess of identical problems
+    init = H.init_traj_straightline(TOPs[0])
+    X_before = init.X.copy()
+    TOSs = [H.TrajectoryOptimizationSolution(TOPs[0]) for _ in range(3)]
+    out = H.solve_SCP_batch(TOSs, [TOPs[0]] * 3, H.solve_gusto_hip, init, "hip", max_iter=30)
+    assert np.array_equal(init.X, X_before)
+    assert out[0].traj is not out[1].traj and out[0].traj.X is not out[1].traj.X
+    TOPb = H.TrajectoryOptimizationProblem(TOPs[1].PD, 40, tf[1], True)
+    with pytest.raises(ValueError):
+        H.solve_SCP_batch(TOSs[:2], [TOPs[0], TOPb], H.solve_gusto_hip)
+
+
+def test_device_views_of_the_trajectories():
+    """BatchSolver.traj_dev: zero-copy torch views of the handle's HBM buffers (what the RCCL gather sends)."""
+    import torch
+    g, _ = _mods()
+    P = g.problems
+    x0, glo, ghi, tf = P.freeflyer_batch(16)
+    s = g.BatchSolver(g.FREEFLYER_SE2, 50, 16, hist_cap=40, boxes=P.freeflyer_env())
+    s.set_problems(x0, glo, ghi, tf)
+    s.solve(30)
+    X, U = s.traj()
+    Xd, Ud = s.traj_dev()
+    assert Xd.is_cuda and Xd.dtype == torch.float64 and tuple(Xd.shape) == X.shape
+    assert np.array_equal(Xd.cpu().numpy(), X) and np.array_equal(Ud.cpu().numpy(), U)
+    out = g.host.gather_batch_results(dict(X=Xd, U=Ud), 1, 0)
+    assert out["X"] is Xd
