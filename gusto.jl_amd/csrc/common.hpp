@@ -183,7 +183,8 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
 struct KParams {
     int N, B, n_obs, n_box, n_sph, hist_cap, max_iter, force, mode;  // mode 0: SCP solve, 1: one subproblem
     int cont;           // 1: second launch of the same gusto_solve call (longest-first schedule, launch.hpp)
-    const int* order;   // workgroup -> problem index (nullptr: identity)
+    const int* order;   // queue position -> problem index (nullptr: identity)
+    int* queue;         // work queue head of this launch: persistent workgroups pull queue positions with atomicAdd
     gusto_scp_params sp;
     gusto_model_params mp;
     gusto_ipm_opts io;
@@ -218,10 +219,10 @@ struct Prof {
     long long t0, acc[PROF_N];
     GD Prof() { for (int i = 0; i < PROF_N; i++) acc[i] = 0; t0 = clock64(); }
     GD void tick(int id) { const long long t = clock64(); acc[id] += t - t0; t0 = t; }
-    GD void flush(long long* out) { if (out && threadIdx.x == 0) for (int i = 0; i < PROF_N; i++) out[(size_t)blockIdx.x * PROF_N + i] = acc[i]; }
+    GD void flush(long long* out, int b) { if (out && threadIdx.x == 0) for (int i = 0; i < PROF_N; i++) out[(size_t)b * PROF_N + i] = acc[i]; }
 #else
     GD void tick(int) {}
-    GD void flush(long long*) {}
+    GD void flush(long long*, int) {}
 #endif
 };
 

@@ -130,6 +130,7 @@ int gusto_destroy(gusto_handle h) {
                     h->d_prof, h->d_subD, h->d_subW, h->d_subT, h->d_subX, h->d_subU, h->d_subObj, h->d_subSt, h->d_subIt, h->d_box, h->d_sph};
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->d_order) hipFree(h->d_order);
+    if (h->d_queue) hipFree(h->d_queue);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);

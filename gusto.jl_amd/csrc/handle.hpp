@@ -30,6 +30,8 @@ struct gusto_handle_s {
     bool pending = false;  // a gusto_solve_async launch has not been waited for yet
     int probe_iters = 2, probe_min_batch = 2048;  // longest-first schedule (gusto_set_schedule)
     int* d_order = nullptr;
+    int* d_queue = nullptr;   // work-queue heads, one per launch of a gusto_solve call
+    int slots = 0;            // resident workgroups the last launch used (persistent kernel)
     bool have_problems = false;
     std::string err;
 };

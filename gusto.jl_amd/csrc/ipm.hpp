@@ -89,10 +89,13 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         x_init = as_global(x_init); goal_lo = as_global(goal_lo); goal_hi = as_global(goal_hi);
     }
 
-    GD Blk(const KParams& P_, double* lds_) : P(P_), lds(lds_) {
-        b = P.order ? P.order[blockIdx.x] : (int)blockIdx.x; tid = threadIdx.x; NTr = blockDim.x; N = P.N;
+    // b = the problem, slot = the resident workgroup: the interior point workspace belongs to the SLOT (a few hundred
+    // KB that every problem this workgroup pulls from the queue reuses, so the working set of a launch is
+    // #slots x wl.total, cache-resident, instead of B x wl.total streamed through HBM once per problem)
+    GD Blk(const KParams& P_, double* lds_, int b_, int slot) : P(P_), lds(lds_) {
+        b = b_; tid = threadIdx.x; NTr = blockDim.x; N = P.N;
         rebind_lds(lds_);
-        double* w = P.ws + (size_t)b * P.wl.total;
+        double* w = P.ws + (size_t)slot * P.wl.total;
         const WsLayout& W = P.wl;
         rowstate = w + W.rowstate; obs_nh = w + W.obs_nh; obs_c0 = w + W.obs_c0;
         obs_mask = reinterpret_cast<uint64_t*>(w + W.obs_mask);

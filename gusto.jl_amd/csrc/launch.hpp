@@ -28,14 +28,7 @@ template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B) {
     P.ipm_it = h->d_ipm;
     P.wl = make_ws_layout<MODEL>(h->N, P.n_obs);
     P.ll = make_lds_layout<MODEL>(h->N);
-    const size_t need = P.wl.total * (size_t)h->batch_cap;
-    if (need > h->ws_doubles) {
-        if (h->d_ws) hipFree(h->d_ws);
-        h->d_ws = nullptr; h->ws_doubles = 0;
-        HIPCHK(h, dalloc(&h->d_ws, need));
-        h->ws_doubles = need;
-    }
-    P.ws = h->d_ws;
+    if (!h->d_queue) HIPCHK(h, dalloc(&h->d_queue, 4));
 #ifdef GUSTO_PROFILE
     if (!h->d_prof) HIPCHK(h, dalloc(&h->d_prof, (size_t)h->batch_cap * PROF_N));
 #endif
@@ -55,13 +48,26 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     // a problem with N <= 64 knots runs as one wave per workgroup (no barriers at all)
     auto kern = (NT == 64) ? &scp_kernel<MODEL, true> : &scp_kernel<MODEL, false>;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (getenv("GUSTO_DEV_DEBUG")) {
-        fprintf(stderr, "ws %p..%p (per problem %zu B)  X %p U %p subX %p subU %p st_i %p st_d %p lds %zu B mode %d\n", (void*)h->d_ws,
-                (void*)(h->d_ws + h->ws_doubles), P.wl.total * 8, (void*)h->d_X, (void*)h->d_U, (void*)h->d_subX, (void*)h->d_subU,
-                (void*)h->d_sti, (void*)h->d_std, lds, mode);
-        fprintf(stderr, "rowstate %zu obs_nh %zu obs_c0 %zu mask %zu PG %zu QQ %zu Paft %zu Piaft %zu KD %zu Phicl %zu pvt %zu total %zu\n",
-                P.wl.rowstate, P.wl.obs_nh, P.wl.obs_c0, P.wl.obs_mask, P.wl.PG, P.wl.QQ, P.wl.Paft, P.wl.Piaft, P.wl.KD, P.wl.Phicl, P.wl.pvt, P.wl.total);
+    // Persistent launch: as many workgroups as the GPU keeps resident (slots), each with its own workspace
+    int per_cu = 0, cus = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NT, lds));
+    HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    int slots = std::max(1, per_cu) * std::max(1, cus);
+    if (const char* e = getenv("GUSTO_DEV_SLOTS")) slots = std::max(1, atoi(e));   // occupancy experiments
+    slots = std::min(slots, h->B);
+    h->slots = slots;
+    {
+        const size_t need = P.wl.total * (size_t)slots;
+        if (need > h->ws_doubles) {
+            if (h->d_ws) hipFree(h->d_ws);
+            h->d_ws = nullptr; h->ws_doubles = 0;
+            HIPCHK(h, dalloc(&h->d_ws, need));
+            h->ws_doubles = need;
+        }
+        P.ws = h->d_ws;
     }
+    HIPCHK(h, hipMemsetAsync(h->d_queue, 0, 4 * sizeof(int), h->stream));
+    P.queue = h->d_queue;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     // Longest-first schedule for big batches.  Workgroups are dispatched in index order onto ~4 slots per CU, so a
     // long problem with a high index starts late and the batch ends with a few problems on an empty GPU (44 % of
@@ -72,13 +78,13 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     if (split) {
         if (!h->d_order) HIPCHK(h, dalloc(&h->d_order, (size_t)h->batch_cap));
         P.max_iter = h->probe_iters;
-        hipLaunchKernelGGL(kern, dim3(h->B), dim3(NT), lds, h->stream, P);
+        hipLaunchKernelGGL(kern, dim3(slots), dim3(NT), lds, h->stream, P);
         HIPCHK(h, hipGetLastError());
         hipLaunchKernelGGL(order_kernel<MODEL>, dim3(1), dim3(256), 0, h->stream, P, h->d_order);
         HIPCHK(h, hipGetLastError());
-        P.max_iter = max_iter - h->probe_iters; P.cont = 1; P.order = h->d_order;
+        P.max_iter = max_iter - h->probe_iters; P.cont = 1; P.order = h->d_order; P.queue = h->d_queue + 1;
     }
-    hipLaunchKernelGGL(kern, dim3(h->B), dim3(NT), lds, h->stream, P);
+    hipLaunchKernelGGL(kern, dim3(slots), dim3(NT), lds, h->stream, P);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->pending = true;   // completed by gusto_finish (handle.hpp)

@@ -75,12 +75,11 @@ template <class BLK> GD void store_traj(BLK& K, const double* Xs, const double* 
     for (int e = K.tid; e < K.N * m; e += K.nt()) Ug[e] = Us[e];
 }
 
-template <int MODEL, bool ONEWAVE> __global__ void __launch_bounds__(ONEWAVE ? 64 : 256, ONEWAVE ? MT<MODEL>::WAVES_PER_EU : 1)
-scp_kernel(const KParams P) {
+// One problem, start to stop: the body of the persistent kernel below.
+template <int MODEL, bool ONEWAVE> GD void scp_problem(const KParams& P, double* lds, int b_, int slot) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m;
-    extern __shared__ double lds[];
-    Blk<MODEL, ONEWAVE> K(P, lds);
+    Blk<MODEL, ONEWAVE> K(P, lds, b_, slot);
     Prof pf;
     const int b = K.b, tid = K.tid, N = K.N, k = tid;
     double* Xg = P.X + (size_t)b * N * n;
@@ -125,7 +124,7 @@ scp_kernel(const KParams P) {
         IpmOut io;
         ipm_solve<MODEL>(K, Delta, omega, (warm && !hook) ? P.io.mu_warm : 0.0, io, pf);  // :96-104
         if (hook) {
-            pf.flush(P.prof);
+            pf.flush(P.prof, b);
             store_traj(K, K.Xw, K.Uw, P.sub_X + (size_t)b * N * n, P.sub_U + (size_t)b * N * m);
             if (tid == 0) {
                 P.sub_obj[b] = io.obj; P.sub_status[b] = io.status; P.sub_iters[b] = io.iters;
@@ -218,11 +217,38 @@ scp_kernel(const KParams P) {
     // a history vector is full although iterations remain: say so instead of posing as MaxIter
     if (stop == GUSTO_STOP_MAXITER && iterations < iter_cap) stop = GUSTO_STOP_HIST_FULL;
     pf.tick(PF_SCP);
-    pf.flush(P.prof);
+    pf.flush(P.prof, b);
     if (tid == 0) {
         sti[ST_ITER] = iterations; sti[ST_CONV] = converged; sti[ST_SUCC] = successful; sti[ST_STOP] = stop;
         sti[ST_IPM] = total_ipm; sti[ST_NHIST] = n_hist; sti[ST_NJ] = nJ; sti[ST_NRHO] = n_rho; sti[ST_WARM] = warm;
         std_[SD_TOGGLE] = toggle;
+    }
+}
+
+// The kernel: PERSISTENT workgroups (the grid is the number of resident slots, launch.hpp) pull problems from a work
+// queue -- one atomicAdd per problem on P.queue -- until it is empty.  A problem that needs 30 trips and one that needs
+// 5 occupy their slot for different times and the queue backfills; P.order (longest-first schedule) maps queue
+// positions to problems.  Problems are independent: no grid-wide synchronisation, no inter-workgroup data.
+template <int MODEL, bool ONEWAVE> __global__ void __launch_bounds__(ONEWAVE ? 64 : 256, ONEWAVE ? MT<MODEL>::WAVES_PER_EU : 1)
+scp_kernel(const KParams P) {
+    extern __shared__ double lds[];
+    const int slot = blockIdx.x;
+    for (;;) {
+        int q = 0;
+        if (threadIdx.x == 0) q = atomicAdd(P.queue, 1);
+        if constexpr (ONEWAVE) {
+            q = __builtin_amdgcn_readfirstlane(q);
+        } else {
+            __shared__ int q_sh;
+            __syncthreads();               // (also: everyone is done with the previous problem's LDS)
+            if (threadIdx.x == 0) q_sh = q;
+            __syncthreads();
+            q = q_sh;
+        }
+        if (q >= P.B) return;
+        const int b = P.order ? P.order[q] : q;
+        scp_problem<MODEL, ONEWAVE>(P, lds, b, slot);
+        blk_sync<ONEWAVE>();               // the next problem reuses this workgroup's LDS and workspace slot
     }
 }
 
