@@ -6,10 +6,16 @@
 
 One "step" = one full pass of the hot path over one batch: straight-line initialisation of every problem,
 then gusto_solve (the whole GuSTO loop: linearisation, convex subproblems, trust-region/penalty updates) until
-every problem of the batch has stopped.  Workload = BASELINE.json configs[1]: freeflyerSE2, batch 4096 random
-initial states, N = 50, fp64, per GPU (weak scaling: every rank solves its own 4096 problems; there is no
-data-path collective -- the problems are independent).  Inputs are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line.
+every problem of the batch has stopped; with N > 1 ranks the step ends with the final gather of every rank's
+trajectories to rank 0 over RCCL, straight from HBM (north_star: "RCCL only for the batch split and final gather").
+Workload = BASELINE.json configs[1]: freeflyerSE2, batch 4096 random initial states, N = 50, fp64, per GPU (weak
+scaling: every rank solves its own 4096 problems; no data-path collective -- the problems are independent).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+`value` = strictly serial steps (one batch in flight), so that the kernel time behind `roofline` is that of a lone
+solve.  Named extras in the same line: `overlapped_traj_per_s` (consecutive batches on two handles/streams, the
+steady-state serving rate) and `pcie_inclusive_traj_per_s` (gusto_set_problems from host buffers +
+gusto_solve + gusto_get_traj to host, median of 5).
 """
 import argparse
 import json
@@ -61,12 +67,12 @@ def cpu_baseline(problems, env, n_sample, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=160)     # ~10 s of GPU time in the timed region
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--cpu-sample", type=int, default=0, help="0 = 2048 problems per usable host core (about 15-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", type=int, default=2,
+    ap.add_argument("--overlap", type=int, default=1,
                     help="batches in flight: consecutive steps alternate between this many handles/streams, so the "
                          "slowest problems of one batch overlap the start of the next (1 = strictly serial steps)")
     args = ap.parse_args()
@@ -103,8 +109,15 @@ def main():
     kernel_ms = []
     timed_in_flight = [False] * D
 
+    gathered = [0]
+
     def collect(j):
         solvers[j].wait()
+        if dist is not None:      # final gather of this step's trajectories to rank 0, device tensors -> RCCL
+            Xd, Ud = solvers[j].traj_dev()
+            out = g.host.gather_batch_results(dict(X=Xd, U=Ud), world, rank)
+            if rank == 0:
+                gathered[0] = int(out["X"].shape[0])
         if timed_in_flight[j]:
             kernel_ms.append(solvers[j].last_solve_ms())
             timed_in_flight[j] = False
@@ -153,25 +166,52 @@ def main():
     tot = tot.cpu().numpy()
     elapsed = float(tmax.item())
 
-    # PCIe-inclusive variant (host buffers in, trajectories out), reported but never the headline value
-    t1 = time.perf_counter()
-    solver.set_problems(x0, glo, ghi, tf)
-    solver.solve(MAX_ITER)
-    solver.traj()
-    pcie_s = time.perf_counter() - t1
+    # named extras, outside the timed region, rank 0's GPU only:
+    # (a) SURVEY.md 8(d): host buffers in, trajectories out (H2D + solve + D2H), median of 5
+    pcie = []
+    for _ in range(5):
+        t1 = time.perf_counter()
+        solver.set_problems(x0, glo, ghi, tf)
+        solver.solve(MAX_ITER)
+        solver.traj()
+        pcie.append(time.perf_counter() - t1)
+    pcie_s = float(np.median(pcie))
+    # (b) two batches in flight on two handles/streams (the tail of one batch overlaps the head of the next)
+    overlapped = None
+    if D == 1 and dist is None:
+        s2 = [solver, g.BatchSolver(g.FREEFLYER_SE2, N_KNOTS, B, hist_cap=MAX_ITER + 34, device=local_rank, boxes=env)]
+        K2 = 12
+        for i in range(2):
+            s2[i].set_problems_dev(B, d_x0.data_ptr(), d_glo.data_ptr(), d_ghi.data_ptr(), d_tf.data_ptr())
+            s2[i].solve_async(MAX_ITER)
+        for q in s2:
+            q.wait()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(K2):
+            q = s2[i % 2]
+            q.wait()
+            q.set_problems_dev(B, d_x0.data_ptr(), d_glo.data_ptr(), d_ghi.data_ptr(), d_tf.data_ptr())
+            q.solve_async(MAX_ITER)
+        for q in s2:
+            q.wait()
+        torch.cuda.synchronize()
+        overlapped = n_conv * K2 / (time.perf_counter() - t1)
 
     if rank == 0:
         value = tot[0] * args.steps / elapsed
         avg_ms = float(np.mean(kernel_ms))
         alg_bytes = BYTES_PER_KKT * ipm_iters + BYTES_PER_LINEARIZE * scp_iters      # this rank, one launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        # HBM traffic of one launch from the latest committed PMC pass (separate rocprofv3 --pmc runs, profiles/)
-        traffic = None
+        # HBM traffic of one solve: NOT measured in this run -- PMC counters need their own rocprofv3 --pmc passes
+        # (tools/profile_round.sh); the figure is read from the latest committed summary of the same workload
+        traffic, traffic_src = None, None
         try:
             import glob
             pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
             if pmc and B == BATCH:
                 traffic = json.load(open(pmc[-1]))["traffic_bytes_per_launch"]
+                traffic_src = "profiles/" + os.path.basename(pmc[-1]) + " (separate rocprofv3 --pmc passes, not this run)"
         except Exception:
             traffic = None
         out = {
@@ -181,12 +221,13 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "freeflyerSE2 batch=4096 random initial states per GPU, N=50, fp64 "
                                    "(BASELINE.json configs[1])", "batch_per_gpu": B, "N": N_KNOTS,
-                       "max_iter": MAX_ITER, "sharding": "independent problems per rank, no collective",
+                       "max_iter": MAX_ITER, "sharding": "independent problems per rank; final gather of X,U to rank 0 "
+                                                         "over RCCL inside every step (N > 1)",
                        "batches_in_flight": D},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # one gusto_solve = two launches of this kernel (2 probe trips of every problem, then the rest
-                         # longest-first, gusto_set_schedule); avg_launch_ms is their sum per solve, from HIP events
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # one gusto_solve = two launches of this persistent kernel (2 probe trips of every problem, then
+                         # the rest longest-first, gusto_set_schedule); avg_launch_ms is their sum per solve, HIP events
                          "kernel": "gusto::scp_kernel<0>", "launches_per_solve": 2, "avg_launch_ms": avg_ms,
                          "kkt_solves_per_launch": ipm_iters, "scp_iters_per_launch": scp_iters,
                          # with D > 1 launches overlap, so a launch's duration spans the batches it shares the GPU
@@ -195,7 +236,9 @@ def main():
                          "aggregate_achieved": alg_bytes * args.steps / elapsed / 1e9},
             "converged": int(tot[0]), "successful": int(tot[1]), "problems": B * world,
             "mean_scp_iters": tot[2] / (B * world), "mean_ipm_iters": tot[3] / (B * world),
-            "pcie_inclusive_traj_per_s": n_conv / pcie_s,
+            "pcie_inclusive_traj_per_s": n_conv / pcie_s, "pcie_inclusive_note": "SURVEY.md 8(d): set_problems (host) + "
+            "solve + get_traj (host), median of 5, one GPU", "overlapped_traj_per_s": overlapped,
+            "gathered_problems_per_step": gathered[0] if dist is not None else None,
         }
         if not args.no_cpu_baseline:
             threads = usable_cores()

@@ -310,6 +310,29 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
     return out
 
 
+def solve_batch_sharded(model_id, N, x_init, goal_lo, goal_hi, tf, world_size, rank, device=0, max_iter=30, boxes=None,
+                        spheres=None, group=None, solver=None):
+    """The multi-GPU path of SURVEY.md 8(e) in one call (one process per GPU, launched by torch.distributed.run):
+    rank r solves the contiguous block shard_bounds(B, G, r) of the batch on its own GPU -- independent problems, no
+    data-path collective -- and the trajectories are gathered to rank 0 STRAIGHT FROM HBM (BatchSolver.traj_dev views,
+    RCCL under the nccl backend), together with the per-problem status vectors.  Returns on rank 0 a dict with X, U
+    (torch tensors on the gather device), iterations, converged, successful, stop_reason (numpy); None elsewhere.
+    `solver` lets a caller keep a BatchSolver (and its device buffers) across calls."""
+    x_init, goal_lo, goal_hi = (np.asarray(a, float) for a in (x_init, goal_lo, goal_hi))
+    B = x_init.shape[0]
+    lo, hi = shard_bounds(B, world_size, rank)
+    tf = np.broadcast_to(np.asarray(tf, float), (B,))
+    bs = solver or BatchSolver(model_id, N, max(1, hi - lo), hist_cap=_hist_cap(max_iter), device=device, boxes=boxes,
+                               spheres=spheres)
+    bs.set_problems(x_init[lo:hi], goal_lo[lo:hi], goal_hi[lo:hi], tf[lo:hi])
+    bs.solve(max_iter)
+    Xd, Ud = bs.traj_dev()
+    st = bs.status()
+    local = dict(X=Xd, U=Ud, iterations=st["iterations"].astype(np.int64), converged=st["converged"].astype(np.int64),
+                 successful=st["successful"].astype(np.int64), stop_reason=st["stop_reason"].astype(np.int64))
+    return gather_batch_results(local, world_size, rank, group)
+
+
 def gather_batch_results(local, world_size, rank, group=None):
     """Final gather of per-rank results to rank 0: the only communication of a multi-GPU run.
     `local` maps names to arrays with the problem index leading: torch tensors ALREADY ON THE GPU (the views

@@ -21,11 +21,16 @@ def run(name, model, N, B, batch, boxes=None, spheres=None, max_iter=30):
     print(json.dumps(out), flush=True)
 
 
+only = set(int(a) for a in sys.argv[1:])      # optional: model ids to run (default all five configs)
 env = P.freeflyer_env()
 one = (P.FREEFLYER_X_INIT[None], P.FREEFLYER_X_GOAL[None], P.FREEFLYER_X_GOAL[None], np.array([P.FREEFLYER_TF]))
-run("1: freeflyerSE2 notebook problem", g.FREEFLYER_SE2, 50, 1, one, boxes=env)
-run("2: freeflyerSE2 random initial states", g.FREEFLYER_SE2, 50, 4096, P.freeflyer_batch(4096), boxes=env)
-run("3: dubins_car", g.DUBINS_CAR, 30, 65536, P.dubins_batch(65536))
+if not only or 0 in only:
+    run("1: freeflyerSE2 notebook problem", g.FREEFLYER_SE2, 50, 1, one, boxes=env)
+    run("2: freeflyerSE2 random initial states", g.FREEFLYER_SE2, 50, 4096, P.freeflyer_batch(4096), boxes=env)
+if not only or 1 in only:
+    run("3: dubins_car", g.DUBINS_CAR, 30, 65536, P.dubins_batch(65536))
 bx, sp = P.iss_corner_env(True)
-run("4: astrobeeSE3 ISS corner", g.ASTROBEE_SE3, 50, 8192, P.astrobee_se3_batch(8192), boxes=bx, spheres=sp)
-run("5: astrobeeSE3manifold ISS corner (tf=40)", g.ASTROBEE_SE3_MANIFOLD, 50, 2048, P.astrobee_manifold_batch(2048), boxes=bx, spheres=sp)
+if not only or 2 in only:
+    run("4: astrobeeSE3 ISS corner", g.ASTROBEE_SE3, 50, 8192, P.astrobee_se3_batch(8192), boxes=bx, spheres=sp)
+if not only or 3 in only:
+    run("5: astrobeeSE3manifold ISS corner (tf=40)", g.ASTROBEE_SE3_MANIFOLD, 50, 2048, P.astrobee_manifold_batch(2048), boxes=bx, spheres=sp)

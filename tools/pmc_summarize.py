@@ -48,6 +48,11 @@ shutil.copy(os.path.join(src, "pmc", "WRITE_SIZE_counter_collection.csv"), os.pa
 shutil.copy(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "stats", "stats_kernel_trace.csv"), os.path.join(dst, f"{tag}_kernel_trace.csv"))
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
-if os.path.exists(os.path.join(src, "bench_serial.json")):
-    shutil.copy(os.path.join(src, "bench_serial.json"), os.path.join(dst, f"{tag}_bench_overlap1.json"))
+for extra, name in (("bench_overlap2.json", "bench_overlap2.json"), ("configs.jsonl", "configs.jsonl")):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{name}"))
+for m, cfg in ((2, "config4_astrobee_se3"), (3, "config5_manifold")):
+    f = os.path.join(src, f"stats_m{m}", "stats_kernel_stats.csv")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_{cfg}.csv"))
 print(json.dumps({k: v for k, v in out.items() if k != "calibration"}, indent=1))
