@@ -173,7 +173,7 @@ def _lockstep_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30, sub_
     R = lambda k: np.array([runs[b][0][k][t + 1] for b, t in trips])
     ec = np.abs(h["convergence_measure"][:, 1] - C_("conv_c")) / w
     same_it = h["ipm_iters"][:, 1] == C_("it_c")
-    assert ec[same_it].max() < 1e-8 and ec.max() < 20 * sub_atol, (ec[same_it].max(), ec.max(), trips[int(ec.argmax())])
+    assert ec[same_it].max() < max(1e-8, 0.05 * (sub_atol - SUB_ATOL)) and ec.max() < 20 * sub_atol, (ec[same_it].max(), ec.max(), trips[int(ec.argmax())])
     eJf = np.abs(h["J_full"][:, 1] - C_("obj_c")) / (w * np.maximum(1.0, np.abs(C_("obj_c"))))
     assert eJf[same_it].max() < 1e-8 and eJf.max() < 1e-6, (eJf[same_it].max(), eJf.max())
     flags = dict(trust_region_satisfied="tr_sat", convex_ineq_satisfied="cvx_sat", accept_solution="accept",
