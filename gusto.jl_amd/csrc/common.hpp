@@ -9,6 +9,7 @@
 namespace gusto {
 
 #define GD __device__ __forceinline__
+typedef double v4d __attribute__((ext_vector_type(4)));   // accumulator tile of v_mfma_f64_16x16x4_f64
 
 // row kinds of the convex subproblem (scp_gusto.jl:192-314)
 constexpr int ROW_HARD = 0;     // hard inequality (convex_control_ineq, BoxGoal rows)          :213-221,236-245
@@ -26,11 +27,15 @@ constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5,
 #define GUSTO_WAVES_PER_EU 1
 #endif
 
+#ifndef GUSTO_USE_MFMA
+#define GUSTO_USE_MFMA true   // -DGUSTO_USE_MFMA=false: the VALU two-step contraction instead (A/B measurements)
+#endif
 template <int MODEL> struct MT;
 template <> struct MT<GUSTO_FREEFLYER_SE2> {
     static constexpr int n = 6, m = 3, WS = 2, NFIX = 3, NHU = 2;
     static constexpr int WAVES_PER_EU = GUSTO_WAVES_PER_EU;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
+    static constexpr bool MFMA = false;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
     static constexpr bool LTI = true, HAS_OBS = true;
     // Double integrator (freeflyer_se2.jl:121,178-179: A = [0 I; 0 0], B = [0; diag]): Phi = I + dt A and
     // Gam = 2 (I + dt/2 A) b have at most TWO nonzeros per column of [Phi Gam], at rows pg_r0(c), pg_r1(c)
@@ -50,6 +55,7 @@ template <> struct MT<GUSTO_DUBINS_CAR> {
     static constexpr int n = 3, m = 1, WS = 2, NFIX = 6, NHU = 2;
     static constexpr int WAVES_PER_EU = 2;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
+    static constexpr bool MFMA = false;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
     static constexpr bool LTI = false, HAS_OBS = false;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
@@ -63,6 +69,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3> {
     static constexpr int n = 12, m = 6, WS = 3, NFIX = 3, NHU = 2;
     static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true;   // factor sweep as a function call (ipm.hpp:factor_sweep)
+    static constexpr bool MFMA = GUSTO_USE_MFMA;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
@@ -78,6 +85,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr int n = 13, m = 6, WS = 3, NFIX = 5, NHU = 2;
     static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true ;   // factor sweep as a function call (ipm.hpp:factor_sweep)
+    static constexpr bool MFMA = GUSTO_USE_MFMA;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }

@@ -5,9 +5,15 @@ import numpy as np
 import gusto_jl_amd as g
 P = g.problems
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-x0, glo, ghi, tf = P.freeflyer_batch(B)
-boxes = None if (len(sys.argv) > 2 and sys.argv[2] == 'noobs') else P.freeflyer_env()
-s = g.BatchSolver(g.FREEFLYER_SE2, 50, B, hist_cap=64, boxes=boxes)
+model = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+spheres = None
+if model == 0:
+    x0, glo, ghi, tf = P.freeflyer_batch(B); boxes = P.freeflyer_env()
+elif model == 2:
+    x0, glo, ghi, tf = P.astrobee_se3_batch(B); boxes, spheres = P.iss_corner_env(True)
+else:
+    x0, glo, ghi, tf = P.astrobee_manifold_batch(B); boxes, spheres = P.iss_corner_env(True)
+s = g.BatchSolver(model, 50, B, hist_cap=64, boxes=boxes, spheres=spheres)
 for rep in range(2):
     s.set_problems(x0, glo, ghi, tf); s.solve(30)
 st = s.status()

@@ -42,6 +42,17 @@ for p in sorted(glob.glob(os.path.join(src, "sq", "*counter_collection.csv"))):
         if "scp_kernel" in k:
             sq.update(v)
 out["sq_counters_per_launch"] = sq
+mf = {}
+for m, cfg in ((2, "config4_astrobee_se3"), (3, "config5_manifold")):
+    f_ = os.path.join(src, f"mfma_m{m}", "c_counter_collection.csv")
+    if os.path.exists(f_):
+        for k, v in per_kernel(f_).items():
+            if "scp_kernel" in k:
+                mf[cfg] = dict(v)
+                if v.get("SQ_BUSY_CYCLES"):
+                    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles, SQ_BUSY_CYCLES quad-cycles per SE... report the raw ratio to wave cycles
+                    mf[cfg]["mfma_busy_over_wave_cycles"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * v.get("SQ_WAVE_CYCLES", 1.0))
+out["mfma_counters_per_solve"] = mf
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "pmc", "FETCH_SIZE_counter_collection.csv"), os.path.join(dst, f"{tag}_pmc_FETCH_SIZE.csv"))
 shutil.copy(os.path.join(src, "pmc", "WRITE_SIZE_counter_collection.csv"), os.path.join(dst, f"{tag}_pmc_WRITE_SIZE.csv"))

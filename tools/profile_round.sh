@@ -27,4 +27,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
   name=$(echo $set | tr ' ' '+' | cut -c1-40)
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/sq -o "$name" -- python tools/pmc_probe.py > "$OUT/sq_$name.log" 2>&1
 done
+for m in 2 3; do   # matrix-core counters of the 12/13-state kernels (v_mfma_f64_16x16x4_f64 in the factor sweep)
+  timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/mfma_m$m -o c -- python tools/bench_configs.py $m > $OUT/mfma_m$m.log 2>&1
+done
 ls -R $OUT | head -80
