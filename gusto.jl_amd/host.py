@@ -88,7 +88,7 @@ class BoxGoal:
 class Goal:
     def __init__(self, params, t_guess, ind_coordinates):
         """ind_coordinates: a model (all coordinates) or 0-based indices (the reference is 1-based)."""
-        self.params, self.t_guess = params, float(t_guess)
+        self.params, self.t_guess, self.k_timestep, self.t_final = params, float(t_guess), None, None
         if isinstance(ind_coordinates, _Model):
             ind_coordinates = range(ind_coordinates.x_dim)
         self.ind_coordinates = np.asarray(list(ind_coordinates), int)
@@ -134,11 +134,26 @@ class Trajectory:
 
 
 class TrajectoryOptimizationProblem:
+    """types.jl:48-61,228.  fixed_final_time=False mirrors what the reference actually does with it: `Tf` becomes a free
+    JuMP variable with the single row `Tf >= 0.1` (scp_gusto.jl:185-187,248-250), but no dynamics row, cost term or
+    trust region contains it -- the trapezoid rows use traj_prev.dt (freeflyer_se2.jl:170) -- so the subproblem leaves
+    it at its start value tf_guess (scp_gusto.jl:102) and every trip runs with dt = tf_guess/(N-1).  The mirror keeps
+    Tf = tf_guess and enforces the one row there is."""
+
     def __init__(self, PD, N, tf_guess, fixed_final_time=False):
-        if not fixed_final_time:
-            raise NotImplementedError("free final time: the reference's dynamics use traj_prev.dt, i.e. Tf never "
-                                      "enters the subproblem (freeflyer_se2.jl:170); only fixed_final_time is mirrored")
-        self.PD, self.N, self.tf_guess, self.fixed_final_time = PD, int(N), float(tf_guess), True
+        if not fixed_final_time and tf_guess < 0.1:
+            raise ValueError("free final time: the only row on Tf is Tf >= 0.1 (scp_gusto.jl:248-250); tf_guess violates it")
+        self.PD, self.N, self.tf_guess, self.fixed_final_time = PD, int(N), float(tf_guess), bool(fixed_final_time)
+        assign_timesteps(PD.goal_set, self.N, self.tf_guess)       # types.jl:58 via the constructor at :228
+
+
+def assign_timesteps(goal_set, N, tf_guess):
+    """goals.jl:18-22, literally: k_timestep = fld(N*tf_guess, N*t_guess) = floor(tf_guess / t_guess) -- 1 for a goal at the
+    final time, NOT its knot index.  Nothing reads it for placement: the goal row functions hard-code knot N
+    (dynamics.jl:33,40) and SCPConstraints only registers the goals whose time equals tf_guess (freeflyer_se2.jl:352-358),
+    so goals at intermediate times are carried in the GoalSet and ignored by the solve -- here exactly as there."""
+    for g in goal_set.goals:
+        g.k_timestep = int((N * tf_guess) // (N * g.t_guess)) if g.t_guess > 0 else None
 
 
 class SCPProblem:
@@ -173,7 +188,8 @@ def init_traj_straightline(TOP):
     """freeflyer_se2.jl:97-111: linear interpolation x_init -> centre of the goals at the final time, U = 0."""
     n, m, N = TOP.PD.model.x_dim, TOP.PD.model.u_dim, TOP.N
     lo, hi = _goal_bounds(TOP.PD.goal_set, n, TOP.tf_guess)
-    xg = np.where(np.isfinite(lo) & np.isfinite(hi), 0.5 * (lo + hi), 0.0)
+    fin = np.isfinite(lo) & np.isfinite(hi)
+    xg = np.where(fin, 0.5 * (np.where(fin, lo, 0.0) + np.where(fin, hi, 0.0)), 0.0)
     t = np.arange(N) / (N - 1)
     X = (1 - t)[None, :] * TOP.PD.x_init[:, None] + t[None, :] * xg[:, None]
     return Trajectory(X, np.zeros((m, N)), TOP.tf_guess)
