@@ -98,8 +98,8 @@ def test_host_mirror_goal_flattening_and_straight_line():
     assert np.allclose(traj.X[:, 0], x_init) and np.allclose(traj.X[6:10, -1], q_goal)     # centre of the box goal
     # quaternions are interpolated linearly, i.e. not unit norm mid-way (SURVEY.md a5 note)
     assert np.linalg.norm(traj.X[6:10, 25]) < 1.0
-    with pytest.raises(NotImplementedError):
-        H.TrajectoryOptimizationProblem(PD, 50, 10.0, fixed_final_time=False)
+    # free final time: accepted, and as inert as in the reference (tests/test_host_cpu.py)
+    assert H.TrajectoryOptimizationProblem(PD, 50, 10.0, fixed_final_time=False).tf_guess == 10.0
 
 
 def test_problem_generators_are_reproducible():
