@@ -190,9 +190,11 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
 // kernel arguments
 struct KParams {
     int N, B, n_obs, n_box, n_sph, hist_cap, max_iter, force, mode;  // mode 0: SCP solve, 1: one subproblem
-    int cont;           // 1: second launch of the same gusto_solve call (longest-first schedule, launch.hpp)
-    const int* order;   // queue position -> problem index (nullptr: identity)
-    int* queue;         // work queue head of this launch: persistent workgroups pull queue positions with atomicAdd
+    int probe_visits;   // longest-first schedule: a problem's first `probe_visits` time slices are ONE trip each (0: off)
+    int* queue;         // scheduler state of this launch (Sched below): persistent workgroups pull work with atomics
+    int* lists;         // [SCHED_LEVELS][list_cap] problems waiting for their next slice, by penalty level; entries start
+                        // at -1; an entry is (slices so far << 24) | problem
+    int list_cap;       // probe_visits * B: a problem is pushed at most once per probing slice
     gusto_scp_params sp;
     gusto_model_params mp;
     gusto_ipm_opts io;
@@ -215,7 +217,11 @@ struct KParams {
     WsLayout wl;
     LdsLayout ll;
 };
-constexpr int ST_ITER = 0, ST_CONV = 1, ST_SUCC = 2, ST_STOP = 3, ST_IPM = 4, ST_NHIST = 5, ST_NJ = 6, ST_NRHO = 7, ST_WARM = 8, ST_NI = 9;
+constexpr int ST_ITER = 0, ST_CONV = 1, ST_SUCC = 2, ST_STOP = 3, ST_IPM = 4, ST_NHIST = 5, ST_NJ = 6, ST_NRHO = 7, ST_WARM = 8,
+              ST_CAP = 9 /* iter_cap of the running gusto_solve call */, ST_VISITS = 10 /* time slices so far */, ST_NI = 11;
+// scheduler words in KParams::queue
+constexpr int SCHED_LEVELS = 16, SQ_HEAD_A = 0, SQ_PROBING = 1 /* problems that may still be pushed */, SQ_TAIL = 2 /* [level] */, SQ_HEAD = 2 + SCHED_LEVELS /* [level] */,
+              SQ_WORDS = 2 + 2 * SCHED_LEVELS;
 constexpr int SD_TOGGLE = 0, SD_DUAL = 2, SD_ND = 2 + GUSTO_MAXN;
 
 // ---- optional phase timers (compile with -DGUSTO_PROFILE) ---------------------------------------------

@@ -29,9 +29,11 @@ struct gusto_handle_s {
     double last_ms = 0.0;
     bool pending = false;  // a gusto_solve_async launch has not been waited for yet
     int probe_iters = 2, probe_min_batch = 2048;  // longest-first schedule (gusto_set_schedule)
-    int* d_order = nullptr;
+    int* d_order = nullptr;   // waiting lists of the scheduler, [SCHED_LEVELS][probe_iters * batch_cap]
+    size_t order_ints = 0;
     int* d_queue = nullptr;   // work-queue heads, one per launch of a gusto_solve call
     int slots = 0;            // resident workgroups the last launch used (persistent kernel)
+    int sched_init[gusto::SQ_WORDS] = {0};   // initial scheduler words of a launch (host side of an async copy)
     bool have_problems = false;
     std::string err;
 };

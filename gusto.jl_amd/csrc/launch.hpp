@@ -28,7 +28,7 @@ template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B) {
     P.ipm_it = h->d_ipm;
     P.wl = make_ws_layout<MODEL>(h->N, P.n_obs);
     P.ll = make_lds_layout<MODEL>(h->N);
-    if (!h->d_queue) HIPCHK(h, dalloc(&h->d_queue, 4));
+    if (!h->d_queue) HIPCHK(h, dalloc(&h->d_queue, (size_t)SQ_WORDS));
 #ifdef GUSTO_PROFILE
     if (!h->d_prof) HIPCHK(h, dalloc(&h->d_prof, (size_t)h->batch_cap * PROF_N));
 #endif
@@ -66,24 +66,29 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
         }
         P.ws = h->d_ws;
     }
-    HIPCHK(h, hipMemsetAsync(h->d_queue, 0, 4 * sizeof(int), h->stream));
-    P.queue = h->d_queue;
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    // Longest-first schedule for big batches.  Workgroups are dispatched in index order onto ~4 slots per CU, so a
-    // long problem with a high index starts late and the batch ends with a few problems on an empty GPU (44 % of
-    // the slot-time of a freeflyer batch of 4096).  Every problem first runs `probe_iters` trips; the rest of the
-    // solve is then launched in order of decreasing penalty weight (scp.hpp:order_kernel).  Results are
-    // bit-identical to the single launch: the second launch continues each problem's state machine.
-    const bool split = mode == 0 && h->probe_iters > 0 && max_iter > h->probe_iters && h->B >= h->probe_min_batch;
-    if (split) {
-        if (!h->d_order) HIPCHK(h, dalloc(&h->d_order, (size_t)h->batch_cap));
-        P.max_iter = h->probe_iters;
-        hipLaunchKernelGGL(kern, dim3(slots), dim3(NT), lds, h->stream, P);
-        HIPCHK(h, hipGetLastError());
-        hipLaunchKernelGGL(order_kernel<MODEL>, dim3(1), dim3(256), 0, h->stream, P, h->d_order);
-        HIPCHK(h, hipGetLastError());
-        P.max_iter = max_iter - h->probe_iters; P.cont = 1; P.order = h->d_order; P.queue = h->d_queue + 1;
+    // scheduler state of this launch (scp.hpp): counters to 0, waiting lists to -1
+    const bool dyn = mode == 0 && h->probe_iters > 0 && h->probe_iters < 128 && max_iter > h->probe_iters &&
+                     h->B >= h->probe_min_batch && h->B < (1 << 24);
+    memset(h->sched_init, 0, sizeof(h->sched_init));
+    h->sched_init[SQ_PROBING] = dyn ? h->B : 0;     // every problem starts with its probing slices still ahead
+    HIPCHK(h, hipMemcpyAsync(h->d_queue, h->sched_init, SQ_WORDS * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (dyn) {
+        const size_t need = (size_t)SCHED_LEVELS * h->probe_iters * h->batch_cap;
+        if (need > h->order_ints) {
+            if (h->d_order) hipFree(h->d_order);
+            h->d_order = nullptr; h->order_ints = 0;
+            HIPCHK(h, dalloc(&h->d_order, need));
+            h->order_ints = need;
+        }
+        P.list_cap = h->probe_iters * h->B;
+        HIPCHK(h, hipMemsetAsync(h->d_order, 0xFF, (size_t)SCHED_LEVELS * P.list_cap * sizeof(int), h->stream));
     }
+    P.queue = h->d_queue; P.lists = h->d_order; P.probe_visits = dyn ? h->probe_iters : 0;
+    if (getenv("GUSTO_DEV_DEBUG"))
+        fprintf(stderr, "launch: B %d slots %d dyn %d probe %d list_cap %d queue %p lists %p..%p ws %p..%p X %p st_i %p..%p hist Delta %p\n", h->B, slots,
+                (int)dyn, P.probe_visits, P.list_cap, (void*)P.queue, (void*)P.lists, (void*)(P.lists + h->order_ints), (void*)P.ws,
+                (void*)(P.ws + h->ws_doubles), (void*)P.X, (void*)P.st_i, (void*)(P.st_i + (size_t)h->batch_cap * ST_NI), (void*)P.Delta);
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(kern, dim3(slots), dim3(NT), lds, h->stream, P);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));

@@ -75,8 +75,10 @@ template <class BLK> GD void store_traj(BLK& K, const double* Xs, const double* 
     for (int e = K.tid; e < K.N * m; e += K.nt()) Ug[e] = Us[e];
 }
 
-// One problem, start to stop: the body of the persistent kernel below.
-template <int MODEL, bool ONEWAVE> GD void scp_problem(const KParams& P, double* lds, int b_, int slot) {
+// One time slice of one problem: the body of the persistent kernel below.  `cont` = the problem has run before in this
+// gusto_solve call (no new leading history entries), `trips` = how many GuSTO trips this slice may take.  Returns the
+// penalty level of the problem (number of omega raises so far) if it has to come back for another slice, -1 if it stopped.
+template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* lds, int b_, int slot, bool cont, int trips) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m;
     Blk<MODEL, ONEWAVE> K(P, lds, b_, slot);
@@ -95,10 +97,8 @@ template <int MODEL, bool ONEWAVE> GD void scp_problem(const KParams& P, double*
     const size_t hb = (size_t)b * P.hist_cap;
     int iterations = sti[ST_ITER], converged = sti[ST_CONV], successful = sti[ST_SUCC], stop = GUSTO_STOP_MAXITER;
     int total_ipm = sti[ST_IPM], n_hist = sti[ST_NHIST], nJ = sti[ST_NJ], n_rho = sti[ST_NRHO];
-    const int iter_cap = iterations + P.max_iter;  // scp_gusto.jl:67
-    // second launch of one gusto_solve call: problems that already stopped are done, the others carry on exactly
-    // where the first launch left them (no new leading history entries)
-    if (P.cont && sti[ST_STOP] != GUSTO_STOP_MAXITER) return;
+    const int call_cap = cont ? sti[ST_CAP] : iterations + P.max_iter;  // scp_gusto.jl:67 (of the whole gusto_solve call)
+    const int iter_cap = (trips < call_cap - iterations) ? iterations + trips : call_cap;   // ... of this slice
 
     // K.Xp / K.Up are the stored trajectory (SCPS.traj) itself
     // scp_gusto.jl:73-76
@@ -108,7 +108,7 @@ template <int MODEL, bool ONEWAVE> GD void scp_problem(const KParams& P, double*
         rho0v = trust_region_ratio<MODEL>(K, K.Xp, K.Up, K.Xp, K.Up);
     }
     double Delta = hook ? P.sub_Delta[b] : P.Delta[hb + n_hist - 1], omega = hook ? P.sub_omega[b] : P.omega[hb + n_hist - 1];
-    if (!P.cont && !hook) {
+    if (!cont && !hook) {
         if (tid == 0 && nJ < P.hist_cap) { P.J_true[hb + nJ] = Jt; P.J_full[hb + nJ] = Jt; }
         if (tid == 0 && n_rho < P.hist_cap) P.rho[hb + n_rho] = rho0v;
         nJ++; n_rho++;
@@ -130,7 +130,7 @@ template <int MODEL, bool ONEWAVE> GD void scp_problem(const KParams& P, double*
                 P.sub_obj[b] = io.obj; P.sub_status[b] = io.status; P.sub_iters[b] = io.iters;
                 for (int i = 0; i < n; i++) P.st_d[(size_t)b * SD_ND + SD_DUAL + i] = K.nu[i] * fmax(1.0, omega);
             }
-            return;
+            return -1;
         }
         warm = io.status == GUSTO_SOLVER_OPTIMAL;
         total_ipm += io.iters;
@@ -214,41 +214,139 @@ template <int MODEL, bool ONEWAVE> GD void scp_problem(const KParams& P, double*
             if (!P.force) { stop = GUSTO_STOP_CONVERGED; break; }
         }
     }
+    // more trips of this call remain: the problem goes back to the scheduler with its penalty level
+    const bool again = stop == GUSTO_STOP_MAXITER && iterations == iter_cap && iterations < call_cap &&
+                       n_hist < P.hist_cap && nJ < P.hist_cap && n_rho < P.hist_cap;
     // a history vector is full although iterations remain: say so instead of posing as MaxIter
-    if (stop == GUSTO_STOP_MAXITER && iterations < iter_cap) stop = GUSTO_STOP_HIST_FULL;
+    if (stop == GUSTO_STOP_MAXITER && !again && iterations < call_cap) stop = GUSTO_STOP_HIST_FULL;
     pf.tick(PF_SCP);
     pf.flush(P.prof, b);
     if (tid == 0) {
         sti[ST_ITER] = iterations; sti[ST_CONV] = converged; sti[ST_SUCC] = successful; sti[ST_STOP] = stop;
         sti[ST_IPM] = total_ipm; sti[ST_NHIST] = n_hist; sti[ST_NJ] = nJ; sti[ST_NRHO] = n_rho; sti[ST_WARM] = warm;
+        sti[ST_CAP] = call_cap; sti[ST_VISITS] = (cont ? sti[ST_VISITS] : 0) + 1;
         std_[SD_TOGGLE] = toggle;
+    }
+    if (!again) return -1;
+    int lvl = 0;   // the long problems are almost exactly those whose penalty weight was raised early (:137-147)
+    for (double x = 1.5 * sp.omega0; x < omega && lvl < SCHED_LEVELS - 1; x *= sp.gamma_fail) lvl++;
+    return lvl;
+}
+
+// ---- scheduler of the persistent kernel -------------------------------------------------------------------------------
+// PERSISTENT workgroups (the grid is the number of resident slots, launch.hpp) pull work until every problem of the
+// batch has stopped.  Problem lengths vary 5...30 trips and are not known in advance; with first-come-first-served a long
+// problem that starts late leaves the GPU empty at the end (makespan 674 "KKT units" against 374 balanced and 415 for the
+// longest problem, freeflyer B = 4096).  So a problem's first `probe_visits` slices are ONE trip each, after which it goes
+// into the list of its penalty level (omega raises so far: the long problems are those raised early); workgroups take
+// fresh problems while there are any, then always the highest level waiting, and from slice probe_visits on a problem
+// runs to its end (simulated makespan 473).  Slicing is free: between trips a problem's whole state lives in HBM
+// (trajectory, histories, st_i), so results are bit-identical to an unsliced run.
+//   hand-off of a problem between workgroups (possibly on different XCDs): the producer writes the state, releases at
+//   agent scope, then publishes the list entry; the consumer claims an index, spins until the entry is there, acquires.
+constexpr int SCHED_SPIN_LIMIT = 1 << 20;   // (seconds of sleeping polls: a scheduler bug must not hang the GPU)
+// wave-uniform primitives: every lane of the wave executes them, the result is the same scalar in every lane
+GD int uload(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+GD int uadd(int* p, int v) {
+    int r = 0;
+    if ((threadIdx.x & 63) == 0) r = atomicAdd(p, v);
+    return __builtin_amdgcn_readfirstlane(r);
+}
+GD int ucas(int* p, int expected, int desired) {   // returns the value found (== expected: the swap happened)
+    int r = expected;
+    if ((threadIdx.x & 63) == 0)
+        __hip_atomic_compare_exchange_strong(p, &r, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(r);
+}
+// Next piece of work for this workgroup: a fresh problem (cont = false), else the entry (slices so far << 24 | problem)
+// at the head of the highest non-empty level list, else -1 when nothing can come any more.  Executed by a WHOLE wave
+// with uniform control flow: a polling loop with exits under `if (lane == 0)` does not survive the compiler's
+// structurizer when the other lanes stay in the outer loop (the wave never reconverges; found the hard way).
+GD int sched_pop(const KParams& P, bool& cont) {
+    int* Q = P.queue;
+    for (int spin = 0;; spin++) {
+        const int probing_seen = uload(Q + SQ_PROBING);   // BEFORE the scan: a push is published before SQ_PROBING drops
+        if (uload(Q + SQ_HEAD_A) < P.B) {
+            const int q = uadd(Q + SQ_HEAD_A, 1);
+            if (q < P.B) { cont = false; return q; }
+        }
+        for (int L = SCHED_LEVELS - 1; L >= 0; L--) {
+            int h = uload(Q + SQ_HEAD + L);
+            while (h < uload(Q + SQ_TAIL + L)) {
+                const int found = ucas(Q + SQ_HEAD + L, h, h + 1);
+                if (found == h) {     // index h is ours; its entry follows the tail increment that made it visible
+                    int e = -1;
+                    for (int w = 0; w < SCHED_SPIN_LIMIT && (e = uload(P.lists + (size_t)L * P.list_cap + h)) < 0; w++)
+                        __builtin_amdgcn_s_sleep(2);
+                    if (e < 0) return -1;
+                    cont = true;
+                    return e;
+                }
+                h = found;
+            }
+        }
+        // Nothing to take.  More can only come from problems still in their probing slices; once there are none, this
+        // workgroup retires and frees its slot -- the tail of a batch then overlaps the head of the next one enqueued on
+        // another stream.
+        if (probing_seen == 0 || spin > SCHED_SPIN_LIMIT) return -1;
+        if (spin < 16) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
     }
 }
 
-// The kernel: PERSISTENT workgroups (the grid is the number of resident slots, launch.hpp) pull problems from a work
-// queue -- one atomicAdd per problem on P.queue -- until it is empty.  A problem that needs 30 trips and one that needs
-// 5 occupy their slot for different times and the queue backfills; P.order (longest-first schedule) maps queue
-// positions to problems.  Problems are independent: no grid-wide synchronisation, no inter-workgroup data.
 template <int MODEL, bool ONEWAVE> __global__ void __launch_bounds__(ONEWAVE ? 64 : 256, ONEWAVE ? MT<MODEL>::WAVES_PER_EU : 1)
 scp_kernel(const KParams P) {
     extern __shared__ double lds[];
     const int slot = blockIdx.x;
     for (;;) {
-        int q = 0;
-        if (threadIdx.x == 0) q = atomicAdd(P.queue, 1);
+        int b = 0, ci = 0;
         if constexpr (ONEWAVE) {
-            q = __builtin_amdgcn_readfirstlane(q);
+            bool c = false;
+            b = sched_pop(P, c); ci = c;
         } else {
-            __shared__ int q_sh;
-            __syncthreads();               // (also: everyone is done with the previous problem's LDS)
-            if (threadIdx.x == 0) q_sh = q;
+            __shared__ int sh_b, sh_cont;
+            __syncthreads();               // (everyone is done with the previous problem's LDS)
+            if (threadIdx.x < 64) {        // wave 0 asks the scheduler, the others get the answer through LDS
+                bool c = false;
+                b = sched_pop(P, c);
+                if (threadIdx.x == 0) { sh_b = b; sh_cont = c; }
+            }
             __syncthreads();
-            q = q_sh;
+            b = sh_b; ci = sh_cont;
         }
-        if (q >= P.B) return;
-        const int b = P.order ? P.order[q] : q;
-        scp_problem<MODEL, ONEWAVE>(P, lds, b, slot);
+        if (b < 0) return;
+        const bool cont = ci != 0;
+        const int visits = cont ? (b >> 24) : 0;     // time slices this problem has had in this gusto_solve call
+        b &= (1 << 24) - 1;
+        // hipcc (ROCm 7.2) otherwise forms some of the problem's base addresses from the UNMASKED register (seen in the
+        // ISA: s_and_b32 for tf[b], but v_mad_u64_u32 with the raw entry for goal_lo + b * n): pin the masked value
+        asm volatile("" : "+v"(b));
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (cont) {   // the state another workgroup left in HBM: drop whatever this CU's L1 still holds of it.  ONE lane
+            // issues the invalidate (the L1 is the CU's, not the lane's), then the workgroup synchronises.
+            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            blk_sync<ONEWAVE>();
+        }
+#ifdef GUSTO_SCHED_DEBUG
+        if (b >= P.B) { if (threadIdx.x == 0) printf("sched: bad b %d (ci %d visits %d) slot %d\n", b, ci, visits, slot); return; }
+#endif
+        const int trips = (P.mode == 0 && visits < P.probe_visits) ? 1 : (1 << 30);
+        const int lvl = scp_problem<MODEL, ONEWAVE>(P, lds, b, slot, cont, trips);
         blk_sync<ONEWAVE>();               // the next problem reuses this workgroup's LDS and workspace slot
+        if constexpr (!ONEWAVE) __syncthreads();
+        if (threadIdx.x == 0) {
+#ifdef GUSTO_SCHED_DEBUG
+            printf("sched: slot %d problem %d cont %d visits %d trips %d -> lvl %d\n", slot, b, (int)cont, visits, trips, lvl);
+#endif
+            if (lvl >= 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // state first ...
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int idx = atomicAdd(P.queue + SQ_TAIL + lvl, 1);
+                __hip_atomic_store(P.lists + (size_t)lvl * P.list_cap + idx, ((visits + 1) << 24) | b, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);                                                        // ... then the entry
+            }
+            // this was the problem's last probing slice (or it stopped inside one): it will not be pushed again
+            if (trips == 1 && (lvl < 0 || visits + 1 >= P.probe_visits)) atomicSub(P.queue + SQ_PROBING, 1);
+        }
     }
 }
 
@@ -268,48 +366,6 @@ template <int MODEL> __global__ void init_straightline_kernel(const KParams P) {
     }
 #pragma unroll
     for (int i = 0; i < m; i++) P.U[((size_t)b * P.N + k) * m + i] = 0.0;
-}
-
-// Longest-first order for the second launch of a gusto_solve call.  Problem lengths are not known in advance, but
-// the long ones are almost exactly those whose penalty weight omega was raised during their first trips
-// (ViolatesConstraints / TrustRegionViolated, scp_gusto.jl:137-147).  Key = number of omega raises so far, problems
-// that already stopped last; counting sort by descending key, stable in the problem index.  One workgroup.
-template <int MODEL> __global__ void __launch_bounds__(256) order_kernel(const KParams P, int* order) {
-    constexpr int NB = 16, NT = 256, KC = 16;
-    __shared__ int cnt[NB][NT + 1];
-    __shared__ int base[NB];
-    const int t = threadIdx.x, B = P.B;
-    const int chunk = (B + NT - 1) / NT, b0 = t * chunk, b1 = min(B, b0 + chunk);
-    auto key = [&](int b) {
-        const int* sti = P.st_i + (size_t)b * ST_NI;
-        if (sti[ST_STOP] != GUSTO_STOP_MAXITER) return 0;
-        const double w = P.omega[(size_t)b * P.hist_cap + sti[ST_NHIST] - 1] / P.sp.omega0;
-        int lvl = 0;
-        for (double x = 1.5; x < w && lvl < NB - 2; x *= P.sp.gamma_fail) lvl++;
-        return 1 + lvl;
-    };
-    int kc[KC];   // keys of this thread's problems (batches up to NT * KC problems: no second trip to memory)
-    for (int q = 0; q < NB; q++) cnt[q][t] = 0;
-#pragma unroll
-    for (int i = 0; i < KC; i++) kc[i] = (b0 + i < b1) ? key(b0 + i) : -1;
-#pragma unroll
-    for (int i = 0; i < KC; i++) if (kc[i] >= 0) cnt[kc[i]][t]++;
-    for (int b = b0 + KC; b < b1; b++) cnt[key(b)][t]++;
-    __syncthreads();
-    if (t < NB) {   // exclusive prefix of row t over the threads; row totals -> offsets in descending key order
-        int acc = 0;
-        for (int u = 0; u < NT; u++) { const int c = cnt[t][u]; cnt[t][u] = acc; acc += c; }
-        cnt[t][NT] = acc;
-    }
-    __syncthreads();
-    if (t == 0) {
-        int acc = 0;
-        for (int q = NB - 1; q >= 0; q--) { base[q] = acc; acc += cnt[q][NT]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < KC; i++) if (kc[i] >= 0) order[base[kc[i]] + cnt[kc[i]][t]++] = b0 + i;
-    for (int b = b0 + KC; b < b1; b++) { const int q = key(b); order[base[q] + cnt[q][t]++] = b; }
 }
 
 // SCPSolution(SCPP, traj_init) + SCPParam_GuSTO ctor (types.jl:233, scp_gusto.jl:21-23)

@@ -89,10 +89,12 @@ int gusto_set_ipm_opts(gusto_handle h, const gusto_ipm_opts* o);
 /* Workspace(robot, env) (types.jl:12-24): keep-out set = keepout_zones then obstacle_set, as AABBs
  * (min xyz, max xyz) followed by spheres (centre xyz, radius) */
 int gusto_set_env(gusto_handle h, int n_box, const double* box_min_max, int n_sph, const double* sph_c_r);
-/* Longest-first schedule of a gusto_solve call (new; affects time only, results are bit-identical): batches of at
- * least `min_batch` problems first run `probe_iters` SCP iterations of every problem, then the rest of the solve in
- * order of decreasing penalty weight omega -- the problems whose omega was raised early are the long ones.
- * probe_iters = 0 disables it.  Default (2, 2048). */
+/* Longest-first schedule of a gusto_solve call (new; affects time only, results are bit-identical).  gusto_solve is ONE
+ * launch of persistent workgroups that pull work from a device-side scheduler.  In batches of at least `min_batch`
+ * problems the first `probe_iters` time slices of a problem are one SCP iteration each; between slices the problem
+ * waits in the list of its penalty level (number of omega raises so far -- the problems whose omega was raised early are
+ * the long ones) and workgroups always take the highest level waiting; from slice `probe_iters` on a problem runs to
+ * its end.  probe_iters = 0: first come, first served.  Default (2, 2048). */
 int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch);
 /* run on a caller-owned hipStream_t (NULL = a new stream owned by the handle).  Like every setter it first completes
  * a pending gusto_solve_async on the stream that solve was enqueued on. */
