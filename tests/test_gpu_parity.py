@@ -731,3 +731,55 @@ def test_device_views_of_the_trajectories():
     assert np.array_equal(Xd.cpu().numpy(), X) and np.array_equal(Ud.cpu().numpy(), U)
     out = g.host.gather_batch_results(dict(X=Xd, U=Ud), 1, 0)
     assert out["X"] is Xd
+
+
+def _full_batch_astrobee(model_id, B, batch, eps_q=None):
+    """Size-independent properties at a BASELINE.json batch size: bitwise determinism, order independence, hard rows."""
+    g, _ = _mods()
+    P = g.problems
+    N = 50
+    boxes, sph = P.iss_corner_env(True)
+    x0, glo, ghi, tf = batch
+    n, m = g.MODEL_DIMS[model_id] if hasattr(g, "MODEL_DIMS") else g._capi.MODEL_DIMS[model_id]
+    s = g.BatchSolver(model_id, N, B, hist_cap=40, boxes=boxes, spheres=sph)
+    s.set_problems(x0, glo, ghi, tf)
+    s.solve(30)
+    X1, U1 = s.traj()
+    st = s.status()
+    perm = np.random.default_rng(1).permutation(B)
+    s.set_problems(x0[perm], glo[perm], ghi[perm], tf[perm])
+    s.solve(30)
+    X2, U2 = s.traj()
+    np.testing.assert_array_equal(X1[perm], X2)          # same problem, other slot / other batch position: same bits
+    np.testing.assert_array_equal(U1[perm], U2)
+    assert st["converged"].mean() > 0.9 and (st["stop_reason"] != 4).all()
+    mp = g.default_params(model_id)[1]
+    assert np.abs(X1[:, 0, :] - x0).max() < 1e-9                                         # init rows
+    pt = glo == ghi
+    assert np.abs(np.where(pt, X1[:, -1, :] - glo, 0.0)).max() < 1e-6                    # point goal rows
+    box = np.isfinite(glo) & np.isfinite(ghi) & ~pt
+    assert (np.where(box, X1[:, -1, :] - ghi, -1.0) <= 1e-7).all() and (np.where(box, glo - X1[:, -1, :], -1.0) <= 1e-7).all()
+    acc = np.linalg.norm(U1[:, :-1, 0:3], axis=2) / mp.mass                              # hard control rows, k = 1..N-1
+    alp = np.linalg.norm(U1[:, :-1, 3:6] / np.array(mp.Jdiag), axis=2)
+    assert acc.max() <= mp.hard_limit_accel * (1 + 1e-6) and alp.max() <= mp.hard_limit_alpha * (1 + 1e-6)
+    # successful problems keep the penalised rows within eps (convex_ineq_satisfied_gusto_jump)
+    ok = st["successful"]
+    sp = g.default_params(model_id)[0]
+    v2 = (X1[ok][:, :, 3:6] ** 2).sum(2)
+    assert (v2 - mp.hard_limit_vel ** 2).max() < sp.eps
+    return X1, st
+
+
+def test_full_batch_properties_astrobee_se3():
+    """BASELINE.json configs[3] at full size: astrobeeSE3, B = 8192, N = 50, ISS corner + obstacle set (32 components)."""
+    g, _ = _mods()
+    _full_batch_astrobee(g.ASTROBEE_SE3, 8192, g.problems.astrobee_se3_batch(8192))
+
+
+def test_full_batch_properties_astrobee_manifold():
+    """BASELINE.json configs[4] at full size: astrobeeSE3manifold, B = 2048, N = 50 (tf = 40)."""
+    g, _ = _mods()
+    X, st = _full_batch_astrobee(g.ASTROBEE_SE3_MANIFOLD, 2048, g.problems.astrobee_manifold_batch(2048))
+    # the linearised unit-norm row keeps |q| near 1 along successful trajectories (eps = 0.1 on the penalised row)
+    qn = np.linalg.norm(X[st["successful"]][:, :, 6:10], axis=2)
+    assert np.abs(qn - 1).max() < 0.2
