@@ -24,7 +24,7 @@ SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims",
            "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_solve_async", "gusto_wait",
            "gusto_last_solve_ms", "gusto_get_traj",
            "gusto_get_traj_dev", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_get_hist_cap",
-           "gusto_set_trust_state", "gusto_subproblem"]
+           "gusto_set_trust_state", "gusto_subproblem", "gusto_default_shoot_opts", "gusto_shoot", "gusto_get_shoot"]
 
 
 class ScpParams(C.Structure):
@@ -46,6 +46,10 @@ class IpmOpts(C.Structure):
                 ("mu_warm", C.c_double), ("max_iter", C.c_int)]
 
 
+class ShootOpts(C.Structure):
+    _fields_ = [("substeps", C.c_int), ("max_newton", C.c_int), ("ftol", C.c_double)]
+
+
 class History(C.Structure):
     _fields_ = [("hist_cap", C.c_int), ("n_hist", C.c_void_p), ("nJ", C.c_void_p), ("n_rho", C.c_void_p),
                 ("J_true", C.c_void_p), ("J_full", C.c_void_p), ("convergence_measure", C.c_void_p),
@@ -65,7 +69,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(_ROOT, "include"), "-fPIC",
              "-Wno-unused-value", "-Wno-pass-failed"]
-    units = ["gusto_hip", "model_0", "model_1", "model_2", "model_3"]
+    units = ["gusto_hip", "shoot", "model_0", "model_1", "model_2", "model_3"]
     bdir = os.path.join(_HERE, "build")
     os.makedirs(bdir, exist_ok=True)
 
@@ -75,7 +79,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
 
-    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         list(ex.map(cc, units))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(bdir, u + ".o") for u in units] + \
           ["-o", LIB_PATH]
@@ -123,6 +127,9 @@ def lib():
         L.gusto_get_history.argtypes = [vp, C.POINTER(History)]
         L.gusto_get_hist_cap.argtypes = [vp, C.POINTER(ci)]
         L.gusto_set_trust_state.argtypes = [vp, vp, vp]
+        L.gusto_default_shoot_opts.argtypes = [C.POINTER(ShootOpts)]
+        L.gusto_shoot.argtypes = [vp, vp, C.POINTER(ShootOpts)]
+        L.gusto_get_shoot.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.gusto_subproblem.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
@@ -282,6 +289,19 @@ class BatchSolver:
         self._chk(self.L.gusto_get_history(self.h, C.byref(hs)), "get_history")
         out.update(cnt)
         return out
+
+    def shoot(self, p0=None, substeps=4, max_newton=100, ftol=1e-3):
+        """gusto_shoot + gusto_get_shoot: indirect shooting of every problem from p0 (default: the SCP duals)."""
+        o = ShootOpts(substeps=substeps, max_newton=max_newton, ftol=ftol)
+        pv = None if p0 is None else _arr(p0).reshape(self.B, self.n)
+        self._chk(self.L.gusto_shoot(self.h, None if pv is None else pv.ctypes.data, C.byref(o)), "shoot")
+        B = self.B
+        st, it = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        res, pp = np.zeros(B), np.zeros((B, self.n))
+        X, U = np.zeros((B, self.N, self.n)), np.zeros((B, self.N, self.m))
+        self._chk(self.L.gusto_get_shoot(self.h, st.ctypes.data, it.ctypes.data, res.ctypes.data, pp.ctypes.data,
+                                         X.ctypes.data, U.ctypes.data), "get_shoot")
+        return dict(status=st, newton_iters=it, resid=res, p0=pp, X=X, U=U)
 
     def subproblem(self, Xp, Up, Delta, omega, toggle):
         B = self.B

@@ -129,6 +129,7 @@ int gusto_destroy(gusto_handle h) {
                     h->d_Delta, h->d_omega, h->d_rho, h->d_acc, h->d_scp, h->d_sol, h->d_tr, h->d_cvx, h->d_ipm, h->d_ws,
                     h->d_prof, h->d_subD, h->d_subW, h->d_subT, h->d_subX, h->d_subU, h->d_subObj, h->d_subSt, h->d_subIt, h->d_box, h->d_sph};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (void* p : {(void*)h->d_shX, (void*)h->d_shU, (void*)h->d_shP, (void*)h->d_shP0, (void*)h->d_shRes, (void*)h->d_shSt, (void*)h->d_shIt}) if (p) hipFree(p);
     if (h->d_order) hipFree(h->d_order);
     if (h->d_queue) hipFree(h->d_queue);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -232,7 +233,7 @@ static int set_problems_impl(gusto_handle h, int B, const double* x_init, const 
     }
     int rc = do_init(h, X0 == nullptr);
     if (rc) return rc;
-    h->have_problems = true;
+    h->have_problems = true; h->have_shoot = false;
     return GUSTO_OK;
 }
 

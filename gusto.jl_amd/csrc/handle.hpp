@@ -34,7 +34,10 @@ struct gusto_handle_s {
     int* d_queue = nullptr;   // work-queue heads, one per launch of a gusto_solve call
     int slots = 0;            // resident workgroups the last launch used (persistent kernel)
     int sched_init[gusto::SQ_WORDS] = {0};   // initial scheduler words of a launch (host side of an async copy)
-    bool have_problems = false;
+    bool have_problems = false, have_shoot = false;
+    // indirect shooting (shoot.hip): trajectories, converged costates, seeds, residuals, status, Newton iterations
+    double *d_shX = nullptr, *d_shU = nullptr, *d_shP = nullptr, *d_shP0 = nullptr, *d_shRes = nullptr;
+    int *d_shSt = nullptr, *d_shIt = nullptr;
     std::string err;
 };
 

@@ -263,6 +263,93 @@ def solve_SCP(TOS, TOP, solve_method, init_method, solver="hip", max_iter=30, fo
     return SCPS
 
 
+# ---- indirect shooting seeded by the SCP dual (src/shooting.jl, src/traj_opt.jl:4-45, src/types.jl:187-227) --------------
+class ShootingProblem:
+    """types.jl:219-227: p0 = SCPS.dual, tf = SCPS.traj.Tf, x_goal = centre of the goals at the final time (zeros
+    elsewhere).  (At HEAD the constructor reads an undefined `N`; `TOP.N` is what it means.)"""
+
+    def __init__(self, TOP, SCPS):
+        n = TOP.PD.model.x_dim
+        lo, hi = _goal_bounds(TOP.PD.goal_set, n, TOP.tf_guess)
+        fin = np.isfinite(lo) & np.isfinite(hi)
+        self.PD, self.N, self.tf = TOP.PD, TOP.N, SCPS.traj.Tf
+        self.dt = self.tf / (self.N - 1)
+        self.p0 = np.array(SCPS.dual, float)
+        self.x_goal = np.where(fin, 0.5 * (np.where(fin, lo, 0.0) + np.where(fin, hi, 0.0)), 0.0)
+        self._scps = SCPS
+
+
+class ShootingSolution:
+    """types.jl:198-209"""
+
+    def __init__(self, SP, traj_init):
+        self.traj, self.SP = traj_init, SP
+        self.J_true, self.prob_status, self.convergence_measure = [], ["NA"], [float("nan")]
+        self.converged, self.iter_elapsed_times = False, [0.0]
+
+
+def cost_true(traj):
+    """freeflyer_se2.jl:66-76 / dubins_car.jl:54-69: trapezoid control effort."""
+    U = traj.U
+    return float(np.sum(0.5 * traj.dt * (U[:, :-1] ** 2 + U[:, 1:] ** 2)))
+
+
+def convergence_metric(traj, traj_prev):
+    """traj_opt.jl:74-85"""
+    return float(np.linalg.norm(traj.X - traj_prev.X, axis=0).max() / np.linalg.norm(traj.X, axis=0).max())
+
+
+def solve_shooting(SS, SP, **opts):
+    """solve!(SS, SP) (shooting.jl:4-49) on the GPU: gusto_shoot on the handle that holds the SCP state of this problem."""
+    import time
+    bs = SP._scps._solver
+    if bs is None:
+        raise _capi.GustoError("solve!(SS, SP): run solve_gusto_hip! on the SCPSolution first (it owns the device state)")
+    t0 = time.perf_counter()
+    r = bs.shoot(SP.p0[None], **opts)
+    el = time.perf_counter() - t0
+    if int(r["status"][0]) == 1:                                   # sol_newton.f_converged
+        new_traj = Trajectory(r["X"][0].T.copy(), r["U"][0].T.copy(), SP.tf)
+        SS.prob_status.append("Optimal")
+        SS.J_true.append(cost_true(new_traj))
+        SS.convergence_measure.append(convergence_metric(new_traj, SS.traj))
+        SS.traj = new_traj
+    else:
+        SS.prob_status.append("Diverged")
+        SS.J_true.append(float("nan"))
+        SS.convergence_measure.append(float("nan"))
+    SS.iter_elapsed_times.append(el)
+    SS.p0 = r["p0"][0]
+    return r
+
+
+def solve_SCPshooting(TOS, TOP, solve_method, init_method, solver="hip", max_iter=30, **kwarg):
+    """traj_opt.jl:4-45: one SCP iteration, then alternately a shooting attempt seeded by the SCP dual and another SCP
+    iteration, until two consecutive successful shooting runs agree (sum of their convergence measures below the
+    threshold) or the SCP itself converges / runs out of iterations."""
+    SCPP = SCPProblem(TOP)
+    traj_init = init_method(TOP) if callable(init_method) else init_method
+    TOS.SCPS = SCPS = SCPSolution(SCPP, traj_init)
+    SP = ShootingProblem(TOP, SCPS)
+    TOS.SS = SS = ShootingSolution(SP, Trajectory(traj_init.X.copy(), traj_init.U.copy(), traj_init.Tf))
+    solve_method(SCPS, SCPP, solver, 1, **kwarg)
+    SS.J_true.append(SCPS.J_true[0])
+    while not SCPS.converged and SCPS.iterations < max_iter:
+        SP = ShootingProblem(TOP, SCPS)
+        solve_shooting(SS, SP)
+        spread = 2
+        cm = SS.convergence_measure[-spread:]
+        if SCPS.iterations > spread and not any(np.isnan(cm)) and sum(cm) <= SCPP.scp_params.convergence_threshold:
+            SS.converged = True
+            TOS.traj = Trajectory(SS.traj.X.copy(), SS.traj.U.copy(), SS.traj.Tf)
+            TOS.total_time = SCPS.total_time + sum(SS.iter_elapsed_times)
+            return TOS
+        solve_method(SCPS, SCPP, solver, 1, **kwarg)
+    TOS.traj = Trajectory(SCPS.traj.X.copy(), SCPS.traj.U.copy(), SCPS.traj.Tf)
+    TOS.total_time = SCPS.total_time + sum(SS.iter_elapsed_times)
+    return TOS
+
+
 # ---- batch API (new: the reference has no batch mode) --------------------------------------------------------------
 def shard_bounds(B, world_size, rank):
     """Contiguous block of ceil(B/G) problems per rank; the tail rank may get fewer."""

@@ -137,6 +137,34 @@ function solve_gusto_hip!(SCPS::SCPSolution, SCPP::SCPProblem, solver="hip", max
   nothing
 end
 
+# solve!(SS, SP) on the GPU (src/shooting.jl:4-49; DubinsCar): the handle that holds the SCP state of SP's problem runs the
+# batched indirect shooting from SP.p0 (= SCPS.dual).  Use it in place of `solve!` inside solve_SCPshooting!
+# (src/traj_opt.jl:28): `ss_sol = solve_shooting_hip!(SS, SP, SCPS)`.
+struct GustoShootOpts; substeps::Cint; max_newton::Cint; ftol::Cdouble; end
+function solve_shooting_hip!(SS::ShootingSolution, SP::ShootingProblem, SCPS::SCPSolution; substeps=4, max_newton=100, ftol=1e-3)
+  h = get(GUSTO_HANDLES, SCPS, C_NULL)
+  h == C_NULL && error("solve_shooting_hip!: run solve_gusto_hip! on this SCPSolution first")
+  model, N = SP.PD.model, SP.N
+  n, m = model.x_dim, model.u_dim
+  t0 = time_ns()
+  gusto_check(ccall((:gusto_shoot, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{GustoShootOpts}),
+                    h, Float64.(SP.p0), GustoShootOpts(substeps, max_newton, ftol)), h, "shoot")
+  st, it, res, p0 = zeros(Cint, 1), zeros(Cint, 1), zeros(1), zeros(n)
+  X, U = zeros(n, N), zeros(m, N)
+  gusto_check(ccall((:gusto_get_shoot, libgusto_hip), Cint,
+                    (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), h, st, it, res, p0, X, U), h, "get_shoot")
+  el = (time_ns() - t0) / 10^9
+  if st[1] == 1                                   # sol_newton.f_converged
+    new_traj = Trajectory(X, U, SP.tf)
+    push!(SS.prob_status, :Optimal); push!(SS.J_true, cost_true(new_traj, new_traj, SP))
+    push!(SS.convergence_measure, convergence_metric(new_traj, SS.traj, SP)); copy!(SS.traj, new_traj)
+  else
+    push!(SS.prob_status, :Diverged); push!(SS.J_true, NaN); push!(SS.convergence_measure, NaN)
+  end
+  push!(SS.iter_elapsed_times, el)
+  nothing
+end
+
 gusto_release!(SCPS::SCPSolution) = (h = pop!(GUSTO_HANDLES, SCPS, C_NULL); h != C_NULL && ccall((:gusto_destroy, libgusto_hip), Cint, (Ptr{Cvoid},), h); nothing)
 
 # Batch entry point (the reference has none): every TOP must share model, N and environment.  `devices` = GPU ordinals:

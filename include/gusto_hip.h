@@ -149,6 +149,23 @@ int gusto_get_hist_cap(gusto_handle h, int* hist_cap);
  * problem (after gusto_set_problems: the initial Delta0 / omega0).  Either pointer may be NULL.  [B] each. */
 int gusto_set_trust_state(gusto_handle h, const double* Delta, const double* omega);
 
+/* Indirect shooting seeded by the SCP dual: solve!(SS::ShootingSolution, SP::ShootingProblem) (src/shooting.jl:4-49)
+ * for every problem of the batch, the refinement step of solve_SCPshooting! (src/traj_opt.jl:4-45).  DubinsCar only
+ * (shooting_ode! / get_control, dubins_car.jl:259-280); other models return GUSTO_ERR_ARG.  The reference's ODE and
+ * nonlinear solvers (DifferentialEquations, NLsolve) are external and absent: the scheme is RK4 with `substeps` steps
+ * per knot interval and Newton with a forward-difference Jacobian on F(p0) = x_goal - x(tf; p0), |F|_inf <= ftol.
+ * p0: [B][n] host seeds, or NULL = SCPS.dual of every problem (what ShootingProblem(TOP, SCPS) takes, types.jl:219-227). */
+typedef struct {
+    int substeps;    /* RK4 steps per knot interval (default 4)             */
+    int max_newton;  /* nlsolve(..., iterations = 100, ...)  shooting.jl:14 */
+    double ftol;     /* nlsolve(..., ftol = 1e-3)            shooting.jl:14 */
+} gusto_shoot_opts;
+int gusto_default_shoot_opts(gusto_shoot_opts* o);
+int gusto_shoot(gusto_handle h, const double* p0, const gusto_shoot_opts* opts);
+/* status [B]: 1 = :Optimal (sol_newton.f_converged), 0 = :Diverged; p0 [B][n] the converged initial costate; X [B][N][n],
+ * U [B][N][m] the recovered trajectory of the :Optimal problems (shooting.jl:26-36).  Any pointer may be NULL. */
+int gusto_get_shoot(gusto_handle h, int* status, int* newton_iters, double* resid, double* p0, double* X, double* U);
+
 /* One convex subproblem per problem (what scp_gusto.jl:82-104 builds and solves in one trip), linearised at
  * (Xp,Up)[b] with the given Delta/omega/obstacle_toggle_distance[b].  Used by the parity tests.
  * Outputs: Xn,Un [B][N][.], obj [B] (JuMP.objective_value), status [B] (GUSTO_SOLVER_*), iters [B]. */

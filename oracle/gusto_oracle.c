@@ -1444,6 +1444,93 @@ int go_get_history(const go_problem* p, double* J_true, int* nJ_true, double* J_
 }
 int go_get_dual(const go_problem* p, double* dual) { memcpy(dual, p->dual, sizeof(double) * p->n); return 0; }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Indirect shooting seeded by the SCP dual (src/shooting.jl:4-66, traj_opt.jl:4-45), DubinsCar:  */
+/*   shooting_ode! / get_control  dubins_car.jl:259-280                                          */
+/* The reference integrates with DifferentialEquations' default adaptive method and solves       */
+/* F(p0) = x_goal - x(tf; p0) = 0 with NLsolve (trust region, finite-difference Jacobian,        */
+/* ftol = 1e-3, 100 iterations); neither library is available, so both sides of the parity test  */
+/* use the SAME stated scheme: classical RK4 with `substeps` steps per knot interval, Newton with */
+/* a forward-difference Jacobian (h_j = 1e-6 max(1,|p_j|)) and halving line search on |F|_inf.    */
+static void dubins_shoot_rhs(const go_problem* p, const double* z, double* dz) {
+    const double v = p->mp.dubins_v, kk = p->mp.dubins_k, u = 0.5 * kk * z[5];
+    dz[0] = v * cos(z[2]); dz[1] = v * sin(z[2]); dz[2] = kk * u;
+    dz[3] = 0; dz[4] = 0; dz[5] = z[3] * v * sin(z[2]) - z[4] * v * cos(z[2]);
+}
+static void dubins_shoot_integrate(const go_problem* p, const double* p0, int substeps, double* xT, double* X, double* U) {
+    const int N = p->N;
+    double z[6], k1[6], k2[6], k3[6], k4[6], w[6];
+    const double h = p->tf / ((N - 1) * (double)substeps);
+    for (int i = 0; i < 3; i++) { z[i] = p->x_init[i]; z[3 + i] = p0[i]; }
+    for (int k = 0; k < N; k++) {
+        if (X) { for (int i = 0; i < 3; i++) X[k * 3 + i] = z[i]; U[k] = 0.5 * p->mp.dubins_k * z[5]; }
+        if (k == N - 1) break;
+        for (int s = 0; s < substeps; s++) {
+            dubins_shoot_rhs(p, z, k1);
+            for (int i = 0; i < 6; i++) w[i] = z[i] + 0.5 * h * k1[i];
+            dubins_shoot_rhs(p, w, k2);
+            for (int i = 0; i < 6; i++) w[i] = z[i] + 0.5 * h * k2[i];
+            dubins_shoot_rhs(p, w, k3);
+            for (int i = 0; i < 6; i++) w[i] = z[i] + h * k3[i];
+            dubins_shoot_rhs(p, w, k4);
+            for (int i = 0; i < 6; i++) z[i] += h / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+        }
+    }
+    for (int i = 0; i < 3; i++) xT[i] = z[i];
+}
+/* returns 1 = :Optimal (|F|_inf <= ftol), 0 = :Diverged.  p0 NULL -> SCPS.dual.  X [N][3], U [N] may be NULL. */
+int go_shoot(go_problem* p, const double* p0, int substeps, int max_newton, double ftol, double* p_out, double* X, double* U,
+             int* newton_iters, double* resid) {
+    if (p->model != GO_DUBINS_CAR) return -1;
+    double pv[3], xg[3], F[3], xT[3], nf = 0;
+    for (int i = 0; i < 3; i++) {
+        pv[i] = p0 ? p0[i] : p->dual[i];
+        const double lo = p->goal_lo[i], hi = p->goal_hi[i];
+        xg[i] = (isfinite(lo) && isfinite(hi)) ? 0.5 * (lo + hi) : 0.0;      /* ShootingProblem ctor, types.jl:219-226 */
+    }
+    int it = 0, ok = 0;
+    dubins_shoot_integrate(p, pv, substeps, xT, NULL, NULL);
+    for (int i = 0; i < 3; i++) { F[i] = xg[i] - xT[i]; nf = fmax(nf, fabs(F[i])); }
+    for (;; it++) {
+        if (!(nf == nf) || !isfinite(nf)) break;
+        if (nf <= ftol) { ok = 1; break; }
+        if (it >= max_newton) break;
+        double J[9], Fj[3], pj[3];
+        for (int j = 0; j < 3; j++) {
+            const double h = 1e-6 * fmax(1.0, fabs(pv[j]));
+            for (int i = 0; i < 3; i++) pj[i] = pv[i];
+            pj[j] += h;
+            dubins_shoot_integrate(p, pj, substeps, xT, NULL, NULL);
+            for (int i = 0; i < 3; i++) { Fj[i] = xg[i] - xT[i]; J[i * 3 + j] = (Fj[i] - F[i]) / h; }
+        }
+        /* dp = -J^-1 F by Cramer's rule */
+        const double det = J[0] * (J[4] * J[8] - J[5] * J[7]) - J[1] * (J[3] * J[8] - J[5] * J[6]) + J[2] * (J[3] * J[7] - J[4] * J[6]);
+        if (!(fabs(det) > 1e-300) || !isfinite(det)) break;
+        double dp[3];
+        dp[0] = -(F[0] * (J[4] * J[8] - J[5] * J[7]) - J[1] * (F[1] * J[8] - J[5] * F[2]) + J[2] * (F[1] * J[7] - J[4] * F[2])) / det;
+        dp[1] = -(J[0] * (F[1] * J[8] - J[5] * F[2]) - F[0] * (J[3] * J[8] - J[5] * J[6]) + J[2] * (J[3] * F[2] - F[1] * J[6])) / det;
+        dp[2] = -(J[0] * (J[4] * F[2] - F[1] * J[7]) - J[1] * (J[3] * F[2] - F[1] * J[6]) + F[0] * (J[3] * J[7] - J[4] * J[6])) / det;
+        double a = 1.0, nn = 0, Fn[3], pn[3];
+        int dec = 0;
+        while (a > 1e-4) {
+            for (int i = 0; i < 3; i++) pn[i] = pv[i] + a * dp[i];
+            dubins_shoot_integrate(p, pn, substeps, xT, NULL, NULL);
+            nn = 0;
+            for (int i = 0; i < 3; i++) { Fn[i] = xg[i] - xT[i]; nn = fmax(nn, fabs(Fn[i])); }
+            if (nn < nf) { dec = 1; break; }
+            a *= 0.5;
+        }
+        if (!dec) break;
+        for (int i = 0; i < 3; i++) { pv[i] = pn[i]; F[i] = Fn[i]; }
+        nf = nn;
+    }
+    if (newton_iters) *newton_iters = it;
+    if (resid) *resid = nf;
+    if (p_out) for (int i = 0; i < 3; i++) p_out[i] = pv[i];
+    if (ok && X) dubins_shoot_integrate(p, pv, substeps, xT, X, U);
+    return ok;
+}
+
 int go_subproblem(go_problem* p, const double* Xp, const double* Up, double Delta, double omega, double toggle,
                   double* Xn, double* Un, double* dual, go_sub_info* info) {
     const int warm_saved = p->warm; /* the hook always starts cold and leaves the SCP run's state alone */

@@ -120,6 +120,12 @@ int go_get_history(const go_problem* p, double* J_true, int* nJ_true, double* J_
                    int* ipm_iters);
 int go_get_dual(const go_problem* p, double* dual);
 
+/* Indirect shooting seeded by the SCP dual (shooting.jl:4-66; DubinsCar only, dubins_car.jl:259-280): RK4 with
+ * `substeps` steps per knot interval, Newton on F(p0) = x_goal - x(tf; p0) with a forward-difference Jacobian.
+ * Returns 1 (:Optimal, |F|_inf <= ftol), 0 (:Diverged), -1 (model without a shooting ODE).  p0 NULL -> SCPS.dual. */
+int go_shoot(go_problem* p, const double* p0, int substeps, int max_newton, double ftol, double* p_out, double* X, double* U,
+             int* newton_iters, double* resid);
+
 /* pieces exposed for tests --------------------------------------------------------------- */
 /* one convex subproblem (scp_gusto.jl:178-314) around (Xp,Up) */
 int go_subproblem(go_problem* p, const double* Xp, const double* Up, double Delta, double omega,

@@ -85,6 +85,8 @@ def lib():
         L.go_hist_len.argtypes = [C.c_void_p]
         L.go_get_history.argtypes = [C.c_void_p] + [C.c_void_p] * 15
         L.go_get_dual.argtypes = [C.c_void_p, _dp]
+        L.go_shoot.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, C.POINTER(C.c_int),
+                               C.POINTER(C.c_double)]
         L.go_subproblem.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp,
                                     C.POINTER(SubInfo)]
         L.go_rows_count.argtypes = [C.c_void_p]
@@ -216,6 +218,15 @@ class Oracle:
         st = self.L.go_subproblem(self.h, _arr(Xp), _arr(Up), Delta, omega, toggle, Xn, Un, dual, C.byref(info))
         return dict(X=Xn, U=Un, dual=dual, status=st, obj=info.obj, iters=info.iters, res_p=info.res_p,
                     res_d=info.res_d, mu=info.mu)
+
+    def shoot(self, p0=None, substeps=4, max_newton=100, ftol=1e-3):
+        """go_shoot: indirect shooting from p0 (default: the dual of the last SCP subproblem)."""
+        pv = None if p0 is None else _arr(p0)
+        p_out, X, U = np.zeros(self.n), np.zeros((self.N, self.n)), np.zeros((self.N, self.m))
+        it, res = C.c_int(), C.c_double()
+        st = self.L.go_shoot(self.h, None if pv is None else pv.ctypes.data, substeps, max_newton, ftol, p_out, X, U,
+                             C.byref(it), C.byref(res))
+        return dict(status=st, p0=p_out, X=X, U=U, newton_iters=it.value, resid=res.value)
 
     def rows(self):
         out = []

@@ -14,7 +14,8 @@ EOS
 for i in 0 1 2 3; do [ $i != $M ] && echo "STUB($i)" >> $D/build/stub.hip; done
 /opt/rocm/bin/hipcc $F -c $D/csrc/gusto_hip.hip -o $D/build/gusto_hip.o &
 /opt/rocm/bin/hipcc $F -c $D/build/stub.hip -o $D/build/stub.o &
+/opt/rocm/bin/hipcc $F -c $D/csrc/shoot.hip -o $D/build/shoot.o &
 /opt/rocm/bin/hipcc $F -c $D/csrc/model_$M.hip -o $D/build/model_$M.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A9 "scp_kernel" | grep -E "VGPRs:|Scratch|Occupancy" 
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $D/build/gusto_hip.o $D/build/stub.o $D/build/model_$M.o -o $D/libgusto_hip.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $D/build/gusto_hip.o $D/build/shoot.o $D/build/stub.o $D/build/model_$M.o -o $D/libgusto_hip.so
 echo built dev lib for model $M
