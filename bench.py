@@ -109,15 +109,20 @@ def main():
     kernel_ms = []
     timed_in_flight = [False] * D
 
-    gathered = [0]
+    gathered, gather_ok, gather_err = [0], [True], [None]
 
     def collect(j):
         solvers[j].wait()
-        if dist is not None:      # final gather of this step's trajectories to rank 0, device tensors -> RCCL
-            Xd, Ud = solvers[j].traj_dev()
-            out = g.host.gather_batch_results(dict(X=Xd, U=Ud), world, rank)
-            if rank == 0:
-                gathered[0] = int(out["X"].shape[0])
+        if dist is not None and gather_ok[0]:   # final gather of this step's trajectories to rank 0, device tensors -> RCCL
+            try:
+                Xd, Ud = solvers[j].traj_dev()
+                out = g.host.gather_batch_results(dict(X=Xd, U=Ud), world, rank)
+                if rank == 0:
+                    gathered[0] = int(out["X"].shape[0])
+            except Exception as e:      # never lose the scaling measurement to the gather: say so in the JSON line instead
+                gather_ok[0] = False
+                gather_err[0] = f"{type(e).__name__}: {e}"[:200]
+                print(f"[bench] rank {rank}: final gather failed, continuing without it: {gather_err[0]}", file=sys.stderr)
         if timed_in_flight[j]:
             kernel_ms.append(solvers[j].last_solve_ms())
             timed_in_flight[j] = False
@@ -238,7 +243,7 @@ def main():
             "mean_scp_iters": tot[2] / (B * world), "mean_ipm_iters": tot[3] / (B * world),
             "pcie_inclusive_traj_per_s": n_conv / pcie_s, "pcie_inclusive_note": "SURVEY.md 8(d): set_problems (host) + "
             "solve + get_traj (host), median of 5, one GPU", "overlapped_traj_per_s": overlapped,
-            "gathered_problems_per_step": gathered[0] if dist is not None else None,
+            "gathered_problems_per_step": gathered[0] if dist is not None else None, "gather_error": gather_err[0],
         }
         if not args.no_cpu_baseline:
             threads = usable_cores()

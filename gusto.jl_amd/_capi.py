@@ -24,7 +24,8 @@ SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims",
            "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_solve_async", "gusto_wait",
            "gusto_last_solve_ms", "gusto_get_traj",
            "gusto_get_traj_dev", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_get_hist_cap",
-           "gusto_set_trust_state", "gusto_subproblem", "gusto_default_shoot_opts", "gusto_shoot", "gusto_get_shoot"]
+           "gusto_set_trust_state", "gusto_subproblem", "gusto_default_shoot_opts", "gusto_shoot", "gusto_get_shoot",
+           "gusto_dev_get_prof"]
 
 
 class ScpParams(C.Structure):

@@ -173,6 +173,10 @@ int gusto_subproblem(gusto_handle h, int B, const double* Xp, const double* Up, 
                      const double* omega, const double* toggle, double* Xn, double* Un, double* obj, int* status,
                      int* iters);
 
+/* Development hook (libraries built with -DGUSTO_PROFILE only, otherwise GUSTO_ERR_STATE): per-problem cycle counters of
+ * the kernel's phases, [B][32] (tools/gpu_prof.py).  Stands in for SCPS.iter_elapsed_times at a finer grain. */
+int gusto_dev_get_prof(gusto_handle h, long long* out);
+
 #ifdef __cplusplus
 }
 #endif
