@@ -12,6 +12,8 @@
 
 namespace gusto {
 
+constexpr int OBS_BATCH = 4, FX_OBS = 64;   // obstacle rows are processed in batches (visit_rows, ObsPre)
+
 template <int CNT> struct RowEv {
     double g;        // scaled row value  ghat = mul * raw - off
     double raw;      // the reference's constraint function value
@@ -102,14 +104,34 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
         quad_row<false, 3, nv, T::NFIX - 2>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
         quad_row<false, iw, nw, T::NFIX - 1>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_omega * mp.hard_limit_omega, kw, 0.0);
         // ncsi_*_obstacle_avoidance_*_convexified (freeflyer_se2.jl:265-288): clearance - (d + nhat.(r - r0))
+        // The rows of one knot are walked in batches of OBS_BATCH: every load of a batch (normal, offset AND the row state
+        // the Op needs, Op::obs_load) is issued before the first row of the batch is processed.  One row at a time, each
+        // row's loads wait behind the stores of the row before it and a pass pays one memory round trip per active
+        // obstacle (3-8 per knot for the freeflyer table, 15-25 in the ISS corner) -- four passes per interior point
+        // iteration.  Lanes with fewer rows left aim the spare positions at their last row and skip them.
         uint64_t mk = c.mask;
         while (mk) {
-            const int i = __ffsll((unsigned long long)mk) - 1;
-            mk &= mk - 1;
-            double b[T::WS];
+            int oi[OBS_BATCH], oslot[OBS_BATCH];
+            bool ov[OBS_BATCH];
+            int last = 0;
 #pragma unroll
-            for (int j = 0; j < T::WS; j++) b[j] = -(c.obs_nh + (size_t)(i * T::WS + j) * (size_t)c.N)[c.k];
-            lin_row<false, 0, T::WS>(op, slot_obs + i, ROW_PEN, xs, b, (c.obs_c0 + (size_t)i * (size_t)c.N)[c.k], kw, 0.0);
+            for (int q = 0; q < OBS_BATCH; q++) {
+                ov[q] = mk != 0;
+                if (ov[q]) { last = __ffsll((unsigned long long)mk) - 1; mk &= mk - 1; }
+                oi[q] = last; oslot[q] = slot_obs + last;
+            }
+            double ob[OBS_BATCH][T::WS], oc[OBS_BATCH];
+#pragma unroll
+            for (int q = 0; q < OBS_BATCH; q++) {
+#pragma unroll
+                for (int j = 0; j < T::WS; j++) ob[q][j] = -(c.obs_nh + (size_t)(oi[q] * T::WS + j) * (size_t)c.N)[c.k];
+                oc[q] = (c.obs_c0 + (size_t)oi[q] * (size_t)c.N)[c.k];
+            }
+            op.obs_load(oslot);
+            static_for<0, OBS_BATCH>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                if (ov[q]) lin_row<false, 0, T::WS, FX_OBS + q>(op, oslot[q], ROW_PEN, xs, ob[q], oc[q], kw, 0.0);
+            });
         }
         if (c.k < c.N - 1) {  // cci_*_accel_bound on k = 1..N-1 only (freeflyer_se2.jl:236-245,380-381)
             constexpr int nf = is2 ? 2 : 3, im = is2 ? 2 : 3, nm = is2 ? 1 : 3;
@@ -174,6 +196,20 @@ template <int NP> struct RowPre {
     }
 };
 
+// Row state of one batch of obstacle rows (visit_rows), fetched by Op::obs_load before the batch is processed.  Template
+// id FX_OBS + q of a row = position q of the current batch.
+struct ObsPre {
+    double v[RS_NVAR][OBS_BATCH];
+    template <class F> GD void load(const RowState& rs, const int* slot, F&& want) {
+#pragma unroll
+        for (int var = 0; var < RS_NVAR; var++)
+            if (want(var)) {
+#pragma unroll
+                for (int q = 0; q < OBS_BATCH; q++) v[var][q] = rs.at(var, slot[q]);
+            }
+    }
+};
+
 // ---- the Ops ---------------------------------------------------------------------------------------
 // Start point.  Cold (muw == 0: the first subproblem of an SCP run, or after a solver failure): slacks just inside (offset 0.01),
 // penalised multipliers lam_a = lam_b = 1/2, hard-row multipliers 0.01/t -- tuned on the freeflyer batch.
@@ -184,6 +220,7 @@ struct OpInit {
     RowState rs;
     double muw;
     int ncomp = 0;
+    GD void obs_load(const int*) {}
     template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
         if (row_is_hard(kind)) {
             const double t = fmax(-ev.g, 1e-2), mu0 = (muw > 0) ? muw : 0.01;
@@ -213,8 +250,18 @@ template <int n, int m, int NP> struct OpResidHess {
     double alpha_prev;  // 0 on the first trip
     const RowPre<NP>* pre;
     double comp = 0, maxrp = 0;
+    ObsPre ob;
+    GD void obs_load(const int* slot) {
+        const bool upd = alpha_prev != 0.0;
+        ob.load(rs, slot, [&](int var) {
+            return var == RS_T || var == RS_LAM || var == RS_S || var == RS_LAMB ||
+                   (upd && (var == RS_DT || var == RS_DL || var == RS_DS));
+        });
+    }
     template <int FX> GD double get(int var, int slot) const {
-        if constexpr (FX >= 0 && NP > 0) return pre->v[var][FX]; else return rs.at(var, slot);
+        if constexpr (FX >= FX_OBS) return ob.v[var][FX - FX_OBS];
+        else if constexpr (FX >= 0 && NP > 0) return pre->v[var][FX];
+        else return rs.at(var, slot);
     }
     template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
         double t = get<FX>(RS_T, slot), lam = get<FX>(RS_LAM, slot);
@@ -263,16 +310,25 @@ struct OpRhs {
     double *gx, *gu;
     int pass;
     double mu_t;
+    ObsPre ob;
+    GD void obs_load(const int* slot) {
+        ob.load(rs, slot, [&](int var) {
+            return var == RS_T || var == RS_LAM || var == RS_S || var == RS_LAMB || (pass && (var == RS_KA || var == RS_KB));
+        });
+    }
+    template <int FX> GD double get(int var, int slot) const {
+        if constexpr (FX >= FX_OBS) return ob.v[var][FX - FX_OBS]; else return rs.at(var, slot);
+    }
     template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
-        const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
-        const double ka = pass ? rs.at(RS_KA, slot) : 0.0;
+        const double t = get<FX>(RS_T, slot), lam = get<FX>(RS_LAM, slot);
+        const double ka = pass ? get<FX>(RS_KA, slot) : 0.0;
         double coef;
         if (row_is_hard(kind)) {
             const double rp = ev.g + t;
             coef = (mu_t - ka + lam * rp) * rcp_nr(t);
         } else {
-            const double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
-            const double kb = pass ? rs.at(RS_KB, slot) : 0.0;
+            const double s = get<FX>(RS_S, slot), lamb = get<FX>(RS_LAMB, slot);
+            const double kb = pass ? get<FX>(RS_KB, slot) : 0.0;
             const double rp = ev.g - s + t;
             const double il = rcp_nr(lamb), lol = lam * il;
             const double D = t + lol * s;
@@ -307,9 +363,18 @@ struct OpStep {
     double mu_t, tau;
     StepFrac amax;
     double c0 = 0, c1 = 0, c2 = 0;
+    ObsPre ob;
+    GD void obs_load(const int* slot) {
+        ob.load(rs, slot, [&](int var) {
+            return var == RS_T || var == RS_LAM || var == RS_S || var == RS_LAMB || (pass && (var == RS_KA || var == RS_KB));
+        });
+    }
+    template <int FX> GD double get(int var, int slot) const {
+        if constexpr (FX >= FX_OBS) return ob.v[var][FX - FX_OBS]; else return rs.at(var, slot);
+    }
     template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
-        const double t = rs.at(RS_T, slot), lam = rs.at(RS_LAM, slot);
-        const double ka = pass ? rs.at(RS_KA, slot) : 0.0;
+        const double t = get<FX>(RS_T, slot), lam = get<FX>(RS_LAM, slot);
+        const double ka = pass ? get<FX>(RS_KA, slot) : 0.0;
         const double* dv = ISU ? dus : dxs;
         double w = 0;
 #pragma unroll
@@ -321,8 +386,8 @@ struct OpStep {
             dl = (mu_t - t * lam - ka - lam * dt) * rcp_nr(t);
             ds = 0.0;
         } else {
-            const double s = rs.at(RS_S, slot), lamb = rs.at(RS_LAMB, slot);
-            const double kb = pass ? rs.at(RS_KB, slot) : 0.0;
+            const double s = get<FX>(RS_S, slot), lamb = get<FX>(RS_LAMB, slot);
+            const double kb = pass ? get<FX>(RS_KB, slot) : 0.0;
             const double rp = ev.g - s + t;
             const double il = rcp_nr(lamb), lol = lam * il;
             const double D = t + lol * s;
@@ -344,6 +409,7 @@ struct OpStep {
 struct OpSlackSum {
     RowState rs;
     double sum = 0;
+    GD void obs_load(const int*) {}
     template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>&) {
         if (!row_is_hard(kind)) sum += rs.at(RS_S, slot);   // (the last residual pass already applied every update)
     }
@@ -353,6 +419,7 @@ struct OpSlackSum {
 struct OpCheck {
     double eps;
     bool ok = true;
+    GD void obs_load(const int*) {}
     template <bool ISU, int I0, int CNT, int FX> GD void row(int, int kind, const RowEv<CNT>& ev) {
         if (ISU) return;
         if (kind == ROW_PEN && ev.raw >= eps) ok = false;
