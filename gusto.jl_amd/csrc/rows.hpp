@@ -12,7 +12,10 @@
 
 namespace gusto {
 
-constexpr int OBS_BATCH = 4, FX_OBS = 64;   // obstacle rows are processed in batches (visit_rows, ObsPre)
+#ifndef GUSTO_OBS_BATCH
+#define GUSTO_OBS_BATCH 4
+#endif
+constexpr int OBS_BATCH = GUSTO_OBS_BATCH, FX_OBS = 64;   // obstacle rows are processed in batches (visit_rows, ObsPre)
 
 template <int CNT> struct RowEv {
     double g;        // scaled row value  ghat = mul * raw - off
