@@ -36,6 +36,7 @@ template <> struct MT<GUSTO_FREEFLYER_SE2> {
     static constexpr int WAVES_PER_EU = GUSTO_WAVES_PER_EU;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool MFMA = false;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
+    static constexpr int SCHED_PROBE = 2;   // default number of one-trip probing slices of the longest-first scheduler
     static constexpr bool LTI = true, HAS_OBS = true;
     // Double integrator (freeflyer_se2.jl:121,178-179: A = [0 I; 0 0], B = [0; diag]): Phi = I + dt A and
     // Gam = 2 (I + dt/2 A) b have at most TWO nonzeros per column of [Phi Gam], at rows pg_r0(c), pg_r1(c)
@@ -56,6 +57,7 @@ template <> struct MT<GUSTO_DUBINS_CAR> {
     static constexpr int WAVES_PER_EU = 2;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool MFMA = false;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
+    static constexpr int SCHED_PROBE = 1;   // (short problems: 2 slices cost more than they order -- 316 vs 211 ms at B = 65 536)
     static constexpr bool LTI = false, HAS_OBS = false;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
@@ -70,6 +72,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3> {
     static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool MFMA = GUSTO_USE_MFMA;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
+    static constexpr int SCHED_PROBE = 2;   // default number of one-trip probing slices of the longest-first scheduler
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
@@ -86,6 +89,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true ;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool MFMA = GUSTO_USE_MFMA;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
+    static constexpr int SCHED_PROBE = 2;   // default number of one-trip probing slices of the longest-first scheduler
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
@@ -219,9 +223,11 @@ struct KParams {
 };
 constexpr int ST_ITER = 0, ST_CONV = 1, ST_SUCC = 2, ST_STOP = 3, ST_IPM = 4, ST_NHIST = 5, ST_NJ = 6, ST_NRHO = 7, ST_WARM = 8,
               ST_CAP = 9 /* iter_cap of the running gusto_solve call */, ST_VISITS = 10 /* time slices so far */, ST_NI = 11;
-// scheduler words in KParams::queue
-constexpr int SCHED_LEVELS = 16, SQ_HEAD_A = 0, SQ_PROBING = 1 /* problems that may still be pushed */, SQ_TAIL = 2 /* [level] */, SQ_HEAD = 2 + SCHED_LEVELS /* [level] */,
-              SQ_WORDS = 2 + 2 * SCHED_LEVELS;
+// scheduler words in KParams::queue.  Every counter sits in its own 128-byte line (SQ_STRIDE ints apart): thousands of
+// workgroups poll and bump them, and two counters in one line serialise each other's atomics in the L2.
+constexpr int SCHED_LEVELS = 16, SQ_STRIDE = 32;
+constexpr int SQ_HEAD_A = 0, SQ_PROBING = SQ_STRIDE /* problems that may still be pushed */, SQ_TAIL = 2 * SQ_STRIDE /* [level] */,
+              SQ_HEAD = (2 + SCHED_LEVELS) * SQ_STRIDE /* [level] */, SQ_WORDS = (2 + 2 * SCHED_LEVELS) * SQ_STRIDE;
 constexpr int SD_TOGGLE = 0, SD_DUAL = 2, SD_ND = 2 + GUSTO_MAXN;
 
 // ---- optional phase timers (compile with -DGUSTO_PROFILE) ---------------------------------------------

@@ -161,7 +161,7 @@ int gusto_set_ipm_opts(gusto_handle h, const gusto_ipm_opts* o) {
 int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch) {
     if (!h || probe_iters < 0 || min_batch < 1) return GUSTO_ERR_ARG;
     { int rc = setter_enter(h); if (rc) return rc; }
-    h->probe_iters = probe_iters; h->probe_min_batch = min_batch;
+    h->probe_iters = probe_iters; h->probe_min_batch = min_batch; h->sched_forced = true;
     return GUSTO_OK;
 }
 

@@ -29,6 +29,7 @@ struct gusto_handle_s {
     double last_ms = 0.0;
     bool pending = false;  // a gusto_solve_async launch has not been waited for yet
     int probe_iters = 2, probe_min_batch = 2048;  // longest-first schedule (gusto_set_schedule)
+    bool sched_forced = false;                    // gusto_set_schedule was called: the caller's choice overrides the model default
     int* d_order = nullptr;   // waiting lists of the scheduler, [SCHED_LEVELS][probe_iters * batch_cap]
     size_t order_ints = 0;
     int* d_queue = nullptr;   // work-queue heads, one per launch of a gusto_solve call

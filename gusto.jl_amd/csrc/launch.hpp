@@ -67,23 +67,24 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
         P.ws = h->d_ws;
     }
     // scheduler state of this launch (scp.hpp): counters to 0, waiting lists to -1
-    const bool dyn = mode == 0 && h->probe_iters > 0 && h->probe_iters < 128 && max_iter > h->probe_iters &&
-                     h->B >= h->probe_min_batch && h->B < (1 << 24);
+    // number of probing slices: the caller's (gusto_set_schedule) or the model's default (2; dubins_car 1)
+    const int probe = h->sched_forced ? h->probe_iters : MT<MODEL>::SCHED_PROBE;
+    const bool dyn = mode == 0 && probe > 0 && probe < 128 && max_iter > probe && h->B >= h->probe_min_batch && h->B < (1 << 24);
     memset(h->sched_init, 0, sizeof(h->sched_init));
     h->sched_init[SQ_PROBING] = dyn ? h->B : 0;     // every problem starts with its probing slices still ahead
     HIPCHK(h, hipMemcpyAsync(h->d_queue, h->sched_init, SQ_WORDS * sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (dyn) {
-        const size_t need = (size_t)SCHED_LEVELS * h->probe_iters * h->batch_cap;
+        const size_t need = (size_t)SCHED_LEVELS * probe * h->batch_cap;
         if (need > h->order_ints) {
             if (h->d_order) hipFree(h->d_order);
             h->d_order = nullptr; h->order_ints = 0;
             HIPCHK(h, dalloc(&h->d_order, need));
             h->order_ints = need;
         }
-        P.list_cap = h->probe_iters * h->B;
+        P.list_cap = probe * h->B;
         HIPCHK(h, hipMemsetAsync(h->d_order, 0xFF, (size_t)SCHED_LEVELS * P.list_cap * sizeof(int), h->stream));
     }
-    P.queue = h->d_queue; P.lists = h->d_order; P.probe_visits = dyn ? h->probe_iters : 0;
+    P.queue = h->d_queue; P.lists = h->d_order; P.probe_visits = dyn ? probe : 0;
     if (getenv("GUSTO_DEV_DEBUG"))
         fprintf(stderr, "launch: B %d slots %d dyn %d probe %d list_cap %d queue %p lists %p..%p ws %p..%p X %p st_i %p..%p hist Delta %p\n", h->B, slots,
                 (int)dyn, P.probe_visits, P.list_cap, (void*)P.queue, (void*)P.lists, (void*)(P.lists + h->order_ints), (void*)P.ws,

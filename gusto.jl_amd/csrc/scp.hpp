@@ -271,9 +271,9 @@ GD int sched_pop(const KParams& P, bool& cont) {
             if (q < P.B) { cont = false; return q; }
         }
         for (int L = SCHED_LEVELS - 1; L >= 0; L--) {
-            int h = uload(Q + SQ_HEAD + L);
-            while (h < uload(Q + SQ_TAIL + L)) {
-                const int found = ucas(Q + SQ_HEAD + L, h, h + 1);
+            int h = uload(Q + SQ_HEAD + L * SQ_STRIDE);
+            while (h < uload(Q + SQ_TAIL + L * SQ_STRIDE)) {
+                const int found = ucas(Q + SQ_HEAD + L * SQ_STRIDE, h, h + 1);
                 if (found == h) {     // index h is ours; its entry follows the tail increment that made it visible
                     int e = -1;
                     for (int w = 0; w < SCHED_SPIN_LIMIT && (e = uload(P.lists + (size_t)L * P.list_cap + h)) < 0; w++)
@@ -289,7 +289,8 @@ GD int sched_pop(const KParams& P, bool& cont) {
         // workgroup retires and frees its slot -- the tail of a batch then overlaps the head of the next one enqueued on
         // another stream.
         if (probing_seen == 0 || spin > SCHED_SPIN_LIMIT) return -1;
-        if (spin < 16) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
+        // idle polling backs off (8 -> 127 x 64 cycles): pollers share the L2 lines the working groups' pushes need
+        if (spin < 4) __builtin_amdgcn_s_sleep(8); else if (spin < 16) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(127);
     }
 }
 
@@ -340,7 +341,7 @@ scp_kernel(const KParams P) {
             if (lvl >= 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // state first ...
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int idx = atomicAdd(P.queue + SQ_TAIL + lvl, 1);
+                const int idx = atomicAdd(P.queue + SQ_TAIL + lvl * SQ_STRIDE, 1);
                 __hip_atomic_store(P.lists + (size_t)lvl * P.list_cap + idx, ((visits + 1) << 24) | b, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);                                                        // ... then the entry
             }
