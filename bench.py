@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--cpu-sample", type=int, default=0, help="0 = 2048 problems per usable host core (about 15-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and overlapped extras (profiling runs: "
+                    "every launch of the kernel is then one serial step, so rocprofv3's average is the step's)")
     ap.add_argument("--overlap", type=int, default=1,
                     help="batches in flight: consecutive steps alternate between this many handles/streams, so the "
                          "slowest problems of one batch overlap the start of the next (1 = strictly serial steps)")
@@ -174,16 +176,16 @@ def main():
     # named extras, outside the timed region, rank 0's GPU only:
     # (a) SURVEY.md 8(d): host buffers in, trajectories out (H2D + solve + D2H), median of 5
     pcie = []
-    for _ in range(5):
+    for _ in range(0 if args.no_extras else 5):
         t1 = time.perf_counter()
         solver.set_problems(x0, glo, ghi, tf)
         solver.solve(MAX_ITER)
         solver.traj()
         pcie.append(time.perf_counter() - t1)
-    pcie_s = float(np.median(pcie))
+    pcie_s = float(np.median(pcie)) if pcie else float("nan")
     # (b) two batches in flight on two handles/streams (the tail of one batch overlaps the head of the next)
     overlapped = None
-    if D == 1 and dist is None:
+    if D == 1 and dist is None and not args.no_extras:
         s2 = [solver, g.BatchSolver(g.FREEFLYER_SE2, N_KNOTS, B, hist_cap=MAX_ITER + 34, device=local_rank, boxes=env)]
         K2 = 12
         for i in range(2):
@@ -231,9 +233,9 @@ def main():
                        "batches_in_flight": D},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         # one gusto_solve = two launches of this persistent kernel (2 probe trips of every problem, then
-                         # the rest longest-first, gusto_set_schedule); avg_launch_ms is their sum per solve, HIP events
-                         "kernel": "gusto::scp_kernel<0>", "launches_per_solve": 2, "avg_launch_ms": avg_ms,
+                         # one gusto_solve = ONE launch of the persistent kernel (device-side longest-first scheduler,
+                         # gusto_set_schedule); avg_launch_ms from HIP events on the handle's stream
+                         "kernel": "gusto::scp_kernel<0>", "launches_per_solve": 1, "avg_launch_ms": avg_ms,
                          "kkt_solves_per_launch": ipm_iters, "scp_iters_per_launch": scp_iters,
                          # with D > 1 launches overlap, so a launch's duration spans the batches it shares the GPU
                          # with; the job-level rate is the algorithmic bytes of all launches over the timed region
@@ -241,7 +243,7 @@ def main():
                          "aggregate_achieved": alg_bytes * args.steps / elapsed / 1e9},
             "converged": int(tot[0]), "successful": int(tot[1]), "problems": B * world,
             "mean_scp_iters": tot[2] / (B * world), "mean_ipm_iters": tot[3] / (B * world),
-            "pcie_inclusive_traj_per_s": n_conv / pcie_s, "pcie_inclusive_note": "SURVEY.md 8(d): set_problems (host) + "
+            "pcie_inclusive_traj_per_s": (n_conv / pcie_s) if pcie else None, "pcie_inclusive_note": "SURVEY.md 8(d): set_problems (host) + "
             "solve + get_traj (host), median of 5, one GPU", "overlapped_traj_per_s": overlapped,
             "gathered_problems_per_step": gathered[0] if dist is not None else None, "gather_error": gather_err[0],
         }

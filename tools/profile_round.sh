@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 300 python bench.py --overlap 2 --steps 60 --no-cpu-baseline > $OUT/bench_overlap2.json 2>> $OUT/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python bench.py --steps 20 --no-cpu-baseline > $OUT/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python bench.py --steps 20 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
 timeout 600 python tools/bench_configs.py > $OUT/configs.jsonl 2>> $OUT/bench.err
 for m in 2 3; do   # kernel stats of BASELINE configs 4 and 5 (astrobeeSE3 B=8192, manifold B=2048)
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_m$m -o stats -- python tools/bench_configs.py $m > $OUT/stats_m$m.log 2>&1
