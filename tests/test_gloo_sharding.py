@@ -110,3 +110,37 @@ def test_two_rank_real_solve_and_gather():
     np.testing.assert_array_equal(out["U"], U)
     np.testing.assert_array_equal(out["iterations"], st["iterations"])
     np.testing.assert_array_equal(out["converged"].astype(bool), st["converged"])
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["GUSTO_FORCE_GATHER"] = "1"        # a one-rank group still runs all_gather + gather
+    import torch
+    import torch.distributed as dist
+    import gusto_jl_amd as g
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    P = g.problems
+    x0, glo, ghi, tf = P.freeflyer_batch(24)
+    s = g.BatchSolver(g.FREEFLYER_SE2, 50, 24, hist_cap=136, boxes=P.freeflyer_env())
+    s.set_problems(x0, glo, ghi, tf)
+    s.solve(30)
+    Xd, Ud = s.traj_dev()
+    out = g.host.gather_batch_results(dict(X=Xd, U=Ud, it=s.status()["iterations"].astype(np.int64)), 1, 0)
+    X, U = s.traj()
+    q.put((bool(out["X"].is_cuda), np.array_equal(out["X"].cpu().numpy(), X), np.array_equal(out["U"].cpu().numpy(), U),
+           np.array_equal(out["it"], s.status()["iterations"])))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_gathers_the_handles_own_device_buffers():
+    """The nccl (= RCCL) backend sends straight from the handle's HBM buffers (zero-copy torch views of hipMalloc'd
+    memory): all_gather of the shard sizes + gather of X, U in a one-rank group on the test box's single GPU."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    on_gpu, okx, oku, okit = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and on_gpu and okx and oku and okit
