@@ -1252,7 +1252,9 @@ template <int MODEL, class BLK> GD void inv_spd_block(BLK& K, double* fail) {
 // The phase between the two vector sweeps of a right-hand side: feed-forward d0 = S^-1 lu, the goal multiplier
 // mu_g = Gd^-1 theta, then d_k = d0 + D_k mu_g and ct_k = c_k - Gam_k d_k.  A function of its own so that the models
 // with MT::SWEEP_CALL can run it as a real call (own register allocation; everything it touches lives in LDS / HBM).
-template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, double hdt, double* red, double* mugn) {
+template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, double hdt, double* red, double* mugn, Prof* pf = nullptr) {
+#define MT_(i) do { if (pf) pf->tick(i); } while (0)
+    MT_(PF_MID);
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m;
@@ -1307,8 +1309,10 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
             th[j] = s;
         }
     }
+    MT_(PF_M_TH);
 #pragma unroll
     for (int j = 0; j < n; j++) th[j] = (K.goalmask != 0) ? block_reduce(th[j], OpSum(), red) : 0.0;
+    MT_(PF_M_RED);
     if (k == 0) {
 #pragma unroll
         for (int j = 0; j < n; j++) {
@@ -1319,6 +1323,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         }
     }
     K.sync();
+    MT_(PF_M_MU);
     if (act) {  // d_k = d0 + D_k mu_g ; ct_k = c_k - Gam_k d_k
         double dk[m];
 #pragma unroll
@@ -1349,7 +1354,10 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
             K.dY[k * n + i] = s;
         }
     }
+    MT_(PF_M_DK);
     K.sync();
+    MT_(PF_M_SYNC);
+#undef MT_
 }
 template <int MODEL, class BLK> __device__ __noinline__ void mid_phase_call(BLK K, int k, bool act, double hdt, double* red,
                                                                             double* mugn) {
@@ -1841,7 +1849,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             pf.tick(PF_BACK);
             GUSTO_REFRESH_K();
             if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL>(K, k, act, hdt, red, mugn);
-            else mid_phase<MODEL>(K, k, act, hdt, red, mugn);
+            else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf);
             pf.tick(PF_MID);
             forward_sweep<MODEL>(K);
             pf.tick(PF_FWD);

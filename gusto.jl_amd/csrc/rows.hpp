@@ -405,7 +405,9 @@ struct OpStep {
         amax.test(t, dt, tau);
         amax.test(lam, dl, tau);
         if (pass == 0) { c0 += t * lam; c1 += dt * lam + t * dl; c2 += dt * dl; rs.at(RS_KA, slot) = dt * dl; }
-        rs.at(RS_DT, slot) = dt; rs.at(RS_DL, slot) = dl; rs.at(RS_DS, slot) = ds;
+        // (the predictor's steps only feed alpha_aff and the second-order terms: the corrector overwrites them, and a
+        //  problem without a corrector pass -- ncomp == 0 -- has no rows)
+        if (pass) { rs.at(RS_DT, slot) = dt; rs.at(RS_DL, slot) = dl; rs.at(RS_DS, slot) = ds; }
     }
 };
 

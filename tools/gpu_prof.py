@@ -21,7 +21,7 @@ print(f"B={B} kernel {s.last_solve_ms():.1f} ms conv {st['converged'].sum()} tra
 prof = np.zeros((B, 32), dtype=np.int64)
 s.L.gusto_dev_get_prof.argtypes = [C.c_void_p, C.c_void_p]
 rc = s.L.gusto_dev_get_prof(s.h, prof.ctypes.data)
-names = ["RESID","BUILD","FACTOR","POSTF","RHS","BACK","MID","FWD","STEP","UPDATE","LIN","SCP","INIT","F:pre","F:AB","F:CD","F1:H","F2:Z","F3:r","F4:chol","F5:ld","F6:solve","F7:store","F8"] + ["-"] * 8
+names = ["RESID","BUILD","FACTOR","POSTF","RHS","BACK","MID","FWD","STEP","UPDATE","LIN","SCP","INIT","F:pre","F:AB","F:CD","F1:H","F2:Z","F3:r","F4:chol","F5:ld","F6:solve","F7:store","F8","M:th","M:reduce","M:mu+sync","M:dk/ct","M:sync2","-","-","-"]
 tot = prof.sum(axis=0).astype(float)
 ipm = st["ipm_iters"].sum()
 print("phase: share, cycles per IPM iteration")
