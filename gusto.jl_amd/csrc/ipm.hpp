@@ -48,6 +48,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     using R = Rec<MODEL>;
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr bool ONE = ONEWAVE;
+    static constexpr int MODEL_ID = MODEL;
     const KParams& P;
     int b, tid, N;
     int NTr;  // runtime block size (multi-wave problems)
@@ -126,6 +127,27 @@ template <int MODEL, bool ONEWAVE> struct Blk {
 template <class BLK> GD void load_M_Gam(const BLK& K, int k, double* M, double* Gam) {
     using T = typename BLK::T;
     constexpr int n = BLK::n, m = BLK::m, NZ = n + m;
+    if constexpr (T::PG2) {
+        // double integrator (A = [0 I; 0 0], B = [0; diag(beta)]): M = I + dt/2 A and Gam = 2 M (dt/2 B) are known in closed
+        // form -- formed from dt and the model constants (SGPRs) with exactly the operations linearize() performs on
+        // them, so the values are bit-identical to the stored block and ~18 wave-uniform global loads per call
+        // (eight calls per interior point iteration) disappear
+        constexpr int h3 = n / 2;
+        const double h = 0.5 * K.dt;
+        double Bd[n * m];
+        Dyn<BLK::MODEL_ID>::B(K.P.mp, Bd);
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+#pragma unroll
+            for (int j = 0; j < n; j++) M[i * n + j] = (i == j) ? 1.0 : ((j == i + h3) ? h : 0.0);
+#pragma unroll
+            for (int j = 0; j < m; j++) {
+                const double hb = h * Bd[(j + h3) * m + j];
+                Gam[i * m + j] = (i == j) ? 2.0 * (h * hb) : ((i == j + h3) ? 2.0 * hb : 0.0);
+            }
+        }
+        return;
+    }
     const double* pg = K.PGk(k);
 #pragma unroll
     for (int i = 0; i < n; i++) {
@@ -1268,11 +1290,16 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
     if (act) {
         double tt[n], lu[m], Gamk[n * m];
         if (k >= 1) {
-            const double* pg = K.PGk(k);
+            if constexpr (T::PG2) {
+                double Mk_[n * n];
+                load_M_Gam(K, k, Mk_, Gamk);
+            } else {
+                const double* pg = K.PGk(k);
 #pragma unroll
-            for (int i = 0; i < n; i++)
+                for (int i = 0; i < n; i++)
 #pragma unroll
-                for (int j = 0; j < m; j++) Gamk[i * m + j] = T::Gnz(i, j) ? pg[i * NZ + n + j] : 0.0;
+                    for (int j = 0; j < m; j++) Gamk[i * m + j] = T::Gnz(i, j) ? pg[i * NZ + n + j] : 0.0;
+            }
         } else {
             Dyn<MODEL>::B(K.P.mp, Gamk);
 #pragma unroll
@@ -1295,11 +1322,30 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
             d0[i] = s;
         }
         // theta_j = sum_k Pi_k^T c_k - D_k^T lu_k  (+ C M rd_{N-1} - rg at the last knot)
+        // LTI models: the last knot's goal term is evaluated by EVERY lane on its own knot's data and selected afterwards --
+        // as a branch it is single-lane work (loads and all) that the whole wave waits for, twice per iteration
+        double gterm[n], gsub[n];
+        if constexpr (T::LTI) {
+            double rdl[n];
+            const double* pg = K.PGk(0);
+#pragma unroll
+            for (int i = 0; i < n; i++) rdl[i] = K.rd[k * n + i];
+#pragma unroll
+            for (int j = 0; j < n; j++) {
+                double g = 0.0;
+#pragma unroll
+                for (int i = 0; i < n; i++) if (T::Mnz(j, i)) g += 0.5 * (pg[j * NZ + i] + (i == j ? 1.0 : 0.0)) * rdl[i];
+                gterm[j] = g; gsub[j] = K.goal_lo[j] - K.Xw[k * n + j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < n; j++) {
             double s = K.nun[k * n + j];   // Pi_k^T c_k from the factor sweep (nun is free until the corrector's costates)
 #pragma unroll
             for (int i = 0; i < m; i++) s -= K.KD[(size_t)k * R::SKD + R::oD + i * n + j] * lu[i];
+            if constexpr (T::LTI) {
+                s = (k == N - 1 && K.is_goal(j)) ? (s + gterm[j]) - gsub[j] : s;
+            } else
             if (k == N - 1 && K.is_goal(j)) {
                 const double* pg = K.PGk(k);
 #pragma unroll
@@ -1336,11 +1382,16 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         }
         double Gamk[n * m];
         if (k >= 1) {
-            const double* pg = K.PGk(k);
+            if constexpr (T::PG2) {
+                double Mk_[n * n];
+                load_M_Gam(K, k, Mk_, Gamk);
+            } else {
+                const double* pg = K.PGk(k);
 #pragma unroll
-            for (int i = 0; i < n; i++)
+                for (int i = 0; i < n; i++)
 #pragma unroll
-                for (int j = 0; j < m; j++) Gamk[i * m + j] = T::Gnz(i, j) ? pg[i * NZ + n + j] : 0.0;
+                    for (int j = 0; j < m; j++) Gamk[i * m + j] = T::Gnz(i, j) ? pg[i * NZ + n + j] : 0.0;
+            }
         } else {
             Dyn<MODEL>::B(K.P.mp, Gamk);
 #pragma unroll
@@ -1576,11 +1627,17 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
 
         // (3) QQ = [Qt, Qt b; ., Hu + b^T Qt b], Qt = M^T Hx M (built even on the last trip: cheap)
         double* qqg = K.QQ + (size_t)k * R::SQQ;
-        if (k >= 1) {
+        {   // knot 0 (x_1 is pinned: Qt = 0, only H_u survives) runs the SAME code with M := 0 -- as an else-branch it was
+            // NQ + n stores issued for one lane while the other 49 waited
             double Mk[n * n], Qt[NHX], Qb[n * m];
             {
                 double Gamk[n * m];
                 load_M_Gam(K, k, Mk, Gamk);
+                const double mz = (k >= 1) ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < n; i++)
+#pragma unroll
+                    for (int j = 0; j < n; j++) if (T::Mnz(i, j)) Mk[i * n + j] *= mz;
             }
 #pragma unroll
             for (int j = 0; j < n; j++) {  // column j of Hx M, then column j of the upper triangle of M^T (Hx M)
@@ -1622,21 +1679,12 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
                 }
 #pragma unroll
             for (int i = 0; i < n; i++) {
-                double s = 0, c = -rdk[i];
+                double s = 0, c = 0.0 - rdk[i];
 #pragma unroll
                 for (int l = 0; l < n; l++) { s += Qt[sidx(i, l, n)] * rdk[l]; if (T::Mnz(i, l)) c += 2.0 * Mk[i * n + l] * rdk[l]; }
                 K.qrd[k * n + i] = s;
                 K.cv[k * n + i] = c;
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < NQ; e++) qqg[e] = 0.0;
-#pragma unroll
-            for (int i = 0; i < m; i++)
-#pragma unroll
-                for (int j = i; j < m; j++) qqg[sidx(n + i, n + j, NZ)] = Hu[sidx(i, j, m)];
-#pragma unroll
-            for (int i = 0; i < n; i++) { K.qrd[i] = 0; K.cv[i] = 0; }
         }
     }
     return ResidOut{l_resp, l_resd, l_comp, l_numax};

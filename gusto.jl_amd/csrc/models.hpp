@@ -192,16 +192,27 @@ template <int WS> GD double sdf_box(const double* q, const double* lo, const dou
     return -best;
 }
 
+// The keep-out set is read-only for the whole launch and indexed by a wave-uniform obstacle number: reading it through
+// the CONSTANT address space makes these scalar loads (s_load_dwordx4 into SGPRs, served by the scalar cache).  As plain
+// global pointers hipcc cannot prove that none of the kernel's stores aliases them and emits one global_load +
+// s_waitcnt vmcnt(0) per obstacle for all 64 lanes -- 14 (freeflyer) to 32 (ISS corner) serial memory round trips per
+// distance loop, and rho alone walks that loop four times per trip.
+typedef const __attribute__((address_space(4))) double cdouble;
+GD const cdouble* as_constant(const double* p) { return (const cdouble*)(uintptr_t)p; }
+
 template <int WS>
 GD double signed_distance(const KParams& P, int comp, const double* r, int i, double* nh) {
     double q[WS];
 #pragma unroll
     for (int j = 0; j < WS; j++) q[j] = r[j] + P.mp.comp_off[comp][j];
     if (i < P.n_box) {
-        const double* bx = P.box + 6 * i;
-        return sdf_box<WS>(q, bx, bx + 3, nh) - P.mp.radius;
+        const cdouble* bx = as_constant(P.box) + 6 * i;
+        double lo[WS], hi[WS];
+#pragma unroll
+        for (int j = 0; j < WS; j++) { lo[j] = bx[j]; hi[j] = bx[3 + j]; }
+        return sdf_box<WS>(q, lo, hi, nh) - P.mp.radius;
     }
-    const double* sp = P.sph + 4 * (i - P.n_box);
+    const cdouble* sp = as_constant(P.sph) + 4 * (i - P.n_box);
     double v[WS], s2 = 0;
 #pragma unroll
     for (int j = 0; j < WS; j++) { v[j] = q[j] - sp[j]; s2 += v[j] * v[j]; }
