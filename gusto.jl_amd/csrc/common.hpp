@@ -51,6 +51,7 @@ template <> struct MT<GUSTO_FREEFLYER_SE2> {
     static constexpr bool Mnz(int i, int j) { return i == j || j == i + 3; }
     static constexpr bool Bnz(int i, int j) { return i == j + 3; }
     static constexpr bool Gnz(int i, int j) { return i == j || i == j + 3; }
+    static constexpr bool Hnz(int, int) { return true; }   // (the trust region row couples every pair of states)
 };
 template <> struct MT<GUSTO_DUBINS_CAR> {
     static constexpr int n = 3, m = 1, WS = 2, NFIX = 6, NHU = 2;
@@ -66,6 +67,7 @@ template <> struct MT<GUSTO_DUBINS_CAR> {
     static constexpr bool Mnz(int, int) { return true; }
     static constexpr bool Bnz(int, int) { return true; }
     static constexpr bool Gnz(int, int) { return true; }
+    static constexpr bool Hnz(int, int) { return true; }
 };
 template <> struct MT<GUSTO_ASTROBEE_SE3> {
     static constexpr int n = 12, m = 6, WS = 3, NFIX = 3, NHU = 2;
@@ -83,6 +85,10 @@ template <> struct MT<GUSTO_ASTROBEE_SE3> {
     static constexpr bool Mnz(int i, int j) { return i < 3 ? (j == i || j == i + 3) : (i < 6 ? j == i : (i < 9 ? j >= 6 : j >= 9)); }
     static constexpr bool Bnz(int i, int j) { return j < 3 ? i == j + 3 : i == j + 6; }
     static constexpr bool Gnz(int i, int j) { return j < 3 ? (i == j || i == j + 3) : i >= 6; }
+    // Hessian of the rows in x: every row but the trust region touches ONE of the blocks r, v, p, w (obstacles r, speed v,
+    // rate w, goal rows single coordinates), so it is block diagonal; the trust region row is a diagonal plus ONE dyad
+    // over all states, which resid_phase carries separately (rank one) instead of filling the 78 entries with it
+    static constexpr bool Hnz(int i, int j) { return i / 3 == j / 3; }
 };
 template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr int n = 13, m = 6, WS = 3, NFIX = 5, NHU = 2;
@@ -100,6 +106,9 @@ template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr bool Mnz(int, int) { return true; }
     static constexpr bool Bnz(int, int) { return true; }
     static constexpr bool Gnz(int, int) { return true; }
+    // (no trust region row on the manifold: the Hessian of the rows is block diagonal in r, v, q (4 rows), w)
+    static constexpr int hblk(int i) { return i < 3 ? 0 : (i < 6 ? 1 : (i < 10 ? 2 : 3)); }
+    static constexpr bool Hnz(int i, int j) { return hblk(i) == hblk(j); }
 };
 
 // symmetric packed index (upper triangle, row-major)

@@ -1060,11 +1060,14 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 // lanes of rows 0..m-1 hold K[i][j], rows m..2m-1 hold D[i-m][j]  (n >= 2m for every model): entry
                 // i*n + j of the K|D|S^-1 record
                 static_assert(n >= 2 * m, "K/D store mapping");
-                double kd = kj[0];
+                // register r of a lane holds entry e = tid + 64 r, i.e. row i = e / n in [64 r / n, (64 r + 63) / n]: rows
+                // outside that range are pruned at compile time (and with them the back-substitutions that feed them)
+                const int ilo = (64 * r) / n, ihi = ((64 * r + 63 < NN - 1) ? 64 * r + 63 : NN - 1) / n;
+                double kd = 0.0;
 #pragma unroll
-                for (int a = 1; a < m; a++) kd = (i == a) ? kj[a] : kd;
+                for (int a = 0; a < m; a++) if (a >= ilo && a <= ihi) kd = (i == a) ? kj[a] : kd;
 #pragma unroll
-                for (int a = 0; a < m; a++) kd = (i == m + a) ? dj[a] : kd;
+                for (int a = 0; a < m; a++) if (m + a >= ilo && m + a <= ihi) kd = (i == m + a) ? dj[a] : kd;
                 kdv[r] = kd;
             }
             {   // S^-1 = L^-T L^-1 (feed-forward only): computed wave-uniformly, the lane of record entry oS + e keeps entry e
@@ -1079,7 +1082,8 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
 #pragma unroll
                         for (int l = a; l < m; l++) s += Li[l * m + a] * Li[l * m + c];
 #pragma unroll
-                        for (int r = 0; r < RKD; r++) {
+                        for (int r = 0; r < RKD; r++) {   // (registers whose 64 entries miss [oS, oS + m^2): nothing to do)
+                            if (64 * r + 63 < R::oS || 64 * r >= R::oS + m * m) continue;
                             const int e = tid + 64 * r - R::oS;
                             sv[r] = (e == a * m + c || e == c * m + a) ? s : sv[r];
                         }
@@ -1089,7 +1093,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 for (int r = 0; r < RKD; r++) {
                     const int e = tid + 64 * r;
                     double v = (r < RN) ? kdv[r < RN ? r : 0] : 0.0;
-                    if (e >= R::oS) v = sv[r];
+                    if (64 * r + 63 >= R::oS && 64 * r < R::oS + m * m) { if (e >= R::oS) v = sv[r]; }
                     K.KD[(size_t)k * R::SKD + e] = v;
                 }
             }
@@ -1574,7 +1578,8 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
                        (upd && (var == RS_DT || var == RS_DL || var == RS_DS));
             });
         }
-        OpResidHess<n, m, NP> op{rs, Hx, Hu, rdx, rdu, gx0, gu0, alpha_prev, &pre};
+        constexpr bool LRTR = MODEL == GUSTO_ASTROBEE_SE3;   // (the manifold model has no trust region row)
+        OpResidHess<n, m, NP, LRTR> op{rs, Hx, Hu, rdx, rdu, gx0, gu0, alpha_prev, &pre};
         visit_rows<MODEL>(ctx, xs, us, op);
         // row part of the predictor right-hand side, parked in the (currently free) step arrays
 #pragma unroll
@@ -1639,21 +1644,38 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
 #pragma unroll
                     for (int j = 0; j < n; j++) if (T::Mnz(i, j)) Mk[i * n + j] *= mz;
             }
+            // H_x = (block diagonal part, T::Hnz) + diag(trh) + trs * trg trg^T (LRTR): the dyad goes through M as a
+            // vector, M^T (trs g g^T) M = trs (M^T g)(M^T g)^T, and the products below skip the structural zeros of H_x
+            double gt[LRTR ? n : 1];
+            if constexpr (LRTR) {
+#pragma unroll
+                for (int i = 0; i < n; i++) {
+                    Hx[sidx(i, i, n)] += op.trh[i];
+                    double s = 0;
+#pragma unroll
+                    for (int l = 0; l < n; l++) if (T::Mnz(l, i)) s += Mk[l * n + i] * op.trg[l];
+                    gt[i] = s;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < n; j++) {  // column j of Hx M, then column j of the upper triangle of M^T (Hx M)
                 double tcol[n];
+                bool tnz[n];   // (compile-time after unrolling: entry i of the column is structurally nonzero)
 #pragma unroll
                 for (int i = 0; i < n; i++) {
                     double s = 0;
+                    tnz[i] = false;
 #pragma unroll
-                    for (int l = 0; l < n; l++) if (T::Mnz(l, j)) s += Hx[sidx(i, l, n)] * Mk[l * n + j];
+                    for (int l = 0; l < n; l++)
+                        if (T::Mnz(l, j) && T::Hnz(i, l)) { s += Hx[sidx(i, l, n)] * Mk[l * n + j]; tnz[i] = true; }
                     tcol[i] = s;
                 }
 #pragma unroll
                 for (int i = 0; i <= j; i++) {
                     double s = 0;
 #pragma unroll
-                    for (int l = 0; l < n; l++) if (T::Mnz(l, i)) s += Mk[l * n + i] * tcol[l];
+                    for (int l = 0; l < n; l++) if (T::Mnz(l, i) && tnz[l]) s += Mk[l * n + i] * tcol[l];
+                    if constexpr (LRTR) s += op.trs * gt[i] * gt[j];
                     Qt[sidx(i, j, n)] = s;
                     qqg[sidx(i, j, NZ)] = s;
                 }

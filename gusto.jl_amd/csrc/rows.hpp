@@ -247,13 +247,16 @@ struct OpInit {
 // The row update of the previous interior point step (t += alpha dt, ...) is folded into this pass, and so is the
 // row part of the PREDICTOR right-hand side (OpRhs with mu_t = ka = kb = 0 reduces to coef = lam + sigma * g), which
 // saves the predictor its own pass over the rows.
-template <int n, int m, int NP> struct OpResidHess {
+// LRTR: a row over ALL states (the trust region) is not added to H_x; its dyad sigma * grad grad^T and diagonal come back
+// as (trs, trg, trh) and resid_phase applies them to the stage cost in factored form.
+template <int n, int m, int NP, bool LRTR = false> struct OpResidHess {
     RowState rs;
     double *Hx, *Hu, *rdx, *rdu, *gx0, *gu0;
     double alpha_prev;  // 0 on the first trip
     const RowPre<NP>* pre;
     double comp = 0, maxrp = 0;
     ObsPre ob;
+    double trs = 0, trg[LRTR ? n : 1], trh[LRTR ? n : 1];
     GD void obs_load(const int* slot) {
         const bool upd = alpha_prev != 0.0;
         ob.load(rs, slot, [&](int var) {
@@ -296,6 +299,17 @@ template <int n, int m, int NP> struct OpResidHess {
         double* g0 = ISU ? gu0 : gx0;
         const double coef0 = lam + sig * ev.g;
         constexpr int dim = ISU ? m : n;
+        if constexpr (LRTR && !ISU && CNT == n) {
+            trs = sig;
+#pragma unroll
+            for (int a = 0; a < CNT; a++) {
+                r[I0 + a] += lam * ev.gr[a];
+                g0[I0 + a] += coef0 * ev.gr[a];
+                trg[a] = ev.gr[a];
+                trh[a] = lam * ev.hd[a];
+            }
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < CNT; a++) {
             r[I0 + a] += lam * ev.gr[a];
