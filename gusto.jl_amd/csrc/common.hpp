@@ -100,12 +100,18 @@ template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
     static constexpr int pg_r1(int) { return 0; }
-    // (x = (r, v, q, w) has the block pattern of astrobeeSE3 with a 4-row quaternion block, but exploiting it made
-    // this kernel 25 % slower -- SGPR spills doubled -- so the products stay dense here)
+#ifdef GUSTO_MANIFOLD_DENSE
     static constexpr bool Anz(int, int) { return true; }
     static constexpr bool Mnz(int, int) { return true; }
     static constexpr bool Bnz(int, int) { return true; }
     static constexpr bool Gnz(int, int) { return true; }
+#else
+    // x = (r, v, q, w): the block pattern of astrobeeSE3 with a 4-row quaternion block
+    static constexpr bool Anz(int i, int j) { return i < 3 ? j == i + 3 : (i < 6 ? false : (i < 10 ? j >= 6 : j >= 10)); }
+    static constexpr bool Mnz(int i, int j) { return i < 3 ? (j == i || j == i + 3) : (i < 6 ? j == i : (i < 10 ? j >= 6 : j >= 10)); }
+    static constexpr bool Bnz(int i, int j) { return j < 3 ? i == j + 3 : i == j + 7; }
+    static constexpr bool Gnz(int i, int j) { return j < 3 ? (i == j || i == j + 3) : i >= 6; }
+#endif
     // (no trust region row on the manifold: the Hessian of the rows is block diagonal in r, v, q (4 rows), w)
     static constexpr int hblk(int i) { return i < 3 ? 0 : (i < 6 ? 1 : (i < 10 ? 2 : 3)); }
     static constexpr bool Hnz(int i, int j) { return hblk(i) == hblk(j); }
@@ -249,10 +255,14 @@ struct Prof {
     long long t0, acc[PROF_N];
     GD Prof() { for (int i = 0; i < PROF_N; i++) acc[i] = 0; t0 = clock64(); }
     GD void tick(int id) { const long long t = clock64(); acc[id] += t - t0; t0 = t; }
-    GD void flush(long long* out, int b) { if (out && threadIdx.x == 0) for (int i = 0; i < PROF_N; i++) out[(size_t)b * PROF_N + i] = acc[i]; }
+    // (a problem runs in several time slices under the scheduler: the first one overwrites, the others accumulate)
+    GD void flush(long long* out, int b, bool cont = false) {
+        if (out && threadIdx.x == 0)
+            for (int i = 0; i < PROF_N; i++) out[(size_t)b * PROF_N + i] = (cont ? out[(size_t)b * PROF_N + i] : 0) + acc[i];
+    }
 #else
     GD void tick(int) {}
-    GD void flush(long long*, int) {}
+    GD void flush(long long*, int, bool = false) {}
 #endif
 };
 

@@ -124,7 +124,7 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
         IpmOut io;
         ipm_solve<MODEL>(K, Delta, omega, (warm && !hook) ? P.io.mu_warm : 0.0, io, pf);  // :96-104
         if (hook) {
-            pf.flush(P.prof, b);
+            pf.flush(P.prof, b, cont);
             store_traj(K, K.Xw, K.Uw, P.sub_X + (size_t)b * N * n, P.sub_U + (size_t)b * N * m);
             if (tid == 0) {
                 P.sub_obj[b] = io.obj; P.sub_status[b] = io.status; P.sub_iters[b] = io.iters;
@@ -220,7 +220,7 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
     // a history vector is full although iterations remain: say so instead of posing as MaxIter
     if (stop == GUSTO_STOP_MAXITER && !again && iterations < call_cap) stop = GUSTO_STOP_HIST_FULL;
     pf.tick(PF_SCP);
-    pf.flush(P.prof, b);
+    pf.flush(P.prof, b, cont);
     if (tid == 0) {
         sti[ST_ITER] = iterations; sti[ST_CONV] = converged; sti[ST_SUCC] = successful; sti[ST_STOP] = stop;
         sti[ST_IPM] = total_ipm; sti[ST_NHIST] = n_hist; sti[ST_NJ] = nJ; sti[ST_NRHO] = n_rho; sti[ST_WARM] = warm;
