@@ -130,7 +130,8 @@ template <int MODEL> struct Rec {
     using T = MT<MODEL>;
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr int r64(int c) { return (c + 63) / 64 * 64; }
-    static constexpr int SQQ = r64(NZ * (NZ + 1) / 2), SNN = r64(n * n), SKD = r64(2 * m * n + m * m);
+    // (+1: every record keeps at least one padding slot, the target of the lanes that hold no entry of a tile store)
+    static constexpr int SQQ = r64(NZ * (NZ + 1) / 2), SNN = r64(n * n + 1), SKD = r64(2 * m * n + m * m + 1);
     static constexpr int oK = 0, oD = m * n, oS = 2 * m * n;
 };
 

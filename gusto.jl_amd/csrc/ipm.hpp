@@ -1108,6 +1108,208 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
     }
 }
 
+// The factor sweep of the 12/13-state models entirely on the matrix cores (MT::MFMA).  Every matrix of a stage is a
+// 16 x 16 tile in the accumulator layout of v_mfma_f64_16x16x4_f64 -- entry (row, col) in register row >> 2 of lane
+// (row & 3) << 4 | col -- and that layout IS an operand layout: register s of a tile X, used as the A operand of K step
+// s, is X^T; used as the B operand it is X.  So   mfma(X.reg[s], Y.reg[s]) summed over s  =  X^T Y   and the whole stage
+//   T = P [Phi Gam],  H = QQ + [Phi Gam]^T T,  Z = [Phi Gam]^T Pi (+E),  W = L^-1 H_uy,  V = L^-1 Z_u,
+//   P' = H_yy - W^T W,  Pi' = Z_y - W^T V,  Gd += V^T V,  K = L^-T W,  D = L^-T V,  S^-1 = L^-T L^-1,  Phicl = Phi - Gam K
+// chains accumulators into operands without a trip through LDS: P, Pi and Gd stay in registers over the 50 stages.
+// The only operands gathered from LDS are Phi, Gam (two layouts) and L^-1 (factored wave-uniformly from the H_uu tile
+// by v_readlane, as before).  Column 15 of the Phi tile carries c_k, so r_k = P_k c_k is column 15 of P Phi and
+// Pi_k^T c_k is row 15 of Phi^T Pi: the two matrix-vector products of the stage come with the tiles.  Rows / columns
+// beyond n (m) of a tile are finite don't-cares that never meet a nonzero operand; stores aim them at the padding slot
+// of their record.
+template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail, Prof& pf) {
+    using T = MT<MODEL>;
+    using R = Rec<MODEL>;
+    constexpr int n = T::n, m = T::m, NZ = n + m, NPG = n * NZ, NN = n * n;
+    constexpr int KS = (n + 3) / 4, MS = (m + 3) / 4, RT = (NPG + 63) / 64, RN = (NN + 63) / 64;
+    static_assert(!T::LTI && n <= 15 && m <= 8 && R::SNN > NN && R::SKD > 2 * m * n + m * m, "tile / record shape");
+    const int tid = K.tid, N = K.N;
+    const int mi = tid & 15, mq = tid >> 4;
+    const bool c15 = mi == 15;
+    // per-lane offsets, fixed for the sweep
+    int oF[KS], oG[KS], oGA[MS], oN[KS], oKr[MS], oDr[MS], oSr[MS], qyy[KS], quy[MS], quu[MS];
+    bool vF[KS], vG[KS], vGA[MS];
+#pragma unroll
+    for (int q = 0; q < KS; q++) {
+        const int row = mq + 4 * q;
+        vF[q] = row < n && (mi < n || c15); vG[q] = row < n && mi < m;
+        oF[q] = (row < n && mi < n) ? row * NZ + mi : 0;
+        oG[q] = vG[q] ? row * NZ + n + mi : 0;
+        oN[q] = (row < n && mi < n) ? row * n + mi : R::SNN - 1;
+        qyy[q] = (row < n && mi < n) ? sidx(row, mi, NZ) : -1;
+    }
+#pragma unroll
+    for (int s = 0; s < MS; s++) {
+        const int row = mq + 4 * s;
+        vGA[s] = mi < n && row < m;
+        oGA[s] = vGA[s] ? mi * NZ + n + row : 0;
+        oKr[s] = (row < m && mi < n) ? R::oK + row * n + mi : R::SKD - 1;
+        oDr[s] = (row < m && mi < n) ? R::oD + row * n + mi : R::SKD - 1;
+        oSr[s] = (row < m && mi < m) ? R::oS + row * m + mi : R::SKD - 1;
+        quy[s] = (row < m && mi < n) ? sidx(mi, n + row, NZ) : -1;
+        quu[s] = (row < m && mi < m) ? sidx(n + row, n + mi, NZ) : -1;
+    }
+    const int oLA0 = (mi < m) ? mi * m : 0;   // L^-1 as the A operand of L^-1 X: lane (i = mi, k = mq + 4 s) holds Li[mi][k]
+    double* Lw = K.sHh;                       // m x m scratch for L^-1 (the H / Z buffers of the VALU path are unused here)
+    for (int e = tid; e < m * m; e += 64) Lw[e] = 0.0;
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+        const int e = tid + 64 * r;
+        if (e < NPG) K.sPG[((N - 1) & 1) * NPG + e] = K.PGk(N - 1)[e];
+    }
+#pragma unroll
+    for (int r = 0; r < RN; r++) {
+        const int e = tid + 64 * r;
+        if (e < NN) { K.Paft[(size_t)(N - 1) * R::SNN + e] = 0.0; K.Piaft[(size_t)(N - 1) * R::SNN + e] = 0.0; }
+    }
+    double qc[KS + 2 * MS], qn[KS + 2 * MS], pgn[RT];
+    auto gather = [&](int kk, double* q) {   // stage cost QQ_kk in the accumulator layout of the H tiles (clamped gathers)
+        const double* rec = K.QQ + (size_t)kk * R::SQQ;
+#pragma unroll
+        for (int r = 0; r < KS; r++) q[r] = rec[qyy[r] < 0 ? 0 : qyy[r]];
+#pragma unroll
+        for (int s = 0; s < MS; s++) { q[KS + s] = rec[quy[s] < 0 ? 0 : quy[s]]; q[KS + MS + s] = rec[quu[s] < 0 ? 0 : quu[s]]; }
+    };
+    gather(N - 1, qc);
+#pragma unroll
+    for (int r = 0; r < RT; r++) pgn[r] = 0.0;
+    v4d Pt = {0, 0, 0, 0}, Pit = {0, 0, 0, 0}, Gdt = {0, 0, 0, 0};
+    K.sync();
+    for (int k = N - 1; k >= 0; k--) {
+        const double* PGs = pg_buf<MODEL>(K, k);
+        gather((k > 0) ? k - 1 : 0, qn);
+        {
+            const double* pg = K.PGk((k > 0) ? k - 1 : 0);
+#pragma unroll
+            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
+        }
+        pf.tick(PF_FPRE);
+        double F[KS], G[KS], GA[MS];
+#pragma unroll
+        for (int q = 0; q < KS; q++) {
+            const int row = mq + 4 * q;
+            const double* pa = (c15 && row < n) ? K.cv + k * n + row : PGs + oF[q];
+            const double a = *pa, b = PGs[oG[q]];
+            F[q] = vF[q] ? a : 0.0; G[q] = vG[q] ? b : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < MS; s++) { const double a = PGs[oGA[s]]; GA[s] = vGA[s] ? -a : 0.0; }
+        v4d tph = {0, 0, 0, 0}, tga = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < KS; q++) {               // T_Phi = P Phi (column 15: P c), T_Gam = P Gam
+            tph = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[q], F[q], tph, 0, 0, 0);
+            tga = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[q], G[q], tga, 0, 0, 0);
+        }
+        v4d hyy = {0, 0, 0, 0}, huy = {0, 0, 0, 0}, huu = {0, 0, 0, 0}, zy = {0, 0, 0, 0}, zu = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < KS; r++) hyy[r] = qyy[r] < 0 ? 0.0 : qc[r];
+#pragma unroll
+        for (int s = 0; s < MS; s++) { huy[s] = quy[s] < 0 ? 0.0 : qc[KS + s]; huu[s] = quu[s] < 0 ? 0.0 : qc[KS + MS + s]; }
+#pragma unroll
+        for (int q = 0; q < KS; q++) {
+            huu = __builtin_amdgcn_mfma_f64_16x16x4f64(G[q], tga[q], huu, 0, 0, 0);     // Gam^T T_Gam
+            huy = __builtin_amdgcn_mfma_f64_16x16x4f64(G[q], tph[q], huy, 0, 0, 0);     // Gam^T T_Phi
+            zu = __builtin_amdgcn_mfma_f64_16x16x4f64(G[q], Pit[q], zu, 0, 0, 0);       // Gam^T Pi
+            hyy = __builtin_amdgcn_mfma_f64_16x16x4f64(F[q], tph[q], hyy, 0, 0, 0);     // Phi^T T_Phi
+            zy = __builtin_amdgcn_mfma_f64_16x16x4f64(F[q], Pit[q], zy, 0, 0, 0);       // Phi^T Pi (row 15: c^T Pi)
+        }
+        // the two matrix-vector products of the stage, for the stage-parallel blocks: r_k = P_k c_k, Pi_k^T c_k
+#pragma unroll
+        for (int q = 0; q < KS; q++) { const int row = mq + 4 * q; if (c15 && row < n) K.rv[k * n + row] = tph[q]; }
+        if (mq == 3 && mi < n) K.nun[k * n + mi] = zy[3];
+        if (k == N - 1) {   // + E = [M^T C^T; b^T M^T C^T], M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
+            const bool gg = mi < n && K.is_goal(mi < n ? mi : 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = mq + 4 * r;
+                if (gg && row < n) zy[r] += 0.5 * (PGs[mi * NZ + row] + ((row == mi) ? 1.0 : 0.0));
+                if (gg && row < m) zu[r] += 0.5 * PGs[mi * NZ + n + row];
+            }
+        }
+        pf.tick(PF_FAB);
+        double S[m * m], Li[m * m];
+#pragma unroll
+        for (int i = 0; i < m; i++)
+#pragma unroll
+            for (int j = 0; j < m; j++) {   // H_uu[a][b], a <= b: lane (a & 3) << 4 | b, register a >> 2 of the tile
+                const int a = i < j ? i : j, b = i < j ? j : i;
+                S[i * m + j] = readlane_f64(huu[a >> 2], ((a & 3) << 4) | b);
+            }
+        if (!chol_inv<m>(S, Li)) *fail = 1.0;
+        pf.tick(PF_F4);
+        // L^-1 is wave-uniform: one lane parks it in LDS, every lane takes its entries of the two operand layouts
+        if (tid == 0) {
+#pragma unroll
+            for (int a = 0; a < m; a++)
+#pragma unroll
+                for (int c = 0; c <= a; c++) Lw[a * m + c] = Li[a * m + c];
+        }
+        K.sync();
+        double LiA[MS], LiT[MS];
+#pragma unroll
+        for (int s = 0; s < MS; s++) {
+            const int kk = mq + 4 * s;
+            const bool v = mi < m && kk < m;
+            const double a = Lw[v ? oLA0 + kk : 0], b = Lw[v ? kk * m + mi : 0];
+            LiA[s] = v ? a : 0.0;   // A[i = mi][k = kk] = Li[mi][kk]:   L^-1 X
+            LiT[s] = v ? b : 0.0;   // A[i = mi][k = kk] = Li[kk][mi]:   L^-T X  (and, as a B operand, L^-1 itself)
+        }
+        // take the prefetched QQ_{k-1} before this stage's stores are issued (see factor_sweep_1w)
+#pragma unroll
+        for (int e = 0; e < KS + 2 * MS; e++) qc[e] = qn[e];
+        __builtin_amdgcn_sched_barrier(0);
+        v4d W = {0, 0, 0, 0}, V = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < MS; s++) {
+            W = __builtin_amdgcn_mfma_f64_16x16x4f64(LiA[s], huy[s], W, 0, 0, 0);      // W = L^-1 H_uy
+            V = __builtin_amdgcn_mfma_f64_16x16x4f64(LiA[s], zu[s], V, 0, 0, 0);       // V = L^-1 Z_u
+        }
+        v4d Kt = {0, 0, 0, 0}, Dt = {0, 0, 0, 0}, Si = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < MS; s++) {
+            const double wn = -W[s];
+            hyy = __builtin_amdgcn_mfma_f64_16x16x4f64(wn, W[s], hyy, 0, 0, 0);        // P'  = H_yy - W^T W
+            zy = __builtin_amdgcn_mfma_f64_16x16x4f64(wn, V[s], zy, 0, 0, 0);          // Pi' = Z_y  - W^T V
+            Gdt = __builtin_amdgcn_mfma_f64_16x16x4f64(V[s], V[s], Gdt, 0, 0, 0);      // Gd += V^T V
+            Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(LiT[s], W[s], Kt, 0, 0, 0);      // K = L^-T W
+            Dt = __builtin_amdgcn_mfma_f64_16x16x4f64(LiT[s], V[s], Dt, 0, 0, 0);      // D = L^-T V
+            Si = __builtin_amdgcn_mfma_f64_16x16x4f64(LiT[s], LiT[s], Si, 0, 0, 0);    // S^-1 = L^-T L^-1
+        }
+        v4d Ph = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < KS; q++) Ph[q] = F[q];
+#pragma unroll
+        for (int s = 0; s < MS; s++) Ph = __builtin_amdgcn_mfma_f64_16x16x4f64(GA[s], Kt[s], Ph, 0, 0, 0);   // Phi - Gam K
+        pf.tick(PF_F6);
+        Pt = hyy; Pit = zy;
+        // records (unconditional stores: lanes outside a matrix aim at the padding slot of the record)
+        {
+            double* phr = K.Phicl + (size_t)k * R::SNN;
+            double* par = K.Paft + (size_t)(k - 1) * R::SNN;    // (record -1 exists for k == 0)
+            double* pir = K.Piaft + (size_t)(k - 1) * R::SNN;
+            double* kdr = K.KD + (size_t)k * R::SKD;
+#pragma unroll
+            for (int q = 0; q < KS; q++) { phr[oN[q]] = Ph[q]; par[oN[q]] = hyy[q]; pir[oN[q]] = zy[q]; }
+#pragma unroll
+            for (int s = 0; s < MS; s++) { kdr[oKr[s]] = Kt[s]; kdr[oDr[s]] = Dt[s]; kdr[oSr[s]] = Si[s]; }
+        }
+        if (k > 0) {
+#pragma unroll
+            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; if (e < NPG) K.sPG[((k - 1) & 1) * NPG + e] = pgn[r]; }
+        }
+        pf.tick(PF_F7);
+        K.sync();
+        pf.tick(PF_FCD);
+    }
+    // Gd = sum V^T V for the goal system of the mid phase
+#pragma unroll
+    for (int q = 0; q < KS; q++) { const int row = mq + 4 * q; if (row < n && mi < n) K.sGd[row * n + mi] = Gdt[q]; }
+    K.sync();
+}
+
 // Affine vector recurrences of the one-wave path.  The wave is split into C = 64/n groups of n lanes; group g
 // holds the operands of knot (k0 -+ g) of the current chunk of C knots, so ONE batch of global loads feeds C knots
 // of the dependency chain (the recurrences are memory-latency bound otherwise), and the next chunk is fetched
@@ -1200,13 +1402,15 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
 template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(SweepView<MODEL> K, Prof* pf) {
     K.rebind_lds(gusto_dyn_lds);
     K.rebind_global();
-    factor_sweep_1w<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
+    if constexpr (MT<MODEL>::MFMA) factor_sweep_mfma<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
+    else factor_sweep_1w<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
 }
 template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof& pf) {
     if constexpr (!BLK::ONE) factor_sweep_mw<MODEL>(K, fail);
 #ifndef GUSTO_SWEEP_INLINE
     else if constexpr (MT<MODEL>::SWEEP_CALL) factor_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K), &pf);
 #endif
+    else if constexpr (MT<MODEL>::MFMA) factor_sweep_mfma<MODEL>(SweepView<MODEL>::make(K), fail, pf);
     else factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail, pf);
 }
 template <int MODEL> __device__ __noinline__ void backward_sweep_1w_call(SweepView<MODEL> K) {
