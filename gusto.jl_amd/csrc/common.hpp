@@ -367,6 +367,10 @@ template <class Tp> GD Tp* as_global(Tp* p) {
     typedef __attribute__((address_space(1))) Tp G;
     return (Tp*)(G*)p;
 }
+// The per-knot records of the workspace start on 16-byte boundaries (WsLayout: even offsets, 64-double strides): told
+// so, the compiler merges the loads of two adjacent entries into one global_load_dwordx4 -- half the instructions for
+// the record walks of the stage-parallel phases, each of which touches one cache line per lane.
+template <class Tp> GD Tp* al16(Tp* p) { return static_cast<Tp*>(__builtin_assume_aligned(p, 16)); }
 
 // 1/d from the hardware seed + two Newton steps (the inner part of the IEEE division sequence, without its scaling
 // and final correction: <= 2 ulp for the normal-range, finite operands of the row algebra): ~6 instructions against

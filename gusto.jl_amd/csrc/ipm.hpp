@@ -83,7 +83,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
 
     GD void rebind_global() {   // (see rebind_lds)
         rowstate = as_global(rowstate); obs_nh = as_global(obs_nh); obs_c0 = as_global(obs_c0); obs_mask = as_global(obs_mask);
-        PG = as_global(PG); QQ = as_global(QQ); Paft = as_global(Paft); Piaft = as_global(Piaft); KD = as_global(KD);
+        PG = al16(as_global(PG)); QQ = al16(as_global(QQ)); Paft = al16(as_global(Paft)); Piaft = al16(as_global(Piaft)); KD = al16(as_global(KD));
         Phicl = as_global(Phicl);
         rd = as_global(rd); qrd = as_global(qrd); dXs = as_global(dXs); dUs = as_global(dUs); qu = as_global(qu); dv = as_global(dv);
         Xp = as_global(Xp); Up = as_global(Up);
@@ -100,7 +100,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         const WsLayout& W = P.wl;
         rowstate = w + W.rowstate; obs_nh = w + W.obs_nh; obs_c0 = w + W.obs_c0;
         obs_mask = reinterpret_cast<uint64_t*>(w + W.obs_mask);
-        PG = w + W.PG; QQ = w + W.QQ; Paft = w + W.Paft; Piaft = w + W.Piaft; KD = w + W.KD; Phicl = w + W.Phicl;
+        PG = al16(w + W.PG); QQ = al16(w + W.QQ); Paft = al16(w + W.Paft); Piaft = al16(w + W.Piaft); KD = al16(w + W.KD); Phicl = w + W.Phicl;
         {   // knot-private vectors in the global workspace, the linearisation point = the stored trajectory
             double* q = w + W.pvt;
             rd = q; qrd = q + N * n; dXs = q + 2 * N * n; dUs = q + 3 * N * n; qu = dUs + N * m; dv = qu + N * m;
@@ -575,7 +575,7 @@ template <int MODEL> struct SweepView {
         if constexpr (C::PHICL_LDS) Phicl = lds + phicl_off;
     }
     GD void rebind_global() {
-        PG = as_global(PG); QQ = as_global(QQ); Paft = as_global(Paft); Piaft = as_global(Piaft); KD = as_global(KD);
+        PG = al16(as_global(PG)); QQ = al16(as_global(QQ)); Paft = al16(as_global(Paft)); Piaft = al16(as_global(Piaft)); KD = al16(as_global(KD));
         if constexpr (!C::PHICL_LDS) Phicl = as_global(Phicl);
     }
     template <class BLK> GD static SweepView make(const BLK& K) {
@@ -1546,11 +1546,21 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
                 gterm[j] = g; gsub[j] = K.goal_lo[j] - K.Xw[k * n + j];
             }
         }
+        // (the record of D is walked in storage order, row by row.  Lane k reads ITS knot's record, so one load touches 50
+        // cache lines, and the 16 entries of a line are served by the L1 only while the wave's live set stays ~50 lines:
+        // column by column it is every line of the block x 50 knots, which does not fit next to the other waves.  The
+        // knot-major records were also tried entry-major (one coalesced load per entry): every load then goes to the
+        // L2 and the stage-parallel phases got 40-170 % slower.)
+        double thd[n];
+#pragma unroll
+        for (int j = 0; j < n; j++) thd[j] = K.nun[k * n + j];   // Pi_k^T c_k from the factor sweep (nun is free until the corrector's costates)
+#pragma unroll
+        for (int i = 0; i < m; i++)
+#pragma unroll
+            for (int j = 0; j < n; j++) thd[j] -= K.KD[(size_t)k * R::SKD + R::oD + i * n + j] * lu[i];
 #pragma unroll
         for (int j = 0; j < n; j++) {
-            double s = K.nun[k * n + j];   // Pi_k^T c_k from the factor sweep (nun is free until the corrector's costates)
-#pragma unroll
-            for (int i = 0; i < m; i++) s -= K.KD[(size_t)k * R::SKD + R::oD + i * n + j] * lu[i];
+            double s = thd[j];
             if constexpr (T::LTI) {
                 s = (k == N - 1 && K.is_goal(j)) ? (s + gterm[j]) - gsub[j] : s;
             } else
@@ -1619,11 +1629,11 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
 #undef MT_
 }
 template <int MODEL, class BLK> __device__ __noinline__ void mid_phase_call(BLK K, int k, bool act, double hdt, double* red,
-                                                                            double* mugn) {
+                                                                            double* mugn, Prof* pf) {
     K.rebind_lds(gusto_dyn_lds);
     K.rebind_global();
     using C = typename BLK::C;
-    mid_phase<MODEL>(K, k, act, hdt, gusto_dyn_lds + C::misc, gusto_dyn_lds + C::misc + 48);
+    mid_phase<MODEL>(K, k, act, hdt, gusto_dyn_lds + C::misc, gusto_dyn_lds + C::misc + 48, pf);
 }
 
 // The phase after the forward sweep of a right-hand side: primal step of this knot, the new costates, row steps and
@@ -2108,12 +2118,16 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                     quk[i] = s;
                     K.qu[k * m + i] = s;
                 }
+                {   // qt_k = gy - K^T qu (the record of K walked in storage order, see mid_phase)
+                    double qt[n];
 #pragma unroll
-                for (int i = 0; i < n; i++) {
-                    double s = gy[i];
+                    for (int i = 0; i < n; i++) qt[i] = gy[i];
 #pragma unroll
-                    for (int l = 0; l < m; l++) s -= K.KD[(size_t)k * R::SKD + R::oK + l * n + i] * quk[l];
-                    K.pv[k * n + i] = s + (k >= 1 ? K.rv[(k - 1) * n + i] : 0.0);   // qq_k = qt_k + r_{k-1}
+                    for (int l = 0; l < m; l++)
+#pragma unroll
+                        for (int i = 0; i < n; i++) qt[i] -= K.KD[(size_t)k * R::SKD + R::oK + l * n + i] * quk[l];
+#pragma unroll
+                    for (int i = 0; i < n; i++) K.pv[k * n + i] = qt[i] + (k >= 1 ? K.rv[(k - 1) * n + i] : 0.0);   // qq_k = qt_k + r_{k-1}
                 }
                 pf.tick(PF_F8);
             }
@@ -2122,7 +2136,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             backward_sweep<MODEL>(K);
             pf.tick(PF_BACK);
             GUSTO_REFRESH_K();
-            if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL>(K, k, act, hdt, red, mugn);
+            if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL>(K, k, act, hdt, red, mugn, &pf);
             else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf);
             pf.tick(PF_MID);
             forward_sweep<MODEL>(K);
