@@ -367,6 +367,25 @@ template <class Tp> GD Tp* as_global(Tp* p) {
     typedef __attribute__((address_space(1))) Tp G;
     return (Tp*)(G*)p;
 }
+// Pointer members that remember their address space.  A struct that is passed to a (non-inlined) phase function, or whose
+// address escapes, lives in memory; a plain pointer reloaded from it is GENERIC to the compiler and every access through
+// it becomes flat_load / flat_store -- which also counts against lgkmcnt, so each wait for an LDS read waits for the
+// global loads in flight as well.  The 12/13-state kernels had 4 200 flat and 146 global memory instructions that way.
+// These wrappers keep the pointer TYPED with its address space (a cast pair generic -> global -> generic at the point
+// of use is folded away before the address space inference runs).
+template <class Tp, int AS> struct ASPtr {
+    typedef __attribute__((address_space(AS))) Tp A;
+    A* p;
+    ASPtr() = default;
+    GD ASPtr(Tp* q) : p((A*)q) {}
+    template <class U> GD ASPtr(const ASPtr<U, AS>& o) : p(o.p) {}
+    template <class I> GD A& operator[](I i) const { return p[i]; }
+    template <class I> GD ASPtr operator+(I i) const { ASPtr r; r.p = p + i; return r; }
+    GD A& operator*() const { return *p; }
+    GD operator Tp*() const { return (Tp*)p; }   // (generic again: for the few callers that take a plain pointer)
+};
+template <class Tp> using GPtr = ASPtr<Tp, 1>;   // global memory
+template <class Tp> using LPtr = ASPtr<Tp, 3>;   // LDS
 // The per-knot records of the workspace start on 16-byte boundaries (WsLayout: even offsets, 64-double strides): told
 // so, the compiler merges the loads of two adjacent entries into one global_load_dwordx4 -- half the instructions for
 // the record walks of the stage-parallel phases, each of which touches one cache line per lane.

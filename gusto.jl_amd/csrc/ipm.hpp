@@ -55,14 +55,16 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     double dt;
     double* lds;
     // LDS working set (compile-time offsets)
-    double *sP, *sPi, *sPG, *sT, *sHh, *sZ, *sK, *sD, *sW, *sV, *sGd, *misc;
-    int* lut;  // packed upper-triangle index -> (i << 8 | j)
+    LPtr<double> sP, sPi, sPG, sT, sHh, sZ, sK, sD, sW, sV, sGd, misc;
+    LPtr<int> lut;  // packed upper-triangle index -> (i << 8 | j)
     // LDS per-knot vectors
-    double *Xw, *Xp, *dY, *rd, *pv, *cv, *rv, *qrd, *nu, *nun, *dXs, *Uw, *Up, *qu, *dv, *dUs;
+    LPtr<double> Xw, dY, pv, cv, rv, nu, nun, Uw;
+    // knot-private vectors and the linearisation point (global)
+    GPtr<double> Xp, rd, qrd, dXs, Up, qu, dv, dUs;
     // global workspace of this problem
-    double *rowstate, *obs_nh, *obs_c0, *PG, *QQ, *Paft, *Piaft, *KD, *Phicl;
-    uint64_t* obs_mask;
-    const double *x_init, *goal_lo, *goal_hi;
+    GPtr<double> rowstate, obs_nh, obs_c0, PG, QQ, Paft, Piaft, KD, Phicl;
+    GPtr<uint64_t> obs_mask;
+    GPtr<const double> x_init, goal_lo, goal_hi;
     unsigned goalmask;  // bit i: coordinate i of x_N has a point goal (goal_lo == goal_hi)
 
     GD int nt() const { return ONEWAVE ? 64 : NTr; }
@@ -82,12 +84,8 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     }
 
     GD void rebind_global() {   // (see rebind_lds)
-        rowstate = as_global(rowstate); obs_nh = as_global(obs_nh); obs_c0 = as_global(obs_c0); obs_mask = as_global(obs_mask);
-        PG = al16(as_global(PG)); QQ = al16(as_global(QQ)); Paft = al16(as_global(Paft)); Piaft = al16(as_global(Piaft)); KD = al16(as_global(KD));
-        Phicl = as_global(Phicl);
-        rd = as_global(rd); qrd = as_global(qrd); dXs = as_global(dXs); dUs = as_global(dUs); qu = as_global(qu); dv = as_global(dv);
-        Xp = as_global(Xp); Up = as_global(Up);
-        x_init = as_global(x_init); goal_lo = as_global(goal_lo); goal_hi = as_global(goal_hi);
+        // (the members carry their address space, GPtr / LPtr; only the alignment promise is renewed)
+        PG = al16((double*)PG); QQ = al16((double*)QQ); Paft = al16((double*)Paft); Piaft = al16((double*)Piaft); KD = al16((double*)KD);
     }
 
     // b = the problem, slot = the resident workgroup: the interior point workspace belongs to the SLOT (a few hundred
@@ -551,10 +549,12 @@ template <int MODEL> struct SweepView {
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr bool ONE = true;
     static constexpr int SPH = C::PHICL_LDS ? n * n : R::SNN;   // stride of Phicl records (LDS copy is unpadded)
-    double *lds, *sP, *sPi, *sPG, *sT, *sHh, *sZ, *sK, *sD, *sW, *sV, *sGd;
-    int* lut;
-    double *cv, *rv, *nun, *pv, *dY;
-    double *PG, *QQ, *Paft, *Piaft, *KD, *Phicl;
+    double* lds;
+    LPtr<double> sP, sPi, sPG, sT, sHh, sZ, sK, sD, sW, sV, sGd;
+    LPtr<int> lut;
+    LPtr<double> cv, rv, nun, pv, dY;
+    GPtr<double> PG, QQ, Paft, Piaft, KD;
+    std::conditional_t<C::PHICL_LDS, LPtr<double>, GPtr<double>> Phicl;
     const gusto_model_params* mpp;
     struct PW { const gusto_model_params& mp; } ;
     int tid, N;
@@ -575,13 +575,12 @@ template <int MODEL> struct SweepView {
         if constexpr (C::PHICL_LDS) Phicl = lds + phicl_off;
     }
     GD void rebind_global() {
-        PG = al16(as_global(PG)); QQ = al16(as_global(QQ)); Paft = al16(as_global(Paft)); Piaft = al16(as_global(Piaft)); KD = al16(as_global(KD));
-        if constexpr (!C::PHICL_LDS) Phicl = as_global(Phicl);
+        PG = al16((double*)PG); QQ = al16((double*)QQ); Paft = al16((double*)Paft); Piaft = al16((double*)Piaft); KD = al16((double*)KD);
     }
     template <class BLK> GD static SweepView make(const BLK& K) {
         SweepView v;
         v.N = K.N; v.phicl_off = K.P.ll.phicl;
-        v.Phicl = K.Phicl;
+        if constexpr (!C::PHICL_LDS) v.Phicl = K.Phicl;   // (LDS copy of the small models: set by rebind_lds)
         v.rebind_lds(K.lds);
         v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.KD = K.KD;
         v.mpp = &K.P.mp; v.tid = K.tid; v.dt = K.dt; v.goalmask = K.goalmask;
@@ -1318,20 +1317,27 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 // backward: pt_{k-1} = Phicl_k^T pt_k + qq_k, k = N-1..1, pt := p + r (so qq_k = qt_k + r_{k-1}), pt_{N-1} = r_{N-1}.
 //           pv[k] holds qq_k on entry and pt_k on exit.
 template <class BLK> GD void backward_sweep_1w(BLK K) {
-    constexpr int n = BLK::n, C = 64 / n;
+    constexpr int n = BLK::n, C = 64 / n, PS = n > 8 ? 4 : 1;
+    // 12/13-state models: the n-vector goes from group to group through 64 doubles of LDS (one ds_write per lane, broadcast
+    // ds_reads at compile-time addresses) instead of 2 n v_readlane per knot
+    constexpr bool XL = n > 8;
+    double* ex = K.sHh;
     using R = typename BLK::R;
     const int tid = K.tid, N = K.N;
     const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
     double col[n], coln[n], qv, qvn = 0, pval;
     auto fetch = [&](int k0, double* c, double& q) {
-        const int kk = k0 - g;
-        const bool ok = kk >= 1;
+        // (clamped, unconditional loads: a group past the end of the sweep never has its step executed -- the steps are
+        // guarded wave-uniformly below -- so its operands only need to be loadable.  As `ok ? load : 0` every load sat
+        // in a branch of its own.)
+        const int kk = (k0 - g >= 1) ? k0 - g : 1;
 #pragma unroll
-        for (int l = 0; l < n; l++) c[l] = ok ? K.Phicl[(size_t)kk * BLK::SPH + l * n + i] : 0.0;
-        q = ok ? K.pv[kk * n + i] : 0.0;
+        for (int l = 0; l < n; l++) c[l] = K.Phicl[(size_t)kk * BLK::SPH + l * n + i];
+        q = K.pv[kk * n + i];
     };
     fetch(N - 1, col, qv);
     pval = K.rv[(N - 1) * n + i];       // every group starts from pt_{N-1}; only group C-1 is read at step 0
+    if constexpr (XL) ex[tid] = pval;
     K.sync();
     if (tid < n) K.pv[(N - 1) * n + tid] = pval;
     for (int k0 = N - 1; k0 >= 1; k0 -= C) {
@@ -1340,10 +1346,23 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
         for (int gs = 0; gs < C; gs++) {
             if (k0 - gs >= 1) {
                 const int sg = (gs == 0) ? C - 1 : gs - 1;
-                double s = qv;
+                // (independent partial sums: the n dependent FMAs of one dot product were most of the time per knot)
+                double acc[PS];
 #pragma unroll
-                for (int l = 0; l < n; l++) s += col[l] * readlane_f64(pval, sg * n + l);
+                for (int q = 0; q < PS; q++) acc[q] = (q == 0) ? qv : 0.0;
+                if constexpr (XL) {
+                    double pb[n];
+#pragma unroll
+                    for (int l = 0; l < n; l++) pb[l] = ex[sg * n + l];
+#pragma unroll
+                    for (int l = 0; l < n; l++) acc[l % PS] += col[l] * pb[l];
+                } else {
+#pragma unroll
+                    for (int l = 0; l < n; l++) acc[l % PS] += col[l] * readlane_f64(pval, sg * n + l);
+                }
+                const double s = (PS == 4) ? (acc[0] + acc[1]) + (acc[2] + acc[PS - 1]) : acc[0];
                 pval = (g == gs) ? s : pval;
+                if constexpr (XL) ex[tid] = pval;
             }
         }
         {   // group g produced pt_{kk-1}, kk = k0 - g
@@ -1359,19 +1378,21 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
 
 // forward: dy_k = Phicl_k dy_{k-1} + ct_k, k = 0..N-1; dY[k] holds ct_k on entry and dy_k on exit
 template <class BLK> GD void forward_sweep_1w(BLK K) {
-    constexpr int n = BLK::n, C = 64 / n;
+    constexpr int n = BLK::n, C = 64 / n, PS = n > 8 ? 4 : 1;
+    constexpr bool XL = n > 8;   // (see backward_sweep_1w)
+    double* ex = K.sHh;
     using R = typename BLK::R;
     const int tid = K.tid, N = K.N;
     const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
     double row[n], rown[n], cv, cvn = 0, yval = 0.0;
     auto fetch = [&](int k0, double* r, double& c) {
-        const int kk = k0 + g;
-        const bool ok = kk < N;
+        const int kk = (k0 + g < N) ? k0 + g : N - 1;   // (clamped, see backward_sweep_1w)
 #pragma unroll
-        for (int l = 0; l < n; l++) r[l] = ok ? K.Phicl[(size_t)kk * BLK::SPH + i * n + l] : 0.0;
-        c = ok ? K.dY[kk * n + i] : 0.0;
+        for (int l = 0; l < n; l++) r[l] = K.Phicl[(size_t)kk * BLK::SPH + i * n + l];
+        c = K.dY[kk * n + i];
     };
     fetch(0, row, cv);
+    if constexpr (XL) ex[tid] = yval;
     K.sync();
     for (int k0 = 0; k0 < N; k0 += C) {
         if (k0 + C < N) fetch(k0 + C, rown, cvn);
@@ -1379,10 +1400,22 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
         for (int gs = 0; gs < C; gs++) {
             if (k0 + gs < N) {
                 const int sg = (gs == 0) ? C - 1 : gs - 1;
-                double s = cv;
+                double acc[PS];
 #pragma unroll
-                for (int l = 0; l < n; l++) s += row[l] * readlane_f64(yval, sg * n + l);
+                for (int q = 0; q < PS; q++) acc[q] = (q == 0) ? cv : 0.0;
+                if constexpr (XL) {
+                    double pb[n];
+#pragma unroll
+                    for (int l = 0; l < n; l++) pb[l] = ex[sg * n + l];
+#pragma unroll
+                    for (int l = 0; l < n; l++) acc[l % PS] += row[l] * pb[l];
+                } else {
+#pragma unroll
+                    for (int l = 0; l < n; l++) acc[l % PS] += row[l] * readlane_f64(yval, sg * n + l);
+                }
+                const double s = (PS == 4) ? (acc[0] + acc[1]) + (acc[2] + acc[PS - 1]) : acc[0];
                 yval = (g == gs) ? s : yval;
+                if constexpr (XL) ex[tid] = yval;
             }
         }
         {
@@ -1723,9 +1756,6 @@ __device__ __noinline__ StepOut step_phase_call(BLK K, RowCtx<MODEL> ctx, RowSta
                                                 double hdt, double tau, double mu_t, const double* mugn, const double* gxs) {
     K.rebind_lds(gusto_dyn_lds);
     K.rebind_global();
-    rs.base = as_global(rs.base);
-    ctx.xp = as_global(ctx.xp); ctx.obs_nh = as_global(ctx.obs_nh); ctx.obs_c0 = as_global(ctx.obs_c0);
-    ctx.goal_lo = as_global(ctx.goal_lo); ctx.goal_hi = as_global(ctx.goal_hi);
     using C = typename BLK::C;
     return step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, gusto_dyn_lds + C::misc + 48,
                              gusto_dyn_lds + C::misc + 16);
@@ -1930,9 +1960,6 @@ __device__ __noinline__ ResidOut resid_phase_call(BLK K, RowCtx<MODEL> ctx, RowS
                                                   double alpha_prev, const double* mug) {
     K.rebind_lds(gusto_dyn_lds);
     K.rebind_global();
-    rs.base = as_global(rs.base);
-    ctx.xp = as_global(ctx.xp); ctx.obs_nh = as_global(ctx.obs_nh); ctx.obs_c0 = as_global(ctx.obs_c0);
-    ctx.goal_lo = as_global(ctx.goal_lo); ctx.goal_hi = as_global(ctx.goal_hi);
     using C = typename BLK::C;
     return resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, gusto_dyn_lds + C::misc + 32);
 }

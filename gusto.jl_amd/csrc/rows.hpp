@@ -28,12 +28,12 @@ template <int MODEL> struct RowCtx {
     const KParams* P;
     int N, k, nslot;
     double kappa, omega, Delta;
-    const double* xp;      // linearisation state of this knot
-    uint64_t mask;         // active obstacle rows (dist < obstacle_toggle_distance)
-    const double* obs_nh;  // [n_obs][WS][N]
-    const double* obs_c0;  // [n_obs][N]
-    const double* goal_lo;
-    const double* goal_hi;
+    GPtr<const double> xp;      // linearisation state of this knot
+    uint64_t mask;              // active obstacle rows (dist < obstacle_toggle_distance)
+    GPtr<const double> obs_nh;  // [n_obs][WS][N]
+    GPtr<const double> obs_c0;  // [n_obs][N]
+    GPtr<const double> goal_lo;
+    GPtr<const double> goal_hi;
 };
 
 template <int I, int E, class F> GD void static_for(F&& f) {
@@ -178,11 +178,11 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
 
 // ---- per-row state access --------------------------------------------------------------------------
 struct RowState {
-    double* base;
+    GPtr<double> base;
     int nslot, N, k;
     // uniform (scalar) row base + per-lane knot index: lets the compiler use the SGPR-base + VGPR-offset form of
     // global_load/store instead of materialising (and hoisting, and spilling) one 64-bit VGPR address per row
-    GD double& at(int var, int slot) const { return (base + (size_t)(var * nslot + slot) * (size_t)N)[k]; }
+    GD auto& at(int var, int slot) const { return (base + (size_t)(var * nslot + slot) * (size_t)N)[k]; }
 };
 
 // State of the rows every knot has at compile-time positions (the NFIX state rows, then the NHU control rows; template
