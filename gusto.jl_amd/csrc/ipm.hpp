@@ -121,6 +121,80 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     GD bool is_goal(int i) const { return (goalmask >> i) & 1u; }
 };
 
+// M = (I - dt/2 A(x, u))^-1 and B of one knot: the linearisation of linearize(), and of the stage-parallel phases of the
+// 12/13-state models, which RECOMPUTE M and Gam (~350 instructions) instead of walking the knot's [Phi Gam] record
+// (~80 loads of one cache line per lane each, five times per interior point iteration).
+template <int MODEL, class XP, class UP>
+GD void stage_M(const gusto_model_params& mp, XP xp, UP up, double h, double* M, double* B) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n, m = T::m;
+    double xl[n], ul[m];   // (read through the caller's typed pointer: a plain pointer parameter would be generic)
+#pragma unroll
+    for (int i = 0; i < n; i++) xl[i] = xp[i];
+#pragma unroll
+    for (int i = 0; i < m; i++) ul[i] = up[i];
+    double A[n * n], G[n * n];
+    Dyn<MODEL>::A(mp, xl, ul, A);
+    Dyn<MODEL>::B(mp, B);
+#pragma unroll
+    for (int i = 0; i < n; i++)
+#pragma unroll
+        for (int j = 0; j < n; j++) G[i * n + j] = (i == j ? 1.0 : 0.0) - h * A[i * n + j];
+    if constexpr (MODEL == GUSTO_ASTROBEE_SE3 || MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD) {
+        // x = (r, v, attitude a, w): G = I - hA = [I -hI 0 0; 0 I 0 0; 0 0 P Q; 0 0 0 W] (Anz), so
+        // M = G^-1 = [I hI 0 0; 0 I 0 0; 0 0 P^-1 -P^-1 Q W^-1; 0 0 0 W^-1]: two small inverses instead of a
+        // pivoted 12 x 24 / 13 x 26 elimination in registers (which was most of this phase for these models)
+        constexpr int q = n - 9;   // attitude block: 3 (MRP) or 4 (quaternion)
+        double Pm[q * q], Pi[q * q], Wm[9], Wi[9], Qm[q * 3], T1[q * 3];
+#pragma unroll
+        for (int i = 0; i < q; i++) {
+#pragma unroll
+            for (int j = 0; j < q; j++) Pm[i * q + j] = G[(6 + i) * n + 6 + j];
+#pragma unroll
+            for (int j = 0; j < 3; j++) Qm[i * 3 + j] = G[(6 + i) * n + 6 + q + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Wm[i * 3 + j] = G[(6 + q + i) * n + 6 + q + j];
+        inv_gauss_jordan<q>(Pm, Pi);
+        inv_gauss_jordan<3>(Wm, Wi);
+#pragma unroll
+        for (int i = 0; i < q; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                double t = 0;
+#pragma unroll
+                for (int l = 0; l < 3; l++) t += Qm[i * 3 + l] * Wi[l * 3 + j];
+                T1[i * 3 + j] = t;
+            }
+#pragma unroll
+        for (int i = 0; i < n * n; i++) M[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) M[i * n + i] = 1.0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) M[i * n + 3 + i] = h;
+#pragma unroll
+        for (int i = 0; i < q; i++) {
+#pragma unroll
+            for (int j = 0; j < q; j++) M[(6 + i) * n + 6 + j] = Pi[i * q + j];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                double t = 0;
+#pragma unroll
+                for (int l = 0; l < q; l++) t -= Pi[i * q + l] * T1[l * 3 + j];
+                M[(6 + i) * n + 6 + q + j] = t;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) M[(6 + q + i) * n + 6 + q + j] = Wi[i * 3 + j];
+    } else {
+        inv_gauss_jordan<n>(G, M);
+    }
+}
+
 // M_k and Gam_k of knot k (k >= 1) from the stored [Phi | Gam] block
 template <class BLK> GD void load_M_Gam(const BLK& K, int k, double* M, double* Gam) {
     using T = typename BLK::T;
@@ -146,6 +220,27 @@ template <class BLK> GD void load_M_Gam(const BLK& K, int k, double* M, double* 
         }
         return;
     }
+    if constexpr (!T::LTI && n > 8) {
+        // recomputed with the operations of linearize() (and the round trip M -> Phi = 2 M - I -> M of the stored block),
+        // so the values are those of the record
+        double Mx[n * n], Bx[n * m];
+        const double h = 0.5 * K.dt;
+        stage_M<BLK::MODEL_ID>(K.P.mp, K.Xp + k * n, K.Up + k * m, h, Mx, Bx);
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+#pragma unroll
+            for (int j = 0; j < n; j++)
+                M[i * n + j] = T::Mnz(i, j) ? 0.5 * ((2.0 * Mx[i * n + j] - (i == j ? 1.0 : 0.0)) + (i == j ? 1.0 : 0.0)) : 0.0;
+#pragma unroll
+            for (int j = 0; j < m; j++) {
+                double s = 0;
+#pragma unroll
+                for (int l = 0; l < n; l++) s += Mx[i * n + l] * (h * Bx[l * m + j]);
+                Gam[i * m + j] = T::Gnz(i, j) ? 2.0 * s : 0.0;
+            }
+        }
+        return;
+    }
     const double* pg = K.PGk(k);
 #pragma unroll
     for (int i = 0; i < n; i++) {
@@ -167,67 +262,9 @@ template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
         const double* xp = K.Xp + k * n;
         const double* up = K.Up + k * m;
         if (!T::LTI || k == 0) {
-            double A[n * n], G[n * n], M[n * n], B[n * m];
-            Dyn<MODEL>::A(K.P.mp, xp, up, A);
-            Dyn<MODEL>::B(K.P.mp, B);
+            double M[n * n], B[n * m];
             const double h = 0.5 * K.dt;
-#pragma unroll
-            for (int i = 0; i < n; i++)
-#pragma unroll
-                for (int j = 0; j < n; j++) G[i * n + j] = (i == j ? 1.0 : 0.0) - h * A[i * n + j];
-            if constexpr (MODEL == GUSTO_ASTROBEE_SE3 || MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD) {
-                // x = (r, v, attitude a, w): G = I - hA = [I -hI 0 0; 0 I 0 0; 0 0 P Q; 0 0 0 W] (Anz), so
-                // M = G^-1 = [I hI 0 0; 0 I 0 0; 0 0 P^-1 -P^-1 Q W^-1; 0 0 0 W^-1]: two small inverses instead of a
-                // pivoted 12 x 24 / 13 x 26 elimination in registers (which was most of this phase for these models)
-                constexpr int q = n - 9;   // attitude block: 3 (MRP) or 4 (quaternion)
-                double Pm[q * q], Pi[q * q], Wm[9], Wi[9], Qm[q * 3], T1[q * 3];
-#pragma unroll
-                for (int i = 0; i < q; i++) {
-#pragma unroll
-                    for (int j = 0; j < q; j++) Pm[i * q + j] = G[(6 + i) * n + 6 + j];
-#pragma unroll
-                    for (int j = 0; j < 3; j++) Qm[i * 3 + j] = G[(6 + i) * n + 6 + q + j];
-                }
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-#pragma unroll
-                    for (int j = 0; j < 3; j++) Wm[i * 3 + j] = G[(6 + q + i) * n + 6 + q + j];
-                inv_gauss_jordan<q>(Pm, Pi);
-                inv_gauss_jordan<3>(Wm, Wi);
-#pragma unroll
-                for (int i = 0; i < q; i++)
-#pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        double t = 0;
-#pragma unroll
-                        for (int l = 0; l < 3; l++) t += Qm[i * 3 + l] * Wi[l * 3 + j];
-                        T1[i * 3 + j] = t;
-                    }
-#pragma unroll
-                for (int i = 0; i < n * n; i++) M[i] = 0.0;
-#pragma unroll
-                for (int i = 0; i < 6; i++) M[i * n + i] = 1.0;
-#pragma unroll
-                for (int i = 0; i < 3; i++) M[i * n + 3 + i] = h;
-#pragma unroll
-                for (int i = 0; i < q; i++) {
-#pragma unroll
-                    for (int j = 0; j < q; j++) M[(6 + i) * n + 6 + j] = Pi[i * q + j];
-#pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        double t = 0;
-#pragma unroll
-                        for (int l = 0; l < q; l++) t -= Pi[i * q + l] * T1[l * 3 + j];
-                        M[(6 + i) * n + 6 + q + j] = t;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-#pragma unroll
-                    for (int j = 0; j < 3; j++) M[(6 + q + i) * n + 6 + q + j] = Wi[i * 3 + j];
-            } else {
-                inv_gauss_jordan<n>(G, M);
-            }
+            stage_M<MODEL>(K.P.mp, xp, up, h, M, B);
             double* pg = K.PG + (size_t)(T::LTI ? 0 : k) * n * NZ;
             const bool knot0 = !T::LTI && k == 0;   // x_1 is pinned: the sweep's operand of knot 0 is [0 | b_0], b_0 = dt/2 B
 #pragma unroll
@@ -1531,7 +1568,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
     if (act) {
         double tt[n], lu[m], Gamk[n * m];
         if (k >= 1) {
-            if constexpr (T::PG2) {
+            if constexpr (T::PG2 || (!T::LTI && n > 8)) {
                 double Mk_[n * n];
                 load_M_Gam(K, k, Mk_, Gamk);
             } else {
@@ -1633,7 +1670,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         }
         double Gamk[n * m];
         if (k >= 1) {
-            if constexpr (T::PG2) {
+            if constexpr (T::PG2 || (!T::LTI && n > 8)) {
                 double Mk_[n * n];
                 load_M_Gam(K, k, Mk_, Gamk);
             } else {
