@@ -187,15 +187,25 @@ template <int MODEL, bool ONE> struct LdsC {
     // One-wave problems of the small models also keep the closed-loop matrices Phicl_k (written once by the factor
     // sweep, read by the four vector sweeps of an iteration) in LDS, behind the vectors: [N][n*n].  4 problems per
     // CU are register-limited anyway, so up to 40 KB of LDS per problem are free.
+    // The double integrator (MT::PG2) keeps K_k | D_k | S_k^-1 there instead (2 m n + m (m + 1) / 2 doubles per knot):
+    // Phicl = Phi - Gam K is ONE fma per entry from K and the model constants, so the vector sweeps rebuild their
+    // operands from K, and the stage-parallel phases -- which walked these records in global memory, one cache line per
+    // lane per load, ~160 loads per interior point iteration -- read them from LDS.
+#ifdef GUSTO_NO_KD_LDS
+    static constexpr bool KD_LDS = false;
+#else
+    static constexpr bool KD_LDS = ONE && T::PG2 && n <= 8;
+#endif
+    static constexpr int KDW = 2 * m * n + m * (m + 1) / 2;
 #ifdef GUSTO_NO_PHICL_LDS
     static constexpr bool PHICL_LDS = false;
 #else
-    static constexpr bool PHICL_LDS = n <= 8;
+    static constexpr bool PHICL_LDS = n <= 8 && !(T::PG2 && n <= 8);
 #endif
 };
 struct LdsLayout {
     int total;
-    int phicl;  // offset of the LDS copy of Phicl (doubles), -1 if it lives in the global workspace
+    int phicl;  // offset of the LDS copy of Phicl -- or of K | D | S^-1, LdsC::KD_LDS -- (doubles), -1 if in the global workspace
 };
 template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     using C1 = LdsC<MODEL, true>;
@@ -203,7 +213,8 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     LdsLayout L;
     L.total = (N <= 64 ? C1::vecs : CM::vecs) + N * (C1::NVN * C1::n + C1::NVM * C1::m);
     L.phicl = -1;
-    if (C1::PHICL_LDS && N <= 64) { L.phicl = L.total; L.total += N * C1::n * C1::n; }
+    if (C1::KD_LDS && N <= 64) { L.phicl = L.total; L.total += N * C1::KDW; }
+    else if (C1::PHICL_LDS && N <= 64) { L.phicl = L.total; L.total += N * C1::n * C1::n; }
     return L;
 }
 

@@ -63,6 +63,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     GPtr<double> Xp, rd, qrd, dXs, Up, qu, dv, dUs;
     // global workspace of this problem
     GPtr<double> rowstate, obs_nh, obs_c0, PG, QQ, Paft, Piaft, KD, Phicl;
+    LPtr<double> kdl;   // K | D | S^-1 (upper triangle) per knot in LDS, stride C::KDW (LdsC::KD_LDS)
     GPtr<uint64_t> obs_mask;
     GPtr<const double> x_init, goal_lo, goal_hi;
     unsigned goalmask;  // bit i: coordinate i of x_N has a point goal (goal_lo == goal_hi)
@@ -81,6 +82,16 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         Xw = v; dY = v + N * n; pv = v + 2 * N * n; cv = v + 3 * N * n; rv = v + 4 * N * n; nu = v + 5 * N * n;
         nun = v + 6 * N * n;
         Uw = v + C::NVN * N * n;
+        if constexpr (C::KD_LDS) kdl = lds + P.ll.phicl;
+    }
+    // entry e of the K | D block of knot k (e = i n + j of K, m n + i n + j of D) and S_k^-1[i][l]
+    GD double kd(int k, int e) const {
+        if constexpr (C::KD_LDS) return kdl[k * C::KDW + e];
+        else return KD[(size_t)k * R::SKD + e];
+    }
+    GD double kdS(int k, int i, int l) const {
+        if constexpr (C::KD_LDS) return kdl[k * C::KDW + 2 * m * n + sidx(i, l, m)];
+        else return KD[(size_t)k * R::SKD + R::oS + i * m + l];
     }
 
     GD void rebind_global() {   // (see rebind_lds)
@@ -585,6 +596,7 @@ template <int MODEL> struct SweepView {
     using R = Rec<MODEL>;
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr bool ONE = true;
+    static constexpr int MODEL_ID = MODEL;
     static constexpr int SPH = C::PHICL_LDS ? n * n : R::SNN;   // stride of Phicl records (LDS copy is unpadded)
     double* lds;
     LPtr<double> sP, sPi, sPG, sT, sHh, sZ, sK, sD, sW, sV, sGd;
@@ -592,6 +604,7 @@ template <int MODEL> struct SweepView {
     LPtr<double> cv, rv, nun, pv, dY;
     GPtr<double> PG, QQ, Paft, Piaft, KD;
     std::conditional_t<C::PHICL_LDS, LPtr<double>, GPtr<double>> Phicl;
+    LPtr<double> kdl;   // K | D | S^-1 per knot in LDS (LdsC::KD_LDS; Phicl is then rebuilt from K by the sweeps)
     const gusto_model_params* mpp;
     struct PW { const gusto_model_params& mp; } ;
     int tid, N;
@@ -610,6 +623,7 @@ template <int MODEL> struct SweepView {
         dY = v + N * n; pv = v + 2 * N * n; cv = v + 3 * N * n; rv = v + 4 * N * n; nun = v + 6 * N * n;
         // (one-wave problems of the small models: Phicl lives in LDS, stride n*n; otherwise padded global records)
         if constexpr (C::PHICL_LDS) Phicl = lds + phicl_off;
+        if constexpr (C::KD_LDS) kdl = lds + phicl_off;
     }
     GD void rebind_global() {
         PG = al16((double*)PG); QQ = al16((double*)QQ); Paft = al16((double*)Paft); Piaft = al16((double*)Piaft); KD = al16((double*)KD);
@@ -1090,7 +1104,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 // padded stage records (Rec<MODEL>): every lane stores, idle lanes land in the padding; record -1 of
                 // Paft/Piaft exists for k == 0
                 if constexpr (C::PHICL_LDS) { if (on) K.Phicl[k * K.SPH + e2] = ph; }
-                else K.Phicl[(size_t)k * R::SNN + e2] = ph;
+                else if constexpr (!C::KD_LDS) K.Phicl[(size_t)k * R::SNN + e2] = ph;   // (KD_LDS: rebuilt from K by the sweeps)
                 K.Paft[(size_t)(k - 1) * R::SNN + e2] = pn;
                 K.Piaft[(size_t)(k - 1) * R::SNN + e2] = pin;
                 // lanes of rows 0..m-1 hold K[i][j], rows m..2m-1 hold D[i-m][j]  (n >= 2m for every model): entry
@@ -1121,7 +1135,8 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                         for (int r = 0; r < RKD; r++) {   // (registers whose 64 entries miss [oS, oS + m^2): nothing to do)
                             if (64 * r + 63 < R::oS || 64 * r >= R::oS + m * m) continue;
                             const int e = tid + 64 * r - R::oS;
-                            sv[r] = (e == a * m + c || e == c * m + a) ? s : sv[r];
+                            if constexpr (C::KD_LDS) sv[r] = (e == sidx(c, a, m)) ? s : sv[r];   // (upper triangle only)
+                            else sv[r] = (e == a * m + c || e == c * m + a) ? s : sv[r];
                         }
                     }
                 // the K|D|S^-1 record: entries [0, 2mn) come from the (i, j) lanes above, [2mn, 2mn + m^2) are S^-1
@@ -1130,7 +1145,8 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                     const int e = tid + 64 * r;
                     double v = (r < RN) ? kdv[r < RN ? r : 0] : 0.0;
                     if (64 * r + 63 >= R::oS && 64 * r < R::oS + m * m) { if (e >= R::oS) v = sv[r]; }
-                    K.KD[(size_t)k * R::SKD + e] = v;
+                    if constexpr (C::KD_LDS) { if (e < C::KDW) K.kdl[k * C::KDW + e] = v; }
+                    else K.KD[(size_t)k * R::SKD + e] = v;
                 }
             }
         }
@@ -1362,14 +1378,43 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
     using R = typename BLK::R;
     const int tid = K.tid, N = K.N;
     const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
+    // (KD_LDS) the entries of Gam and Phi of the double integrator, formed as linearize() forms them
+    double gl[n];
+    auto phi_e = [&](int r_, int c_) { return (r_ == c_) ? 1.0 : ((c_ == r_ + n / 2) ? K.dt : 0.0); };
+    if constexpr (BLK::C::KD_LDS) {
+        constexpr int m = BLK::m;
+        double Bd[n * m];
+        Dyn<BLK::MODEL_ID>::B(*K.mpp, Bd);
+        const double h = 0.5 * K.dt;
+#pragma unroll
+        for (int l = 0; l < n; l++) {
+            const int c_ = l % m;
+            const double hb = h * Bd[(c_ + n / 2) * m + c_];
+            gl[l] = (l < n / 2) ? 2.0 * (h * hb) : 2.0 * hb;
+        }
+    }
+    double phc[n];   // column i of Phi
+#pragma unroll
+    for (int l = 0; l < n; l++) phc[l] = phi_e(l, i);
     double col[n], coln[n], qv, qvn = 0, pval;
     auto fetch = [&](int k0, double* c, double& q) {
         // (clamped, unconditional loads: a group past the end of the sweep never has its step executed -- the steps are
         // guarded wave-uniformly below -- so its operands only need to be loadable.  As `ok ? load : 0` every load sat
         // in a branch of its own.)
         const int kk = (k0 - g >= 1) ? k0 - g : 1;
+        if constexpr (BLK::C::KD_LDS) {
+            // column i of Phicl = Phi - Gam K from the LDS copy of K: Gam has ONE entry per row (row l: column l mod m),
+            // Phi = I + dt [0 I; 0 0]; the fma of the factor sweep (which formed Phi - Gam K with the zero terms too)
+            constexpr int m = BLK::m;
+            double kc[m];
 #pragma unroll
-        for (int l = 0; l < n; l++) c[l] = K.Phicl[(size_t)kk * BLK::SPH + l * n + i];
+            for (int a = 0; a < m; a++) kc[a] = K.kdl[kk * BLK::C::KDW + a * n + i];
+#pragma unroll
+            for (int l = 0; l < n; l++) c[l] = phc[l] - gl[l] * kc[l % m];
+        } else {
+#pragma unroll
+            for (int l = 0; l < n; l++) c[l] = K.Phicl[(size_t)kk * BLK::SPH + l * n + i];
+        }
         q = K.pv[kk * n + i];
     };
     fetch(N - 1, col, qv);
@@ -1421,11 +1466,36 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
     using R = typename BLK::R;
     const int tid = K.tid, N = K.N;
     const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
+    double gi = 0.0;
+    auto phi_e = [&](int r_, int c_) { return (r_ == c_) ? 1.0 : ((c_ == r_ + n / 2) ? K.dt : 0.0); };
+    if constexpr (BLK::C::KD_LDS) {
+        constexpr int m = BLK::m;
+        double Bd[n * m];
+        Dyn<BLK::MODEL_ID>::B(*K.mpp, Bd);
+        const double h = 0.5 * K.dt;
+#pragma unroll
+        for (int l = 0; l < n; l++) {   // Gam[i][i mod m] of this lane's row
+            const int c_ = l % m;
+            const double hb = h * Bd[(c_ + n / 2) * m + c_];
+            const double gv = (l < n / 2) ? 2.0 * (h * hb) : 2.0 * hb;
+            gi = (i == l) ? gv : gi;
+        }
+    }
+    double phr[n];   // row i of Phi
+#pragma unroll
+    for (int l = 0; l < n; l++) phr[l] = phi_e(i, l);
     double row[n], rown[n], cv, cvn = 0, yval = 0.0;
     auto fetch = [&](int k0, double* r, double& c) {
         const int kk = (k0 + g < N) ? k0 + g : N - 1;   // (clamped, see backward_sweep_1w)
+        if constexpr (BLK::C::KD_LDS) {   // row i of Phicl = Phi - Gam K (see backward_sweep_1w)
+            constexpr int m = BLK::m;
+            const int ic = (i < m) ? i : i - m;
 #pragma unroll
-        for (int l = 0; l < n; l++) r[l] = K.Phicl[(size_t)kk * BLK::SPH + i * n + l];
+            for (int l = 0; l < n; l++) r[l] = phr[l] - gi * K.kdl[kk * BLK::C::KDW + ic * n + l];
+        } else {
+#pragma unroll
+            for (int l = 0; l < n; l++) r[l] = K.Phicl[(size_t)kk * BLK::SPH + i * n + l];
+        }
         c = K.dY[kk * n + i];
     };
     fetch(0, row, cv);
@@ -1596,7 +1666,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         for (int i = 0; i < m; i++) {
             double s = 0;
 #pragma unroll
-            for (int l = 0; l < m; l++) s += K.KD[(size_t)k * R::SKD + R::oS + i * m + l] * lu[l];
+            for (int l = 0; l < m; l++) s += K.kdS(k, i, l) * lu[l];
             d0[i] = s;
         }
         // theta_j = sum_k Pi_k^T c_k - D_k^T lu_k  (+ C M rd_{N-1} - rg at the last knot)
@@ -1627,7 +1697,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
 #pragma unroll
         for (int i = 0; i < m; i++)
 #pragma unroll
-            for (int j = 0; j < n; j++) thd[j] -= K.KD[(size_t)k * R::SKD + R::oD + i * n + j] * lu[i];
+            for (int j = 0; j < n; j++) thd[j] -= K.kd(k, R::oD + i * n + j) * lu[i];
 #pragma unroll
         for (int j = 0; j < n; j++) {
             double s = thd[j];
@@ -1664,7 +1734,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         for (int i = 0; i < m; i++) {
             double s = d0[i];
 #pragma unroll
-            for (int j = 0; j < n; j++) s += K.KD[(size_t)k * R::SKD + R::oD + i * n + j] * mugn[j];
+            for (int j = 0; j < n; j++) s += K.kd(k, R::oD + i * n + j) * mugn[j];
             dk[i] = s;
             K.dv[k * m + i] = s;
         }
@@ -1725,7 +1795,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         for (int i = 0; i < m; i++) {
             double s = -K.dv[k * m + i];
 #pragma unroll
-            for (int l = 0; l < n; l++) s -= K.KD[(size_t)k * R::SKD + R::oK + i * n + l] * dyp[l];
+            for (int l = 0; l < n; l++) s -= K.kd(k, R::oK + i * n + l) * dyp[l];
             dus[i] = s;
             K.dUs[k * m + i] = s;
         }
@@ -2189,7 +2259,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
 #pragma unroll
                     for (int l = 0; l < m; l++)
 #pragma unroll
-                        for (int i = 0; i < n; i++) qt[i] -= K.KD[(size_t)k * R::SKD + R::oK + l * n + i] * quk[l];
+                        for (int i = 0; i < n; i++) qt[i] -= K.kd(k, R::oK + l * n + i) * quk[l];
 #pragma unroll
                     for (int i = 0; i < n; i++) K.pv[k * n + i] = qt[i] + (k >= 1 ? K.rv[(k - 1) * n + i] : 0.0);   // qq_k = qt_k + r_{k-1}
                 }
