@@ -23,7 +23,8 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY" \
            "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA" \
-           "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" "GRBM_GUI_ACTIVE"; do
+           "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" "GRBM_GUI_ACTIVE" \
+           "VmemLatency" "LdsLatency" "InstrFetchLatency" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_TC_INST_REQ" "SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_IFETCH"; do
   name=$(echo $set | tr ' ' '+' | cut -c1-40)
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/sq -o "$name" -- python tools/pmc_probe.py > "$OUT/sq_$name.log" 2>&1
 done
