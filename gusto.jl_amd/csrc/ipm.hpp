@@ -1112,15 +1112,44 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 static_assert(n >= 2 * m, "K/D store mapping");
                 // register r of a lane holds entry e = tid + 64 r, i.e. row i = e / n in [64 r / n, (64 r + 63) / n]: rows
                 // outside that range are pruned at compile time (and with them the back-substitutions that feed them)
-                const int ilo = (64 * r) / n, ihi = ((64 * r + 63 < NN - 1) ? 64 * r + 63 : NN - 1) / n;
-                double kd = 0.0;
+                if constexpr (C::KD_LDS) {
+                    // LDS copy of K | D: every lane of column j holds all of K[:, j] and D[:, j]; the lanes of row 0 (entry
+                    // e2 = j) write them -- six ds_write under one lane mask instead of a select chain per record entry
+                    static_assert(RN == 1, "one register of (i, j) entries");
+                    if (e2 < n) {
 #pragma unroll
-                for (int a = 0; a < m; a++) if (a >= ilo && a <= ihi) kd = (i == a) ? kj[a] : kd;
+                        for (int a = 0; a < m; a++) {
+                            K.kdl[k * C::KDW + a * n + e2] = kj[a];
+                            K.kdl[k * C::KDW + m * n + a * n + e2] = dj[a];
+                        }
+                    }
+                    kdv[r] = 0.0;
+                } else {
+                    const int ilo = (64 * r) / n, ihi = ((64 * r + 63 < NN - 1) ? 64 * r + 63 : NN - 1) / n;
+                    double kd = 0.0;
 #pragma unroll
-                for (int a = 0; a < m; a++) if (m + a >= ilo && m + a <= ihi) kd = (i == m + a) ? dj[a] : kd;
-                kdv[r] = kd;
+                    for (int a = 0; a < m; a++) if (a >= ilo && a <= ihi) kd = (i == a) ? kj[a] : kd;
+#pragma unroll
+                    for (int a = 0; a < m; a++) if (m + a >= ilo && m + a <= ihi) kd = (i == m + a) ? dj[a] : kd;
+                    kdv[r] = kd;
+                }
             }
-            {   // S^-1 = L^-T L^-1 (feed-forward only): computed wave-uniformly, the lane of record entry oS + e keeps entry e
+            if constexpr (C::KD_LDS) {   // S^-1 = L^-T L^-1, upper triangle: wave-uniform values, lane 0 writes them
+                double sp[m * (m + 1) / 2];
+#pragma unroll
+                for (int a = 0; a < m; a++)
+#pragma unroll
+                    for (int c = 0; c <= a; c++) {
+                        double s = 0;
+#pragma unroll
+                        for (int l = a; l < m; l++) s += Li[l * m + a] * Li[l * m + c];
+                        sp[sidx(c, a, m)] = s;
+                    }
+                if (tid == 0) {
+#pragma unroll
+                    for (int e = 0; e < m * (m + 1) / 2; e++) K.kdl[k * C::KDW + 2 * m * n + e] = sp[e];
+                }
+            } else {   // S^-1 = L^-T L^-1 (feed-forward only): computed wave-uniformly, the lane of record entry oS + e keeps entry e
                 double sv[RKD];
 #pragma unroll
                 for (int r = 0; r < RKD; r++) sv[r] = 0;
@@ -1135,8 +1164,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                         for (int r = 0; r < RKD; r++) {   // (registers whose 64 entries miss [oS, oS + m^2): nothing to do)
                             if (64 * r + 63 < R::oS || 64 * r >= R::oS + m * m) continue;
                             const int e = tid + 64 * r - R::oS;
-                            if constexpr (C::KD_LDS) sv[r] = (e == sidx(c, a, m)) ? s : sv[r];   // (upper triangle only)
-                            else sv[r] = (e == a * m + c || e == c * m + a) ? s : sv[r];
+                            sv[r] = (e == a * m + c || e == c * m + a) ? s : sv[r];
                         }
                     }
                 // the K|D|S^-1 record: entries [0, 2mn) come from the (i, j) lanes above, [2mn, 2mn + m^2) are S^-1
@@ -1145,8 +1173,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                     const int e = tid + 64 * r;
                     double v = (r < RN) ? kdv[r < RN ? r : 0] : 0.0;
                     if (64 * r + 63 >= R::oS && 64 * r < R::oS + m * m) { if (e >= R::oS) v = sv[r]; }
-                    if constexpr (C::KD_LDS) { if (e < C::KDW) K.kdl[k * C::KDW + e] = v; }
-                    else K.KD[(size_t)k * R::SKD + e] = v;
+                    K.KD[(size_t)k * R::SKD + e] = v;
                 }
             }
         }
