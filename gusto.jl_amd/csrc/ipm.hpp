@@ -1438,6 +1438,12 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
             for (int a = 0; a < m; a++) kc[a] = K.kdl[kk * BLK::C::KDW + a * n + i];
 #pragma unroll
             for (int l = 0; l < n; l++) c[l] = phc[l] - gl[l] * kc[l % m];
+        } else if constexpr (n <= 4) {
+            const bool ok = k0 - g >= 1;
+#pragma unroll
+            for (int l = 0; l < n; l++) c[l] = ok ? K.Phicl[(size_t)kk * BLK::SPH + l * n + i] : 0.0;
+            q = ok ? K.pv[kk * n + i] : 0.0;
+            return;
         } else {
 #pragma unroll
             for (int l = 0; l < n; l++) c[l] = K.Phicl[(size_t)kk * BLK::SPH + l * n + i];
@@ -1519,6 +1525,12 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
             const int ic = (i < m) ? i : i - m;
 #pragma unroll
             for (int l = 0; l < n; l++) r[l] = phr[l] - gi * K.kdl[kk * BLK::C::KDW + ic * n + l];
+        } else if constexpr (n <= 4) {
+            const bool ok = k0 + g < N;
+#pragma unroll
+            for (int l = 0; l < n; l++) r[l] = ok ? K.Phicl[(size_t)kk * BLK::SPH + i * n + l] : 0.0;
+            c = ok ? K.dY[kk * n + i] : 0.0;
+            return;
         } else {
 #pragma unroll
             for (int l = 0; l < n; l++) r[l] = K.Phicl[(size_t)kk * BLK::SPH + i * n + l];
