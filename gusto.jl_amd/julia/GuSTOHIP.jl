@@ -137,7 +137,7 @@ function solve_gusto_hip!(SCPS::SCPSolution, SCPP::SCPProblem, solver="hip", max
   nothing
 end
 
-# solve!(SS, SP) on the GPU (src/shooting.jl:4-49; DubinsCar): the handle that holds the SCP state of SP's problem runs the
+# solve!(SS, SP) on the GPU (src/shooting.jl:4-49; DubinsCar and AstrobeeSE3Manifold): the handle that holds the SCP state of SP's problem runs the
 # batched indirect shooting from SP.p0 (= SCPS.dual).  Use it in place of `solve!` inside solve_SCPshooting!
 # (src/traj_opt.jl:28): `ss_sol = solve_shooting_hip!(SS, SP, SCPS)`.
 struct GustoShootOpts; substeps::Cint; max_newton::Cint; ftol::Cdouble; end

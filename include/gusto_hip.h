@@ -151,8 +151,10 @@ int gusto_get_hist_cap(gusto_handle h, int* hist_cap);
 int gusto_set_trust_state(gusto_handle h, const double* Delta, const double* omega);
 
 /* Indirect shooting seeded by the SCP dual: solve!(SS::ShootingSolution, SP::ShootingProblem) (src/shooting.jl:4-49)
- * for every problem of the batch, the refinement step of solve_SCPshooting! (src/traj_opt.jl:4-45).  DubinsCar only
- * (shooting_ode! / get_control, dubins_car.jl:259-280); other models return GUSTO_ERR_ARG.  The reference's ODE and
+ * for every problem of the batch, the refinement step of solve_SCPshooting! (src/traj_opt.jl:4-45).  The two models
+ * that have a shooting ODE in the reference: DubinsCar (shooting_ode! / get_control, dubins_car.jl:259-280) and
+ * AstrobeeSE3Manifold (dynamics_shooting! / shooting_ode! / get_control, astrobee_se3_manifold.jl:831-895, 26 states +
+ * costates); other models return GUSTO_ERR_ARG.  The reference's ODE and
  * nonlinear solvers (DifferentialEquations, NLsolve) are external and absent: the scheme is RK4 with `substeps` steps
  * per knot interval and Newton with a forward-difference Jacobian on F(p0) = x_goal - x(tf; p0), |F|_inf <= ftol.
  * p0: [B][n] host seeds, or NULL = SCPS.dual of every problem (what ShootingProblem(TOP, SCPS) takes, types.jl:219-227). */

@@ -1478,56 +1478,165 @@ static void dubins_shoot_integrate(const go_problem* p, const double* p0, int su
     }
     for (int i = 0; i < 3; i++) xT[i] = z[i];
 }
-/* returns 1 = :Optimal (|F|_inf <= ftol), 0 = :Diverged.  p0 NULL -> SCPS.dual.  X [N][3], U [N] may be NULL. */
+/* AstrobeeSE3Manifold: dynamics_shooting! / shooting_ode! / get_control, astrobee_se3_manifold.jl:831-895 (the row      */
+/* contributions of :897-1006 are commented out in shooting_ode! at HEAD).  z = (r v q w | pr pv pq pw), 26 values;     */
+/* get_control: F = pv / (2 mass), M = Jinv' pw / 2 (J diagonal).                                                      */
+static void manifold_shoot_ctrl(const go_problem* p, const double* z, double* u) {
+    for (int i = 0; i < 3; i++) { u[i] = z[13 + 3 + i] / (2.0 * p->mp.mass); u[3 + i] = z[13 + 10 + i] / p->mp.Jdiag[i] / 2.0; }
+}
+static void manifold_shoot_rhs(const go_problem* p, const double* z, double* dz) {
+    const double *v = z + 3, *w = z + 10, *pr = z + 13, *pq = z + 13 + 6;
+    const double qw = z[6], qx = z[7], qy = z[8], qz = z[9], wx = w[0], wy = w[1], wz = w[2];
+    const double pqw = pq[0], pqx = pq[1], pqy = pq[2], pqz = pq[3];
+    const double Jx = p->mp.Jdiag[0], Jy = p->mp.Jdiag[1], Jz = p->mp.Jdiag[2];
+    double u[6];
+    manifold_shoot_ctrl(p, z, u);
+    for (int i = 0; i < 3; i++) { dz[i] = v[i]; dz[3 + i] = u[i] / p->mp.mass; }
+    dz[6] = 0.5 * (-wx * qx - wy * qy - wz * qz);
+    dz[7] = 0.5 * (wx * qw - wz * qy + wy * qz);
+    dz[8] = 0.5 * (wy * qw + wz * qx - wx * qz);
+    dz[9] = 0.5 * (wz * qw - wy * qx + wx * qy);
+    {   /* Jinv (M - w x J w) */
+        const double Jw[3] = {Jx * wx, Jy * wy, Jz * wz};
+        const double c[3] = {wy * Jw[2] - wz * Jw[1], wz * Jw[0] - wx * Jw[2], wx * Jw[1] - wy * Jw[0]};
+        dz[10] = (u[3] - c[0]) / Jx; dz[11] = (u[4] - c[1]) / Jy; dz[12] = (u[5] - c[2]) / Jz;
+    }
+    dz[13] = 0; dz[14] = 0; dz[15] = 0;
+    for (int i = 0; i < 3; i++) dz[16 + i] = -pr[i];
+    dz[19] = -0.5 * (pqx * wx + pqy * wy + pqz * wz);
+    dz[20] = -0.5 * (-pqw * wx + pqy * wz - pqz * wy);
+    dz[21] = -0.5 * (-pqw * wy - pqx * wz + pqz * wx);
+    dz[22] = -0.5 * (-pqw * wz + pqx * wy - pqy * wx);
+    dz[23] = -0.5 * (-pqw * qx + pqx * qw - pqy * qz + pqz * qy);
+    dz[24] = -0.5 * (-pqw * qy + pqx * qz + pqy * qw - pqz * qx);
+    dz[25] = -0.5 * (-pqw * qz - pqx * qy + pqy * qx + pqz * qw);
+}
+static void manifold_shoot_integrate(const go_problem* p, const double* p0, int substeps, double* xT, double* X, double* U) {
+    const int N = p->N;
+    double z[26], k1[26], k2[26], k3[26], k4[26], w[26];
+    const double h = p->tf / ((N - 1) * (double)substeps);
+    for (int i = 0; i < 13; i++) { z[i] = p->x_init[i]; z[13 + i] = p0[i]; }
+    for (int k = 0; k < N; k++) {
+        if (X) { for (int i = 0; i < 13; i++) X[k * 13 + i] = z[i]; manifold_shoot_ctrl(p, z, U + k * 6); }
+        if (k == N - 1) break;
+        for (int s = 0; s < substeps; s++) {
+            manifold_shoot_rhs(p, z, k1);
+            for (int i = 0; i < 26; i++) w[i] = z[i] + 0.5 * h * k1[i];
+            manifold_shoot_rhs(p, w, k2);
+            for (int i = 0; i < 26; i++) w[i] = z[i] + 0.5 * h * k2[i];
+            manifold_shoot_rhs(p, w, k3);
+            for (int i = 0; i < 26; i++) w[i] = z[i] + h * k3[i];
+            manifold_shoot_rhs(p, w, k4);
+            for (int i = 0; i < 26; i++) z[i] += h / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+        }
+    }
+    for (int i = 0; i < 13; i++) xT[i] = z[i];
+}
+static void shoot_integrate(const go_problem* p, const double* p0, int substeps, double* xT, double* X, double* U) {
+    if (p->model == GO_DUBINS_CAR) dubins_shoot_integrate(p, p0, substeps, xT, X, U);
+    else manifold_shoot_integrate(p, p0, substeps, xT, X, U);
+}
+/* dp = -J^-1 F: Cramer's rule for n = 3 (DubinsCar), Gaussian elimination with partial pivoting otherwise; 0 if singular */
+static int shoot_newton_step(int n, double* J, const double* F, double* dp) {
+    if (n == 3) {
+        const double det = J[0] * (J[4] * J[8] - J[5] * J[7]) - J[1] * (J[3] * J[8] - J[5] * J[6]) + J[2] * (J[3] * J[7] - J[4] * J[6]);
+        if (!(fabs(det) > 1e-300) || !isfinite(det)) return 0;
+        dp[0] = -(F[0] * (J[4] * J[8] - J[5] * J[7]) - J[1] * (F[1] * J[8] - J[5] * F[2]) + J[2] * (F[1] * J[7] - J[4] * F[2])) / det;
+        dp[1] = -(J[0] * (F[1] * J[8] - J[5] * F[2]) - F[0] * (J[3] * J[8] - J[5] * J[6]) + J[2] * (J[3] * F[2] - F[1] * J[6])) / det;
+        dp[2] = -(J[0] * (J[4] * F[2] - F[1] * J[7]) - J[1] * (J[3] * F[2] - F[1] * J[6]) + F[0] * (J[3] * J[7] - J[4] * J[6])) / det;
+        return 1;
+    }
+    /* Gaussian elimination with COMPLETE pivoting, stopped at the numerical rank: pivots below 1e-6 max|J| -- the accuracy
+     * of a forward-difference Jacobian with h = 1e-6 -- are noise.  The costate of the quaternion along q itself does not
+     * move the state (the flow keeps |q|), so dF/dp0 is rank deficient by one; the free component of the step is left
+     * at 0 (NLsolve's trust region bounds it in the reference) instead of being divided by noise. */
+    double r[GO_MAXN], jmax = 0;
+    int perm[GO_MAXN], rank = 0;
+    for (int i = 0; i < n; i++) { r[i] = -F[i]; perm[i] = i; dp[i] = 0.0; }
+    for (int i = 0; i < n * n; i++) jmax = fmax(jmax, fabs(J[i]));
+    if (!(jmax > 0) || !isfinite(jmax)) return 0;
+    for (int c = 0; c < n; c++) {
+        int pi = c, pj = c;
+        double best = -1.0;
+        for (int i = c; i < n; i++)
+            for (int j = c; j < n; j++) {
+                const double a = fabs(J[i * n + j]);
+                if (!(a == a)) return 0;
+                if (a > best) { best = a; pi = i; pj = j; }
+            }
+        if (!(best > 1e-6 * jmax)) break;
+        if (pi != c) {
+            for (int j = 0; j < n; j++) { const double t = J[c * n + j]; J[c * n + j] = J[pi * n + j]; J[pi * n + j] = t; }
+            const double t = r[c]; r[c] = r[pi]; r[pi] = t;
+        }
+        if (pj != c) {
+            for (int i = 0; i < n; i++) { const double t = J[i * n + c]; J[i * n + c] = J[i * n + pj]; J[i * n + pj] = t; }
+            const int t = perm[c]; perm[c] = perm[pj]; perm[pj] = t;
+        }
+        for (int i = c + 1; i < n; i++) {
+            const double f = J[i * n + c] / J[c * n + c];
+            for (int j = c; j < n; j++) J[i * n + j] -= f * J[c * n + j];
+            r[i] -= f * r[c];
+        }
+        rank = c + 1;
+    }
+    if (rank == 0) return 0;
+    double y[GO_MAXN];
+    for (int c = rank - 1; c >= 0; c--) {
+        double sacc = r[c];
+        for (int j = c + 1; j < rank; j++) sacc -= J[c * n + j] * y[j];
+        y[c] = sacc / J[c * n + c];
+    }
+    for (int c = 0; c < rank; c++) dp[perm[c]] = y[c];
+    return 1;
+}
+/* returns 1 = :Optimal (|F|_inf <= ftol), 0 = :Diverged, -1 = the model has no shooting ODE.  p0 NULL -> SCPS.dual.   */
+/* X [N][n], U [N][m] may be NULL.                                                                                      */
 int go_shoot(go_problem* p, const double* p0, int substeps, int max_newton, double ftol, double* p_out, double* X, double* U,
              int* newton_iters, double* resid) {
-    if (p->model != GO_DUBINS_CAR) return -1;
-    double pv[3], xg[3], F[3], xT[3], nf = 0;
-    for (int i = 0; i < 3; i++) {
+    if (p->model != GO_DUBINS_CAR && p->model != GO_ASTROBEE_SE3_MANIFOLD) return -1;
+    const int n = p->n;
+    double pv[GO_MAXN], xg[GO_MAXN], F[GO_MAXN], xT[GO_MAXN], nf = 0;
+    for (int i = 0; i < n; i++) {
         pv[i] = p0 ? p0[i] : p->dual[i];
         const double lo = p->goal_lo[i], hi = p->goal_hi[i];
         xg[i] = (isfinite(lo) && isfinite(hi)) ? 0.5 * (lo + hi) : 0.0;      /* ShootingProblem ctor, types.jl:219-226 */
     }
     int it = 0, ok = 0;
-    dubins_shoot_integrate(p, pv, substeps, xT, NULL, NULL);
-    for (int i = 0; i < 3; i++) { F[i] = xg[i] - xT[i]; nf = fmax(nf, fabs(F[i])); }
+    shoot_integrate(p, pv, substeps, xT, NULL, NULL);
+    for (int i = 0; i < n; i++) { F[i] = xg[i] - xT[i]; nf = (F[i] != F[i] || nf != nf) ? NAN : fmax(nf, fabs(F[i])); }
     for (;; it++) {
         if (!(nf == nf) || !isfinite(nf)) break;
         if (nf <= ftol) { ok = 1; break; }
         if (it >= max_newton) break;
-        double J[9], Fj[3], pj[3];
-        for (int j = 0; j < 3; j++) {
+        double J[GO_MAXN * GO_MAXN], Fj[GO_MAXN], pj[GO_MAXN];
+        for (int j = 0; j < n; j++) {
             const double h = 1e-6 * fmax(1.0, fabs(pv[j]));
-            for (int i = 0; i < 3; i++) pj[i] = pv[i];
+            for (int i = 0; i < n; i++) pj[i] = pv[i];
             pj[j] += h;
-            dubins_shoot_integrate(p, pj, substeps, xT, NULL, NULL);
-            for (int i = 0; i < 3; i++) { Fj[i] = xg[i] - xT[i]; J[i * 3 + j] = (Fj[i] - F[i]) / h; }
+            shoot_integrate(p, pj, substeps, xT, NULL, NULL);
+            for (int i = 0; i < n; i++) { Fj[i] = xg[i] - xT[i]; J[i * n + j] = (Fj[i] - F[i]) / h; }
         }
-        /* dp = -J^-1 F by Cramer's rule */
-        const double det = J[0] * (J[4] * J[8] - J[5] * J[7]) - J[1] * (J[3] * J[8] - J[5] * J[6]) + J[2] * (J[3] * J[7] - J[4] * J[6]);
-        if (!(fabs(det) > 1e-300) || !isfinite(det)) break;
-        double dp[3];
-        dp[0] = -(F[0] * (J[4] * J[8] - J[5] * J[7]) - J[1] * (F[1] * J[8] - J[5] * F[2]) + J[2] * (F[1] * J[7] - J[4] * F[2])) / det;
-        dp[1] = -(J[0] * (F[1] * J[8] - J[5] * F[2]) - F[0] * (J[3] * J[8] - J[5] * J[6]) + J[2] * (J[3] * F[2] - F[1] * J[6])) / det;
-        dp[2] = -(J[0] * (J[4] * F[2] - F[1] * J[7]) - J[1] * (J[3] * F[2] - F[1] * J[6]) + F[0] * (J[3] * J[7] - J[4] * J[6])) / det;
-        double a = 1.0, nn = 0, Fn[3], pn[3];
+        double dp[GO_MAXN];
+        if (!shoot_newton_step(n, J, F, dp)) break;
+        double a = 1.0, nn = 0, Fn[GO_MAXN], pn[GO_MAXN];
         int dec = 0;
         while (a > 1e-4) {
-            for (int i = 0; i < 3; i++) pn[i] = pv[i] + a * dp[i];
-            dubins_shoot_integrate(p, pn, substeps, xT, NULL, NULL);
+            for (int i = 0; i < n; i++) pn[i] = pv[i] + a * dp[i];
+            shoot_integrate(p, pn, substeps, xT, NULL, NULL);
             nn = 0;
-            for (int i = 0; i < 3; i++) { Fn[i] = xg[i] - xT[i]; nn = fmax(nn, fabs(Fn[i])); }
+            for (int i = 0; i < n; i++) { Fn[i] = xg[i] - xT[i]; nn = (Fn[i] != Fn[i] || nn != nn) ? NAN : fmax(nn, fabs(Fn[i])); }
             if (nn < nf) { dec = 1; break; }
             a *= 0.5;
         }
         if (!dec) break;
-        for (int i = 0; i < 3; i++) { pv[i] = pn[i]; F[i] = Fn[i]; }
+        for (int i = 0; i < n; i++) { pv[i] = pn[i]; F[i] = Fn[i]; }
         nf = nn;
     }
     if (newton_iters) *newton_iters = it;
     if (resid) *resid = nf;
-    if (p_out) for (int i = 0; i < 3; i++) p_out[i] = pv[i];
-    if (ok && X) dubins_shoot_integrate(p, pv, substeps, xT, X, U);
+    if (p_out) for (int i = 0; i < n; i++) p_out[i] = pv[i];
+    if (ok && X) shoot_integrate(p, pv, substeps, xT, X, U);
     return ok;
 }
 

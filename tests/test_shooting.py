@@ -1,4 +1,5 @@
-"""Indirect shooting seeded by the SCP dual (src/shooting.jl, src/traj_opt.jl:4-45), DubinsCar.
+"""Indirect shooting seeded by the SCP dual (src/shooting.jl, src/traj_opt.jl:4-45): DubinsCar and
+AstrobeeSE3Manifold, the two models with a shooting ODE in the reference.
 CPU: the oracle's restatement against scipy.  GPU: gusto_shoot against the oracle, and solve_SCPshooting! end to end."""
 import numpy as np
 import pytest
@@ -52,6 +53,64 @@ def test_oracle_shooting_diverges_from_a_useless_seed_and_refuses_other_models()
     assert f.shoot()["status"] == -1
 
 
+def _manifold_ode(mass, J):
+    """independent restatement of dynamics_shooting! + get_control (astrobee_se3_manifold.jl:831-895) for scipy"""
+    J = np.asarray(J, dtype=float)
+
+    def ode(t, z):
+        v, q, w = z[3:6], z[6:10], z[10:13]
+        pr, pv, pq, pw = z[13:16], z[16:19], z[19:23], z[23:26]
+        F, M = pv / (2 * mass), pw / J / 2
+        qw, qx, qy, qz = q
+        wx, wy, wz = w
+        pqw, pqx, pqy, pqz = pq
+        d = np.zeros(26)
+        d[0:3] = v
+        d[3:6] = F / mass
+        d[6] = 0.5 * (-wx * qx - wy * qy - wz * qz)
+        d[7] = 0.5 * (wx * qw - wz * qy + wy * qz)
+        d[8] = 0.5 * (wy * qw + wz * qx - wx * qz)
+        d[9] = 0.5 * (wz * qw - wy * qx + wx * qy)
+        d[10:13] = (M - np.cross(w, J * w)) / J
+        d[16:19] = -pr
+        d[19] = -0.5 * (pqx * wx + pqy * wy + pqz * wz)
+        d[20] = -0.5 * (-pqw * wx + pqy * wz - pqz * wy)
+        d[21] = -0.5 * (-pqw * wy - pqx * wz + pqz * wx)
+        d[22] = -0.5 * (-pqw * wz + pqx * wy - pqy * wx)
+        d[23] = -0.5 * (-pqw * qx + pqx * qw - pqy * qz + pqz * qy)
+        d[24] = -0.5 * (-pqw * qy + pqx * qz + pqy * qw - pqz * qx)
+        d[25] = -0.5 * (-pqw * qz - pqx * qy + pqy * qx + pqz * qw)
+        return d
+    return ode
+
+
+@pytest.mark.parametrize("b", [0, 1, 3])
+def test_oracle_manifold_shooting_against_scipy(b):
+    """The 26-dimensional state + costate ODE: the oracle's RK4 extremal from its converged costate against an adaptive
+    integration (RK45 at 1e-12) of an independent restatement, knot by knot; the boundary condition at shooting.jl's ftol."""
+    from scipy.integrate import solve_ivp
+    N = 50
+    x0, glo, ghi, tf = P.astrobee_manifold_batch(8)
+    bx, sp = P.iss_corner_env(True)
+    o = go.Oracle(go.ASTROBEE_SE3_MANIFOLD, N, boxes=bx, spheres=sp)
+    o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+    r = o.solve(30)
+    s = o.shoot()                                    # shooting.jl:14: ftol = 1e-3, seeded by SCPS.dual
+    assert r["converged"] and s["status"] == 1 and s["newton_iters"] <= 3 and s["resid"] <= 1e-3
+    mass, J = o.mp.mass, list(o.mp.Jdiag)           # gusto_default_params: astrobee_se3_manifold.jl's robot constants
+    sol = solve_ivp(_manifold_ode(mass, J), (0, tf[b]), np.concatenate([x0[b], s["p0"]]), rtol=1e-12, atol=1e-14,
+                    t_eval=np.linspace(0, tf[b], N))
+    assert sol.success
+    assert np.abs(sol.y[:13].T - s["X"]).max() < 1e-6                      # RK4, 4 substeps per knot interval
+    U = np.concatenate([sol.y[16:19] / (2 * mass), sol.y[23:26] / np.asarray(J)[:, None] / 2]).T
+    assert np.abs(U - s["U"]).max() < 1e-7
+    assert np.abs(s["X"][0] - x0[b]).max() == 0 and np.abs(s["X"][-1] - glo[b]).max() <= 1e-3
+    assert abs(np.linalg.norm(s["X"][-1, 6:10]) - 1.0) < 1e-6               # the flow keeps the quaternion on the sphere
+    # the SCP dual (trapezoid rule, obstacle rows) seeds Newton within its basin -- <= 3 steps above -- and no component of
+    # the costate runs away along the unobservable direction p_q || q (the step leaves it untouched)
+    assert np.abs(s["p0"] - r["dual"]).max() < 1.0 * np.abs(r["dual"]).max()
+
+
 @pytest.mark.gpu
 def test_gpu_shooting_matches_the_oracle():
     B = 256
@@ -83,6 +142,32 @@ def test_gpu_shooting_matches_the_oracle():
 
 
 @pytest.mark.gpu
+def test_gpu_manifold_shooting_matches_the_oracle():
+    B, N = 48, 50
+    x0, glo, ghi, tf = P.astrobee_manifold_batch(B)
+    bx, sp = P.iss_corner_env(True)
+    s = g.BatchSolver(g.ASTROBEE_SE3_MANIFOLD, N, B, hist_cap=40, boxes=bx, spheres=sp)
+    s.set_problems(x0, glo, ghi, tf)
+    s.solve(30)
+    duals = s.dual()
+    r = s.shoot()                                    # seeds = SCPS.dual on device
+    o = go.Oracle(go.ASTROBEE_SE3_MANIFOLD, N, boxes=bx, spheres=sp)
+    n_opt = 0
+    for b in range(B):
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        ro = o.shoot(p0=duals[b])
+        assert int(r["status"][b]) == ro["status"], b
+        if ro["status"] == 1:
+            n_opt += 1
+            assert int(r["newton_iters"][b]) == ro["newton_iters"], b
+            # (13 x 13 finite-difference Jacobian, rank deficient along the quaternion norm: see DESIGN.md 7)
+            assert np.abs(r["X"][b] - ro["X"]).max() < 1e-5 and np.abs(r["U"][b] - ro["U"]).max() < 1e-5
+            assert np.abs(r["X"][b, -1] - glo[b]).max() <= 1e-3          # ftol of shooting.jl:14
+            assert r["X"][b].shape == (N, 13) and r["U"][b].shape == (N, 6)
+    assert n_opt > B // 2
+
+
+@pytest.mark.gpu
 def test_solve_SCPshooting_through_the_seam():
     """solve_SCPshooting!(TOS, TOP, solve_gusto_hip!, init_traj_straightline, "hip") (traj_opt.jl:4-45)."""
     H = g.host
@@ -106,3 +191,26 @@ def test_solve_SCPshooting_through_the_seam():
         else:
             assert np.array_equal(TOS.traj.X, SCPS.traj.X)
     assert done >= 2
+
+
+@pytest.mark.gpu
+def test_solve_SCPshooting_manifold_through_the_seam():
+    """The same driver for AstrobeeSE3Manifold in the ISS corner (26-dimensional shooting ODE, 13 x 13 Newton system)."""
+    H = g.host
+    model = H.AstrobeeSE3Manifold()
+    x0, glo, ghi, tf = P.astrobee_manifold_batch(4)
+    for b in (0, 1):
+        gs = H.GoalSet()
+        H.add_goal(gs, H.Goal(H.PointGoal(glo[b]), tf[b], model))
+        TOP = H.TrajectoryOptimizationProblem(H.ProblemDefinition(H.Robot(), model, H.ISSCorner(True), x0[b], gs), 50, tf[b], True)
+        TOS = H.TrajectoryOptimizationSolution(TOP)
+        H.solve_SCPshooting(TOS, TOP, H.solve_gusto_hip, H.init_traj_straightline, "hip", max_iter=30)
+        SS, SCPS = TOS.SS, TOS.SCPS
+        assert len(SS.prob_status) == len(SS.convergence_measure) >= 2 and SS.prob_status[0] == "NA"
+        assert "Optimal" in SS.prob_status          # the SCP dual seeds a converging Newton run
+        assert TOS.traj.X.shape == (13, 50) and TOS.traj.U.shape == (6, 50)
+        assert np.abs(TOS.traj.X[:, 0] - x0[b]).max() < 1e-12 and np.abs(TOS.traj.X[:, -1] - glo[b]).max() <= 1e-3
+        if SS.converged:
+            assert SS.prob_status[-1] == SS.prob_status[-2] == "Optimal" and np.isfinite(SS.J_true[-1])
+        else:
+            assert np.array_equal(TOS.traj.X, SCPS.traj.X)
