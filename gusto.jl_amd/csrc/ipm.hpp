@@ -695,33 +695,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             if (e < NPG) K.sPG[((N - 1) & 1) * NPG + e] = K.PGk(N - 1)[e];
         }
     }
-    // MFMA path (MT::MFMA, the 12/13-state models): the stage cost QQ_k enters as the C operand of the H tiles, so it is
-    // fetched in the accumulator layout of v_mfma_f64_16x16x4_f64 -- lane l, register r holds entry (row (l>>4)+4r,
-    // column l&15) of a 16 x 16 tile -- straight from the packed record (clamped gathers, zero outside the block)
-    constexpr bool MF = T::MFMA;
-    constexpr int KS = (n + 3) / 4;              // K steps of 4 over the state dimension (zero padded)
-    const int mi = tid & 15, mq = tid >> 4;      // tile column / row group of this lane
-    int qoff[MF ? 10 : 1];
-    double qtile[MF ? 10 : 1], qtile_n[MF ? 10 : 1];
-    if constexpr (MF) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = mq + 4 * r;
-            qoff[r] = (row < n && mi < n) ? sidx(row, mi, NZ) : -1;                 // H_yy tile
-            qoff[4 + r] = (row < n && mi < m) ? sidx(row, n + mi, NZ) : -1;         // H_yu tile
-        }
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int row = mq + 4 * r;
-            qoff[8 + r] = (row < m && mi < m) ? sidx(n + row, n + mi, NZ) : -1;     // H_uu tile
-        }
-#pragma unroll
-        for (int e = 0; e < 10; e++) {
-            const double v = K.QQ[(size_t)(N - 1) * R::SQQ + (qoff[e] < 0 ? 0 : qoff[e])];
-            qtile[e] = qoff[e] < 0 ? 0.0 : v;
-        }
-    }
-    v4d huu = {0, 0, 0, 0};                      // H_uu accumulator tile: the S = H_uu broadcast of phase CD reads it
+    static_assert(!T::MFMA, "the matrix-core models run factor_sweep_mfma");
     double qq[RQ], pgn[RT];
 #pragma unroll
     for (int r = 0; r < RQ; r++) { const int e = tid + 64 * r; qq[r] = K.QQ[(size_t)(N - 1) * R::SQQ + e]; }
@@ -749,10 +723,6 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             const double* pg = K.PGk((k > 0) ? k - 1 : 0);
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
-        }
-        if constexpr (MF) {
-#pragma unroll
-            for (int e = 0; e < 10; e++) qtile_n[e] = K.QQ[(size_t)((k > 0) ? k - 1 : 0) * R::SQQ + (qoff[e] < 0 ? 0 : qoff[e])];
         }
         pf.tick(PF_FPRE);
         double hreg[RQ];   // this lane's entries of H, kept for the S = H_uu broadcast of phase CD
@@ -897,73 +867,6 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 for (int l = 0; l < n; l++) s += ra[l] * rb[l];
                 if (tid < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = s;
             }
-        } else if constexpr (MF) {
-            // 12/13-state models: the dense per-knot products on the matrix cores.  With the 16x16x4 f64 tile layout
-            //   A[i][k] -> lane (k & 3) << 4 | i at K step k >> 2,  B[k][j] -> the same lane/step for column j,
-            //   D[row][col] -> lane (row & 3) << 4 | col, register row >> 2,
-            // the accumulator of T = P [Phi Gam] IS the B operand of H = QQ + [Phi Gam]^T T (register s = K step s), and
-            // one load of Phi / Gam / P / Pi per lane and K step feeds every product: 4 KS LDS reads per lane and stage
-            // instead of ~2 n per output entry, and no n x n block ever lives in a lane's registers.
-            double phi[KS], gam[KS], pp[KS], pim[KS];
-#pragma unroll
-            for (int q = 0; q < KS; q++) {
-                const int row = mq + 4 * q;
-                const bool rv = row < n;                 // (padding rows / columns read a valid address and are zeroed)
-                const int rr = rv ? row : 0, cn = (mi < n) ? mi : 0, cm = (mi < m) ? mi : 0;
-                const double a = PGs[rr * NZ + cn], b = PGs[rr * NZ + n + cm], c = K.sP[rr * n + cn], d = K.sPi[rr * n + cn];
-                phi[q] = (rv && mi < n) ? a : 0.0; gam[q] = (rv && mi < m) ? b : 0.0;
-                pp[q] = (rv && mi < n) ? c : 0.0; pim[q] = (rv && mi < n) ? d : 0.0;
-            }
-            v4d tph = {0, 0, 0, 0}, tga = {0, 0, 0, 0};
-#pragma unroll
-            for (int q = 0; q < KS; q++) {               // T_Phi = P Phi, T_Gam = P Gam  (P symmetric: A[i][k] = P[k][i])
-                tph = __builtin_amdgcn_mfma_f64_16x16x4f64(pp[q], phi[q], tph, 0, 0, 0);
-                tga = __builtin_amdgcn_mfma_f64_16x16x4f64(pp[q], gam[q], tga, 0, 0, 0);
-            }
-            v4d hyy = {qtile[0], qtile[1], qtile[2], qtile[3]}, hyu = {qtile[4], qtile[5], qtile[6], qtile[7]};
-            v4d zy = {0, 0, 0, 0}, zu = {0, 0, 0, 0};
-            huu = v4d{qtile[8], qtile[9], 0, 0};
-#pragma unroll
-            for (int q = 0; q < KS; q++) {
-                hyy = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[q], tph[q], hyy, 0, 0, 0);   // Phi^T T_Phi
-                hyu = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[q], tga[q], hyu, 0, 0, 0);   // Phi^T T_Gam
-                huu = __builtin_amdgcn_mfma_f64_16x16x4f64(gam[q], tga[q], huu, 0, 0, 0);   // Gam^T T_Gam
-                zy = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[q], pim[q], zy, 0, 0, 0);     // Phi^T Pi
-                zu = __builtin_amdgcn_mfma_f64_16x16x4f64(gam[q], pim[q], zu, 0, 0, 0);     // Gam^T Pi
-            }
-            if (k == N - 1) {   // + E = [M^T C^T; b^T M^T C^T], M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
-                const bool gg = mi < n && K.is_goal(mi < n ? mi : 0);
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = mq + 4 * r;
-                    if (gg && row < n) zy[r] += 0.5 * (PGs[mi * NZ + row] + ((row == mi) ? 1.0 : 0.0));
-                    if (gg && row < m) zu[r] += 0.5 * PGs[mi * NZ + n + row];
-                }
-            }
-            // one triangle of H_yy / H_uu is kept and mirrored (the tile holds both, equal up to rounding)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = mq + 4 * r;
-                if (row < n && mi < n) {
-                    if (row <= mi) { K.sHh[row * NZ + mi] = hyy[r]; K.sHh[mi * NZ + row] = hyy[r]; }
-                    K.sZ[row * n + mi] = zy[r];
-                }
-                if (row < n && mi < m) { K.sHh[row * NZ + n + mi] = hyu[r]; K.sHh[(n + mi) * NZ + row] = hyu[r]; }
-                if (row < m && mi < m && row <= mi) { K.sHh[(n + row) * NZ + n + mi] = huu[r]; K.sHh[(n + mi) * NZ + n + row] = huu[r]; }
-                if (row < m && mi < n) K.sZ[(n + row) * n + mi] = zu[r];
-            }
-            for (int e = tid; e < 2 * n; e += 64) {   // r_k = P_k c_k and Pi_k^T c_k for the stage-parallel blocks
-                const bool isr = e < n;
-                const int i = isr ? e : e - n;
-                double a[n], bb[n];
-#pragma unroll
-                for (int l = 0; l < n; l++) { a[l] = isr ? K.sP[i * n + l] : K.sPi[l * n + i]; bb[l] = K.cv[k * n + l]; }
-                __builtin_amdgcn_sched_barrier(0);
-                double s2 = 0;
-#pragma unroll
-                for (int l = 0; l < n; l++) s2 += a[l] * bb[l];
-                (isr ? K.rv : K.nun)[k * n + i] = s2;
-            }
         } else {
             // large models: the same two steps, one round of 64 entries at a time (n^2 operands per lane do not fit
             // the register file: the one-step form spilled 5-6 KB per lane and cost n^2 + n FMAs per entry)
@@ -1037,13 +940,8 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             for (int i = 0; i < m; i++)
 #pragma unroll
                 for (int j = 0; j < m; j++) {
-                    if constexpr (MF) {   // H_uu[a][b], a <= b: lane (a & 3) << 4 | b, register a >> 2 of the huu tile
-                        const int a = i < j ? i : j, b = i < j ? j : i;
-                        S[i * m + j] = readlane_f64(huu[a >> 2], ((a & 3) << 4) | b);
-                    } else {
-                        const int e = sidx(n + (i < j ? i : j), n + (i < j ? j : i), NZ);
-                        S[i * m + j] = readlane_f64(hreg[e / 64], e % 64);
-                    }
+                    const int e = sidx(n + (i < j ? i : j), n + (i < j ? j : i), NZ);
+                    S[i * m + j] = readlane_f64(hreg[e / 64], e % 64);
                 }
             // the operands of the solves do not depend on the Cholesky factor: request them first, they land while
             // the (latency-bound, wave-uniform) factorisation runs
@@ -1067,10 +965,6 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             // prefetch and the previous stage's stores (a whole phase old), not a store issued a moment ago
 #pragma unroll
             for (int r = 0; r < RQ; r++) qq[r] = qqn[r];
-            if constexpr (MF) {
-#pragma unroll
-                for (int e = 0; e < 10; e++) qtile[e] = qoff[e] < 0 ? 0.0 : qtile_n[e];
-            }
             __builtin_amdgcn_sched_barrier(0);
             double kdv[RN];
 #pragma unroll
