@@ -735,16 +735,26 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
         if constexpr (T::PG2 && RZ == 1 && RQ == 1) {
             // H[i][j] = QQ + sum_{a,b} PG[ra(i)][i] P[ra(i)][rb(j)] PG[rb(j)][j]: four entries of P per lane, one phase
             const int zc = zJ[0], zg = zG[0], hc = hI[0], hj = hJ[0];
-            const int z0 = T::pg_r0(zc), z1 = T::pg_r1(zc);
-            const int i0 = T::pg_r0(hc), i1 = T::pg_r1(hc), j0 = T::pg_r0(hj), j1 = T::pg_r1(hj);
+            // the second structural row of a column is always h3 = n/2 rows below the first (pg_r1 = pg_r0 + h3), so each
+            // operand pair / quadruple is ONE lane-dependent LDS address plus immediates; r_k = P c reads column ri of the
+            // (exactly symmetric) P, the same access pattern as Pi^T c: one address for both kinds of lane
+            constexpr int h3 = n / 2;
+            static_assert(T::pg_r1(0) == T::pg_r0(0) + h3 && T::pg_r1(n) == T::pg_r0(n) + h3 && T::pg_r1(n - 1) == T::pg_r0(n - 1) + h3, "PG2 row pairs");
+            const int z0 = T::pg_r0(zc), i0 = T::pg_r0(hc), j0 = T::pg_r0(hj);
             const bool isr = tid < n;
             const int ri = isr ? tid : ((tid < 2 * n) ? tid - n : 0);
             double ra[n], rb[n];
-            const double a0 = PGs[i0 * NZ + hc], a1 = PGs[i1 * NZ + hc], b0 = PGs[j0 * NZ + hj], b1 = PGs[j1 * NZ + hj];
-            const double p00 = K.sP[i0 * n + j0], p01 = K.sP[i0 * n + j1], p10 = K.sP[i1 * n + j0], p11 = K.sP[i1 * n + j1];
-            const double zb0 = K.sPi[z0 * n + zg], zb1 = K.sPi[z1 * n + zg], zv0 = PGs[z0 * NZ + zc], zv1 = PGs[z1 * NZ + zc];
+            const double* pa = PGs + i0 * NZ + hc;
+            const double* pb = PGs + j0 * NZ + hj;
+            const double a0 = pa[0], a1 = pa[h3 * NZ], b0 = pb[0], b1 = pb[h3 * NZ];
+            const auto pp = K.sP + (i0 * n + j0);
+            const double p00 = pp[0], p01 = pp[h3], p10 = pp[h3 * n], p11 = pp[h3 * n + h3];
+            const auto pz = K.sPi + (z0 * n + zg);
+            const double* pv2 = PGs + z0 * NZ + zc;
+            const double zb0 = pz[0], zb1 = pz[h3 * n], zv0 = pv2[0], zv1 = pv2[h3 * NZ];
+            const auto pr = (isr ? K.sP : K.sPi) + ri;
 #pragma unroll
-            for (int l = 0; l < n; l++) { ra[l] = *(isr ? K.sP + ri * n + l : K.sPi + l * n + ri); rb[l] = K.cv[k * n + l]; }
+            for (int l = 0; l < n; l++) { ra[l] = pr[l * n]; rb[l] = K.cv[k * n + l]; }
             __builtin_amdgcn_sched_barrier(0);
             {
                 const double h = qq[0] + a0 * (b0 * p00 + b1 * p01) + a1 * (b0 * p10 + b1 * p11);
