@@ -197,6 +197,10 @@ template <int MODEL, bool ONE> struct LdsC {
     static constexpr bool KD_LDS = ONE && T::PG2 && n <= 8;
 #endif
     static constexpr int KDW = 2 * m * n + m * (m + 1) / 2;
+    // ... and the slot of knot k first holds the stage cost QQ_k (NZ (NZ + 1) / 2 doubles): the residual phase writes it
+    // there, factor stage k reads it and then overwrites the slot with K_k | D_k | S_k^-1 -- the factors of the previous
+    // interior point iteration are dead by the time the next residual phase runs.  No QQ record in global memory at all.
+    static constexpr int KDS = (KDW > NZ * (NZ + 1) / 2) ? KDW : NZ * (NZ + 1) / 2;
 #ifdef GUSTO_NO_PHICL_LDS
     static constexpr bool PHICL_LDS = false;
 #else
@@ -213,7 +217,7 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     LdsLayout L;
     L.total = (N <= 64 ? C1::vecs : CM::vecs) + N * (C1::NVN * C1::n + C1::NVM * C1::m);
     L.phicl = -1;
-    if (C1::KD_LDS && N <= 64) { L.phicl = L.total; L.total += N * C1::KDW; }
+    if (C1::KD_LDS && N <= 64) { L.phicl = L.total; L.total += N * C1::KDS; }
     else if (C1::PHICL_LDS && N <= 64) { L.phicl = L.total; L.total += N * C1::n * C1::n; }
     return L;
 }

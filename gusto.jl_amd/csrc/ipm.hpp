@@ -63,7 +63,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     GPtr<double> Xp, rd, qrd, dXs, Up, qu, dv, dUs;
     // global workspace of this problem
     GPtr<double> rowstate, obs_nh, obs_c0, PG, QQ, Paft, Piaft, KD, Phicl;
-    LPtr<double> kdl;   // K | D | S^-1 (upper triangle) per knot in LDS, stride C::KDW (LdsC::KD_LDS)
+    LPtr<double> kdl;   // K | D | S^-1 (upper triangle) per knot in LDS, stride C::KDS (LdsC::KD_LDS); before factor stage k the slot of knot k holds QQ_k
     GPtr<uint64_t> obs_mask;
     GPtr<const double> x_init, goal_lo, goal_hi;
     unsigned goalmask;  // bit i: coordinate i of x_N has a point goal (goal_lo == goal_hi)
@@ -86,11 +86,15 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     }
     // entry e of the K | D block of knot k (e = i n + j of K, m n + i n + j of D) and S_k^-1[i][l]
     GD double kd(int k, int e) const {
-        if constexpr (C::KD_LDS) return kdl[k * C::KDW + e];
+        if constexpr (C::KD_LDS) return kdl[k * C::KDS + e];
         else return KD[(size_t)k * R::SKD + e];
     }
+    GD void qq_put(int k, int e, double v) const {   // entry e of the packed stage cost of knot k
+        if constexpr (C::KD_LDS) kdl[k * C::KDS + e] = v;
+        else QQ[(size_t)k * R::SQQ + e] = v;
+    }
     GD double kdS(int k, int i, int l) const {
-        if constexpr (C::KD_LDS) return kdl[k * C::KDW + 2 * m * n + sidx(i, l, m)];
+        if constexpr (C::KD_LDS) return kdl[k * C::KDS + 2 * m * n + sidx(i, l, m)];
         else return KD[(size_t)k * R::SKD + R::oS + i * m + l];
     }
 
@@ -698,7 +702,11 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
     static_assert(!T::MFMA, "the matrix-core models run factor_sweep_mfma");
     double qq[RQ], pgn[RT];
 #pragma unroll
-    for (int r = 0; r < RQ; r++) { const int e = tid + 64 * r; qq[r] = K.QQ[(size_t)(N - 1) * R::SQQ + e]; }
+    for (int r = 0; r < RQ; r++) {
+        const int e = tid + 64 * r;
+        if constexpr (C::KD_LDS) qq[r] = K.kdl[(N - 1) * C::KDS + (e < NQ ? e : 0)];
+        else qq[r] = K.QQ[(size_t)(N - 1) * R::SQQ + e];
+    }
 #pragma unroll
     for (int r = 0; r < RT; r++) pgn[r] = 0.0;
 #pragma unroll
@@ -717,7 +725,8 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
 #pragma unroll
         for (int r = 0; r < RQ; r++) {   // unconditional (clamped) prefetch: see phase CD
             const int e = tid + 64 * r;
-            qqn[r] = K.QQ[(size_t)((k > 0) ? k - 1 : 0) * R::SQQ + e];   // (padded record: every lane has an entry)
+            if constexpr (C::KD_LDS) qqn[r] = K.kdl[((k > 0) ? k - 1 : 0) * C::KDS + (e < NQ ? e : 0)];   // (slot k-1 still holds QQ_{k-1})
+            else qqn[r] = K.QQ[(size_t)((k > 0) ? k - 1 : 0) * R::SQQ + e];   // (padded record: every lane has an entry)
         }
         if (!T::LTI) {
             const double* pg = K.PGk((k > 0) ? k - 1 : 0);
@@ -1023,8 +1032,8 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                     if (e2 < n) {
 #pragma unroll
                         for (int a = 0; a < m; a++) {
-                            K.kdl[k * C::KDW + a * n + e2] = kj[a];
-                            K.kdl[k * C::KDW + m * n + a * n + e2] = dj[a];
+                            K.kdl[k * C::KDS + a * n + e2] = kj[a];
+                            K.kdl[k * C::KDS + m * n + a * n + e2] = dj[a];
                         }
                     }
                     kdv[r] = 0.0;
@@ -1051,7 +1060,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                     }
                 if (tid == 0) {
 #pragma unroll
-                    for (int e = 0; e < m * (m + 1) / 2; e++) K.kdl[k * C::KDW + 2 * m * n + e] = sp[e];
+                    for (int e = 0; e < m * (m + 1) / 2; e++) K.kdl[k * C::KDS + 2 * m * n + e] = sp[e];
                 }
             } else {   // S^-1 = L^-T L^-1 (feed-forward only): computed wave-uniformly, the lane of record entry oS + e keeps entry e
                 double sv[RKD];
@@ -1339,7 +1348,7 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
             constexpr int m = BLK::m;
             double kc[m];
 #pragma unroll
-            for (int a = 0; a < m; a++) kc[a] = K.kdl[kk * BLK::C::KDW + a * n + i];
+            for (int a = 0; a < m; a++) kc[a] = K.kdl[kk * BLK::C::KDS + a * n + i];
 #pragma unroll
             for (int l = 0; l < n; l++) c[l] = phc[l] - gl[l] * kc[l % m];
         } else if constexpr (n <= 4) {
@@ -1428,7 +1437,7 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
             constexpr int m = BLK::m;
             const int ic = (i < m) ? i : i - m;
 #pragma unroll
-            for (int l = 0; l < n; l++) r[l] = phr[l] - gi * K.kdl[kk * BLK::C::KDW + ic * n + l];
+            for (int l = 0; l < n; l++) r[l] = phr[l] - gi * K.kdl[kk * BLK::C::KDS + ic * n + l];
         } else if constexpr (n <= 4) {
             const bool ok = k0 + g < N;
 #pragma unroll
@@ -1925,7 +1934,6 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
         for (int i = 0; i < m; i++) l_resd = nanmax(l_resd, fabs(rdu[i]));
 
         // (3) QQ = [Qt, Qt b; ., Hu + b^T Qt b], Qt = M^T Hx M (built even on the last trip: cheap)
-        double* qqg = K.QQ + (size_t)k * R::SQQ;
         {   // knot 0 (x_1 is pinned: Qt = 0, only H_u survives) runs the SAME code with M := 0 -- as an else-branch it was
             // NQ + n stores issued for one lane while the other 49 waited
             double Mk[n * n], Qt[NHX], Qb[n * m];
@@ -1971,7 +1979,7 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
                     for (int l = 0; l < n; l++) if (T::Mnz(l, i) && tnz[l]) s += Mk[l * n + i] * tcol[l];
                     if constexpr (LRTR) s += op.trs * gt[i] * gt[j];
                     Qt[sidx(i, j, n)] = s;
-                    qqg[sidx(i, j, NZ)] = s;
+                    K.qq_put(k, sidx(i, j, NZ), s);
                 }
             }
 #pragma unroll
@@ -1982,7 +1990,7 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
 #pragma unroll
                     for (int l = 0; l < n; l++) if (T::Bnz(l, j)) s += Qt[sidx(i, l, n)] * (hdt * Bd[l * m + j]);
                     Qb[i * m + j] = s;
-                    qqg[sidx(i, n + j, NZ)] = s;
+                    K.qq_put(k, sidx(i, n + j, NZ), s);
                 }
 #pragma unroll
             for (int i = 0; i < m; i++)
@@ -1991,7 +1999,7 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
                     double s = Hu[sidx(i, j, m)];
 #pragma unroll
                     for (int l = 0; l < n; l++) if (T::Bnz(l, i)) s += (hdt * Bd[l * m + i]) * Qb[l * m + j];
-                    qqg[sidx(n + i, n + j, NZ)] = s;
+                    K.qq_put(k, sidx(n + i, n + j, NZ), s);
                 }
 #pragma unroll
             for (int i = 0; i < n; i++) {
