@@ -1018,8 +1018,12 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 // Paft/Piaft exists for k == 0
                 if constexpr (C::PHICL_LDS) { if (on) K.Phicl[k * K.SPH + e2] = ph; }
                 else if constexpr (!C::KD_LDS) K.Phicl[(size_t)k * R::SNN + e2] = ph;   // (KD_LDS: rebuilt from K by the sweeps)
-                K.Paft[(size_t)(k - 1) * R::SNN + e2] = pn;
-                K.Piaft[(size_t)(k - 1) * R::SNN + e2] = pin;
+                // (idle lanes all aim at ONE padding slot, the entry after the matrix: the stores stay unconditional, but the
+                // record dirties 10 sectors of 32 B in the L2 instead of 16)
+                static_assert(R::SNN > NN, "padding slot");
+                const int eo = on ? e2 : NN;
+                K.Paft[(size_t)(k - 1) * R::SNN + eo] = pn;
+                K.Piaft[(size_t)(k - 1) * R::SNN + eo] = pin;
                 // lanes of rows 0..m-1 hold K[i][j], rows m..2m-1 hold D[i-m][j]  (n >= 2m for every model): entry
                 // i*n + j of the K|D|S^-1 record
                 static_assert(n >= 2 * m, "K/D store mapping");
