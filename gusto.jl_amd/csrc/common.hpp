@@ -158,7 +158,7 @@ template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     L.Piaft = take((size_t)(N + 1) * R::SNN) + R::SNN;
     L.KD = take((size_t)N * R::SKD);
     L.Phicl = take((size_t)N * R::SNN);
-    L.pvt = take((size_t)N * (3 * n + 3 * m));
+    L.pvt = take((size_t)N * (5 * n + 5 * m));   // rd qrd dXs | dUs qu dv | gAx gBx gAu gBu (corrector row sums)
     L.total = o;
     return L;
 }

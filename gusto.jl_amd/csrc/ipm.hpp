@@ -60,7 +60,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     // LDS per-knot vectors
     LPtr<double> Xw, dY, pv, cv, rv, nu, nun, Uw;
     // knot-private vectors and the linearisation point (global)
-    GPtr<double> Xp, rd, qrd, dXs, Up, qu, dv, dUs;
+    GPtr<double> Xp, rd, qrd, dXs, Up, qu, dv, dUs, gAx, gBx, gAu, gBu;
     // global workspace of this problem
     GPtr<double> rowstate, obs_nh, obs_c0, PG, QQ, Paft, Piaft, KD, Phicl;
     LPtr<double> kdl;   // K | D | S^-1 (upper triangle) per knot in LDS, stride C::KDS (LdsC::KD_LDS); before factor stage k the slot of knot k holds QQ_k
@@ -117,6 +117,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         {   // knot-private vectors in the global workspace, the linearisation point = the stored trajectory
             double* q = w + W.pvt;
             rd = q; qrd = q + N * n; dXs = q + 2 * N * n; dUs = q + 3 * N * n; qu = dUs + N * m; dv = qu + N * m;
+            gAx = dv + N * m; gBx = gAx + N * n; gAu = gBx + N * n; gBu = gAu + N * m;
             Xp = P.X + (size_t)b * N * n; Up = P.U + (size_t)b * N * m;
         }
         x_init = P.x_init + (size_t)b * n; goal_lo = P.goal_lo + (size_t)b * n; goal_hi = P.goal_hi + (size_t)b * n;
@@ -1792,9 +1793,20 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         for (int i = 0; i < n; i++) xs[i] = K.Xw[k * n + i];
 #pragma unroll
         for (int i = 0; i < m; i++) us[i] = K.Uw[k * m + i];
-        OpStep op{rs, dxs, dus, pass, mu_t, tau};
+        double gAx[n], gBx[n], gAu[m], gBu[m];   // (pass 0) row part of the corrector's right-hand side, see OpStep
+#pragma unroll
+        for (int i = 0; i < n; i++) { gAx[i] = 0; gBx[i] = 0; }
+#pragma unroll
+        for (int i = 0; i < m; i++) { gAu[i] = 0; gBu[i] = 0; }
+        OpStep op{rs, dxs, dus, pass, mu_t, tau, gAx, gAu, gBx, gBu};
         visit_rows<MODEL>(ctx, xs, us, op);
         l_amax = op.amax.value(); l_c0 = op.c0; l_c1 = op.c1; l_c2 = op.c2;
+        if (pass == 0) {
+#pragma unroll
+            for (int i = 0; i < n; i++) { K.gAx[k * n + i] = gAx[i]; K.gBx[k * n + i] = gBx[i]; }
+#pragma unroll
+            for (int i = 0; i < m; i++) { K.gAu[k * m + i] = gAu[i]; K.gBu[k * m + i] = gBu[i]; }
+        }
     }
     K.sync();
     if (k == 0 && (pass == 1 || ncomp == 0)) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0
@@ -2179,9 +2191,11 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                     for (int i = 0; i < n; i++) gx[i] = K.dXs[k * n + i];
 #pragma unroll
                     for (int i = 0; i < m; i++) gu[i] += K.dUs[k * m + i];
-                } else {
-                    OpRhs op{rs, gx, gu, pass, mu_t};
-                    visit_rows<MODEL>(ctx, xs, us, op);
+                } else {   // the corrector's row sums were accumulated by the predictor's step pass: coef = A + mu_t B per row
+#pragma unroll
+                    for (int i = 0; i < n; i++) gx[i] = K.gAx[k * n + i] + mu_t * K.gBx[k * n + i];
+#pragma unroll
+                    for (int i = 0; i < m; i++) gu[i] += K.gAu[k * m + i] + mu_t * K.gBu[k * m + i];
                 }
                 pf.tick(PF_F2);
                 if (k >= 1) {

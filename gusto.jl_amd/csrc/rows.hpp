@@ -245,7 +245,8 @@ struct OpInit {
 
 // residuals + condensed Hessian:  H += sigma * grad grad^T + lam * hess,  dual residual += lam * grad.
 // The row update of the previous interior point step (t += alpha dt, ...) is folded into this pass, and so is the
-// row part of the PREDICTOR right-hand side (OpRhs with mu_t = ka = kb = 0 reduces to coef = lam + sigma * g), which
+// row part of the PREDICTOR right-hand side (the coefficient of a row, the predicted new multiplier at dz = 0, reduces to
+// coef = lam + sigma * g for mu_t = ka = kb = 0; the corrector's is accumulated by OpStep), which
 // saves the predictor its own pass over the rows.
 // LRTR: a row over ALL states (the trust region) is not added to H_x; its dyad sigma * grad grad^T and diagonal come back
 // as (trs, trg, trh) and resid_phase applies them to the stage cost in factored form.
@@ -321,43 +322,6 @@ template <int n, int m, int NP, bool LRTR = false> struct OpResidHess {
     }
 };
 
-// right-hand side of the Newton system: g += coef * grad, coef = predicted new multiplier at dz = 0
-struct OpRhs {
-    RowState rs;
-    double *gx, *gu;
-    int pass;
-    double mu_t;
-    ObsPre ob;
-    GD void obs_load(const int* slot) {
-        ob.load(rs, slot, [&](int var) {
-            return var == RS_T || var == RS_LAM || var == RS_S || var == RS_LAMB || (pass && (var == RS_KA || var == RS_KB));
-        });
-    }
-    template <int FX> GD double get(int var, int slot) const {
-        if constexpr (FX >= FX_OBS) return ob.v[var][FX - FX_OBS]; else return rs.at(var, slot);
-    }
-    template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
-        const double t = get<FX>(RS_T, slot), lam = get<FX>(RS_LAM, slot);
-        const double ka = pass ? get<FX>(RS_KA, slot) : 0.0;
-        double coef;
-        if (row_is_hard(kind)) {
-            const double rp = ev.g + t;
-            coef = (mu_t - ka + lam * rp) * rcp_nr(t);
-        } else {
-            const double s = get<FX>(RS_S, slot), lamb = get<FX>(RS_LAMB, slot);
-            const double kb = pass ? get<FX>(RS_KB, slot) : 0.0;
-            const double rp = ev.g - s + t;
-            const double il = rcp_nr(lamb), lol = lam * il;
-            const double D = t + lol * s;
-            const double rho0 = mu_t - t * lam - ka + lam * rp - lol * (mu_t - s * lamb - kb);
-            coef = lam + rho0 * rcp_nr(D);
-        }
-        double* g = ISU ? gu : gx;
-#pragma unroll
-        for (int a = 0; a < CNT; a++) g[I0 + a] += coef * ev.gr[a];
-    }
-};
-
 // fraction-to-boundary ratio test without a division per candidate: the running minimum is kept as a fraction
 // an/ad (ad > 0); tau v / (-dv) < an / ad  <=>  tau v ad < an (-dv)
 struct StepFrac {
@@ -373,11 +337,17 @@ struct StepFrac {
 // row steps (dt, dlam, ds) from the primal step and the fraction-to-boundary step length.  In the predictor pass
 // the complementarity after a step alpha is accumulated as c0 + c1 alpha + c2 alpha^2 (so no second row pass is
 // needed once alpha_aff is known) and the Mehrotra second-order terms are stored.
+// The predictor pass also accumulates the row part of the CORRECTOR's right-hand side.  Its coefficient per row (what
+// a row pass of its own used to evaluate: coef = predicted multiplier at dz = 0 with the second-order terms ka, kb) is
+// affine in the centring parameter, coef = A + mu_t B, and everything A and B need is in registers right here, so the
+// pass leaves gA = sum A grad and gB = sum B grad per knot and the corrector forms gA + mu_t gB once mu_t is known: one
+// row pass (6 row-state reads per row) less per interior point iteration.
 struct OpStep {
     RowState rs;
     const double *dxs, *dus;
     int pass;
     double mu_t, tau;
+    double *gAx, *gAu, *gBx, *gBu;   // (pass 0) corrector row sums of this knot
     StepFrac amax;
     double c0 = 0, c1 = 0, c2 = 0;
     ObsPre ob;
@@ -397,11 +367,14 @@ struct OpStep {
 #pragma unroll
         for (int a = 0; a < CNT; a++) w += ev.gr[a] * dv[I0 + a];
         double dt, dl, ds;
+        double cA = 0, cB = 0;   // (pass 0) corrector coefficient = cA + mu_t cB
         if (row_is_hard(kind)) {
             const double rp = ev.g + t;
+            const double rt = rcp_nr(t);
             dt = -rp - w;
-            dl = (mu_t - t * lam - ka - lam * dt) * rcp_nr(t);
+            dl = (mu_t - t * lam - ka - lam * dt) * rt;
             ds = 0.0;
+            if (pass == 0) { cA = (lam * rp - dt * dl) * rt; cB = rt; }
         } else {
             const double s = get<FX>(RS_S, slot), lamb = get<FX>(RS_LAMB, slot);
             const double kb = pass ? get<FX>(RS_KB, slot) : 0.0;
@@ -409,16 +382,28 @@ struct OpStep {
             const double il = rcp_nr(lamb), lol = lam * il;
             const double D = t + lol * s;
             const double rho0 = mu_t - t * lam - ka + lam * rp - lol * (mu_t - s * lamb - kb);
-            dl = (rho0 + lam * w) * rcp_nr(D);
+            const double rD = rcp_nr(D);
+            dl = (rho0 + lam * w) * rD;
             ds = (mu_t - s * lamb - kb + s * dl) * il;
             dt = -rp - w + ds;
             amax.test(s, ds, tau);
             amax.test(lamb, -dl, tau);
-            if (pass == 0) { c0 += s * lamb; c1 += ds * lamb - s * dl; c2 -= ds * dl; rs.at(RS_KB, slot) = -ds * dl; }
+            if (pass == 0) {
+                c0 += s * lamb; c1 += ds * lamb - s * dl; c2 -= ds * dl; rs.at(RS_KB, slot) = -ds * dl;
+                // with ka = dt dl, kb = -ds dl:  rho0 = mu_t (1 - lol) - t lam - ka + lam rp + lol (s lamb + kb)
+                cA = lam + (lam * rp - t * lam - dt * dl + lol * (s * lamb - ds * dl)) * rD;
+                cB = (1.0 - lol) * rD;
+            }
         }
         amax.test(t, dt, tau);
         amax.test(lam, dl, tau);
-        if (pass == 0) { c0 += t * lam; c1 += dt * lam + t * dl; c2 += dt * dl; rs.at(RS_KA, slot) = dt * dl; }
+        if (pass == 0) {
+            c0 += t * lam; c1 += dt * lam + t * dl; c2 += dt * dl; rs.at(RS_KA, slot) = dt * dl;
+            double* gA = ISU ? gAu : gAx;
+            double* gB = ISU ? gBu : gBx;
+#pragma unroll
+            for (int a = 0; a < CNT; a++) { gA[I0 + a] += cA * ev.gr[a]; gB[I0 + a] += cB * ev.gr[a]; }
+        }
         // (the predictor's steps only feed alpha_aff and the second-order terms: the corrector overwrites them, and a
         //  problem without a corrector pass -- ncomp == 0 -- has no rows)
         if (pass) { rs.at(RS_DT, slot) = dt; rs.at(RS_DL, slot) = dl; rs.at(RS_DS, slot) = ds; }

@@ -193,8 +193,11 @@ def _lockstep_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30, sub_
     erho = np.abs(rd - ro) / np.maximum(np.abs(ro), 1e-300)
     si = same_it[tr_ok]
     # rho is a ratio of sums of SECOND-order linearisation errors (often 1e-5..1e-3 against thresholds rho0, rho1 of
-    # 0.01..1.5): 1e-6 relative plus 1e-8 absolute, i.e. 1e-7 of the smallest threshold it is compared with
-    assert (np.abs(rd - ro)[si] <= 1e-6 * np.abs(ro)[si] + 1e-8).all(), (np.abs(rd - ro)[si].max(), erho[si].max())
+    # 0.01..1.5): 1e-6 relative plus 3e-8 absolute, i.e. 3e-7 of the smallest freeflyer threshold it is compared with.
+    # (Both sides stop their interior point method at the same 1e-8 tolerances but sum the corrector's right-hand side
+    # in different orders -- the device as gA + mu_t gB accumulated in the predictor's row pass, the oracle row by row
+    # with the final coefficient --, so the two optima differ by ~1e-9 and rho by up to 2e-8.)
+    assert (np.abs(rd - ro)[si] <= 1e-6 * np.abs(ro)[si] + 3e-8).all(), (np.abs(rd - ro)[si].max(), erho[si].max())
     assert (np.abs(rd - ro) <= 1e-3 * np.abs(ro) + 1e-6).all(), (np.abs(rd - ro).max(), erho.max())
     worst_rho = float(erho.max()) if len(erho) else 0.0
     return dict(cold_fail=len(cold_fail), same_iters=float(same_it.mean()), trips=T, max_omega=float(omega.max()), ex=float(ex.max()), eu=float(eu.max()), conv=float(ec.max()),
