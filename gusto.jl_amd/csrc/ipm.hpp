@@ -718,6 +718,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             K.Paft[(size_t)(N - 1) * R::SNN + e] = 0.0;   // value function after the last knot
             K.Piaft[(size_t)(N - 1) * R::SNN + e] = 0.0;
         }
+        if constexpr (C::KD_LDS) { if (e < R::SNN) K.Paft[(size_t)(N - 1) * R::SNN + e] = 0.0; }   // (packed P | Pi record)
     }
     K.sync();
     for (int k = N - 1; k >= 0; k--) {
@@ -1022,9 +1023,20 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 // (idle lanes all aim at ONE padding slot, the entry after the matrix: the stores stay unconditional, but the
                 // record dirties 10 sectors of 32 B in the L2 instead of 16)
                 static_assert(R::SNN > NN, "padding slot");
-                const int eo = on ? e2 : NN;
-                K.Paft[(size_t)(k - 1) * R::SNN + eo] = pn;
-                K.Piaft[(size_t)(k - 1) * R::SNN + eo] = pin;
+                if constexpr (C::KD_LDS) {
+                    // one record per knot for both: P is symmetric, its upper triangle (n (n + 1) / 2 entries) and Pi (n^2)
+                    // fit the 64 doubles; the step phase walks one record instead of two
+                    constexpr int NH = n * (n + 1) / 2;
+                    static_assert(NH + NN < R::SNN, "P | Pi record");
+                    const int ep = (on && i <= j) ? sidx(i, j, n) : R::SNN - 1;
+                    const int eq = on ? NH + e2 : R::SNN - 1;
+                    K.Paft[(size_t)(k - 1) * R::SNN + ep] = pn;
+                    K.Paft[(size_t)(k - 1) * R::SNN + eq] = pin;
+                } else {
+                    const int eo = on ? e2 : NN;
+                    K.Paft[(size_t)(k - 1) * R::SNN + eo] = pn;
+                    K.Piaft[(size_t)(k - 1) * R::SNN + eo] = pin;
+                }
                 // lanes of rows 0..m-1 hold K[i][j], rows m..2m-1 hold D[i-m][j]  (n >= 2m for every model): entry
                 // i*n + j of the K|D|S^-1 record
                 static_assert(n >= 2 * m, "K/D store mapping");
@@ -1783,6 +1795,10 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
                 double s = K.pv[k * n + i] - K.rv[k * n + i];
 #pragma unroll
                 for (int l = 0; l < n; l++)
+                    if constexpr (BLK::C::KD_LDS)   // (packed record: upper triangle of P, then Pi; factor_sweep_1w)
+                        s += K.Paft[(size_t)k * R::SNN + sidx(i, l, n)] * K.dY[k * n + l] +
+                             K.Paft[(size_t)k * R::SNN + n * (n + 1) / 2 + i * n + l] * mugn[l];
+                    else
                     s += K.Paft[(size_t)k * R::SNN + i * n + l] * K.dY[k * n + l] +
                          K.Piaft[(size_t)k * R::SNN + i * n + l] * mugn[l];
                 K.nun[(k + 1) * n + i] = s;
