@@ -1814,7 +1814,17 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         for (int i = 0; i < n; i++) { gAx[i] = 0; gBx[i] = 0; }
 #pragma unroll
         for (int i = 0; i < m; i++) { gAu[i] = 0; gBu[i] = 0; }
-        OpStep op{rs, dxs, dus, pass, mu_t, tau, gAx, gAu, gBx, gBu};
+        // (small models: the state of the rows every knot has, in one batch of loads -- row by row, each row's loads wait
+        // behind the stores of the row before it and the pass pays one memory round trip per row)
+        constexpr int NP = (n <= 8) ? T::NFIX + T::NHU : 0;
+        RowPre<NP> pre;
+        if constexpr (NP > 0) {
+            const int slot_u = T::NFIX + K.P.n_obs + 2 * n;
+            pre.load(rs, T::NFIX, slot_u, [&](int var) {
+                return var == RS_T || var == RS_LAM || var == RS_S || var == RS_LAMB || (pass && (var == RS_KA || var == RS_KB));
+            });
+        }
+        OpStep<NP> op{rs, dxs, dus, pass, mu_t, tau, gAx, gAu, gBx, gBu, &pre};
         visit_rows<MODEL>(ctx, xs, us, op);
         l_amax = op.amax.value(); l_c0 = op.c0; l_c1 = op.c1; l_c2 = op.c2;
         if (pass == 0) {

@@ -342,12 +342,13 @@ struct StepFrac {
 // affine in the centring parameter, coef = A + mu_t B, and everything A and B need is in registers right here, so the
 // pass leaves gA = sum A grad and gB = sum B grad per knot and the corrector forms gA + mu_t gB once mu_t is known: one
 // row pass (6 row-state reads per row) less per interior point iteration.
-struct OpStep {
+template <int NP> struct OpStep {
     RowState rs;
     const double *dxs, *dus;
     int pass;
     double mu_t, tau;
     double *gAx, *gAu, *gBx, *gBu;   // (pass 0) corrector row sums of this knot
+    const RowPre<NP>* pre;           // state of the fixed-position rows, fetched in one batch (small models)
     StepFrac amax;
     double c0 = 0, c1 = 0, c2 = 0;
     ObsPre ob;
@@ -357,7 +358,9 @@ struct OpStep {
         });
     }
     template <int FX> GD double get(int var, int slot) const {
-        if constexpr (FX >= FX_OBS) return ob.v[var][FX - FX_OBS]; else return rs.at(var, slot);
+        if constexpr (FX >= FX_OBS) return ob.v[var][FX - FX_OBS];
+        else if constexpr (FX >= 0 && NP > 0) return pre->v[var][FX];
+        else return rs.at(var, slot);
     }
     template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
         const double t = get<FX>(RS_T, slot), lam = get<FX>(RS_LAM, slot);
