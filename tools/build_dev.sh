@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 M=${1:-0}; shift || true
 D=gusto.jl_amd
-F="--offload-arch=gfx950 -O3 -std=c++17 -Iinclude -fPIC -Wno-unused-value -Wno-pass-failed $@"
+F="--offload-arch=gfx950 ${GUSTO_OPT:--O3} -std=c++17 -Iinclude -fPIC -Wno-unused-value -Wno-pass-failed $@"
 mkdir -p $D/build
 cat > $D/build/stub.hip <<EOS
 #include "../csrc/handle.hpp"
