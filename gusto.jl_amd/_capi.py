@@ -25,7 +25,7 @@ SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims",
            "gusto_last_solve_ms", "gusto_get_traj",
            "gusto_get_traj_dev", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_get_hist_cap",
            "gusto_set_trust_state", "gusto_subproblem", "gusto_default_shoot_opts", "gusto_shoot", "gusto_get_shoot",
-           "gusto_dev_get_prof"]
+           "gusto_dev_get_prof", "gusto_dev_launch_info"]
 
 
 class ScpParams(C.Structure):
@@ -110,6 +110,7 @@ def lib():
         L.gusto_model_dims.argtypes = [ci, C.POINTER(ci), C.POINTER(ci)]
         L.gusto_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci]
         L.gusto_destroy.argtypes = [vp]
+        L.gusto_dev_launch_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
         L.gusto_set_params.argtypes = [vp, C.POINTER(ScpParams), C.POINTER(ModelParams)]
         L.gusto_set_ipm_opts.argtypes = [vp, C.POINTER(IpmOpts)]
         L.gusto_set_env.argtypes = [vp, ci, vp, ci, vp]
@@ -290,6 +291,12 @@ class BatchSolver:
         self._chk(self.L.gusto_get_history(self.h, C.byref(hs)), "get_history")
         out.update(cnt)
         return out
+
+    def launch_info(self):
+        """gusto_dev_launch_info: (persistent workgroups, LDS bytes per workgroup, workgroups per CU) of the last launch."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.gusto_dev_launch_info(self.h, C.byref(a), C.byref(b), C.byref(c)), "dev_launch_info")
+        return a.value, b.value, c.value
 
     def shoot(self, p0=None, substeps=4, max_newton=100, ftol=1e-3):
         """gusto_shoot + gusto_get_shoot: indirect shooting of every problem from p0 (default: the SCP duals)."""

@@ -278,6 +278,16 @@ int gusto_dev_get_prof(gusto_handle h, long long* out) {
     return GUSTO_OK;
 }
 
+// development hook: shape of the last launch (persistent workgroups, dynamic LDS per workgroup, workgroups per CU)
+int gusto_dev_launch_info(gusto_handle h, int* slots, int* lds_bytes, int* per_cu) {
+    if (!h) return GUSTO_ERR_ARG;
+    if (h->slots <= 0) { h->err = "gusto_dev_launch_info: nothing launched yet"; return GUSTO_ERR_STATE; }
+    if (slots) *slots = h->slots;
+    if (lds_bytes) *lds_bytes = h->lds_bytes;
+    if (per_cu) *per_cu = h->per_cu;
+    return GUSTO_OK;
+}
+
 int gusto_last_solve_ms(gusto_handle h, double* ms) {
     if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
     if (!h || !ms) return GUSTO_ERR_ARG;

@@ -34,6 +34,7 @@ struct gusto_handle_s {
     size_t order_ints = 0;
     int* d_queue = nullptr;   // work-queue heads, one per launch of a gusto_solve call
     int slots = 0;            // resident workgroups the last launch used (persistent kernel)
+    int lds_bytes = 0, per_cu = 0;   // ... its dynamic LDS per workgroup and workgroups per CU (gusto_dev_launch_info)
     int sched_init[gusto::SQ_WORDS] = {0};   // initial scheduler words of a launch (host side of an async copy)
     bool have_problems = false, have_shoot = false;
     // indirect shooting (shoot.hip): trajectories, converged costates, seeds, residuals, status, Newton iterations

@@ -55,7 +55,7 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     int slots = std::max(1, per_cu) * std::max(1, cus);
     if (const char* e = getenv("GUSTO_DEV_SLOTS")) slots = std::max(1, atoi(e));   // occupancy experiments
     slots = std::min(slots, h->B);
-    h->slots = slots;
+    h->slots = slots; h->lds_bytes = (int)lds; h->per_cu = per_cu;
     {
         const size_t need = P.wl.total * (size_t)slots;
         if (need > h->ws_doubles) {

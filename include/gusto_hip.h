@@ -179,6 +179,10 @@ int gusto_subproblem(gusto_handle h, int B, const double* Xp, const double* Up, 
 /* Development hook (libraries built with -DGUSTO_PROFILE only, otherwise GUSTO_ERR_STATE): per-problem cycle counters of
  * the kernel's phases, [B][32] (tools/gpu_prof.py).  Stands in for SCPS.iter_elapsed_times at a finer grain. */
 int gusto_dev_get_prof(gusto_handle h, long long* out);
+/* Development hook: shape of the last gusto_solve / gusto_subproblem launch -- resident (persistent) workgroups, dynamic
+ * LDS bytes per workgroup, workgroups per CU.  GUSTO_ERR_STATE before the first launch.  (The freeflyerSE2 N = 50 kernel
+ * is tuned to 4 problems per CU: 40 664 B of the 160 KiB; tests/test_gpu_parity.py guards it.) */
+int gusto_dev_launch_info(gusto_handle h, int* slots, int* lds_bytes, int* per_cu);
 
 #ifdef __cplusplus
 }

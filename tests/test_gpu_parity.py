@@ -786,3 +786,21 @@ def test_full_batch_properties_astrobee_manifold():
     # the linearised unit-norm row keeps |q| near 1 along successful trajectories (eps = 0.1 on the penalised row)
     qn = np.linalg.norm(X[st["successful"]][:, :, 6:10], axis=2)
     assert np.abs(qn - 1).max() < 0.2
+
+
+@pytest.mark.gpu
+def test_freeflyer_launch_keeps_four_problems_per_cu():
+    """The bench configuration is tuned to 4 resident problems per CU (one wave per SIMD): 40 664 B of dynamic LDS per
+    problem (vectors + the K | D | S^-1 / stage-cost slots) of the 160 KiB.  A layout change that costs the fourth problem
+    would show up as a 25 % throughput loss long before anything else notices."""
+    g, _ = _mods()
+    P = g.problems
+    B = 2048
+    x0, glo, ghi, tf = P.freeflyer_batch(B)
+    s = g.BatchSolver(g.FREEFLYER_SE2, 50, B, hist_cap=40, boxes=P.freeflyer_env())
+    with pytest.raises(g.GustoError):
+        s.launch_info()                     # nothing launched yet
+    s.set_problems(x0, glo, ghi, tf)
+    s.solve(3)
+    slots, lds, per_cu = s.launch_info()
+    assert per_cu == 4 and lds <= 160 * 1024 // 4 and slots == min(B, slots) and slots % per_cu == 0
