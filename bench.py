@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- converged trajectories/sec of the batched GuSTO SCP hot path (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}] [--scaling {weak,strong}]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one full pass of the hot path over one batch: straight-line initialisation of every problem,
 then gusto_solve (the whole GuSTO loop: linearisation, convex subproblems, trust-region/penalty updates) until
 every problem of the batch has stopped; with N > 1 ranks the step ends with the final gather of every rank's
 trajectories to rank 0 over RCCL, straight from HBM (north_star: "RCCL only for the batch split and final gather").
-Workload = BASELINE.json configs[1]: freeflyerSE2, batch 4096 random initial states, N = 50, fp64, per GPU (weak
-scaling: every rank solves its own 4096 problems; no data-path collective -- the problems are independent).
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Workload (`--config`, numbered as the lines of BASELINE.json `configs`, 1-based; default 2 = configs[1], the
+configuration the metric is quoted on):
+  2  freeflyerSE2 batch=4096 random initial states, N=50
+  3  dubins_car batch=65536, N=30
+  4  astrobeeSE3 batch=8192, N=50, ISS corner obstacle set
+  5  astrobeeSE3manifold batch=2048, N=50
+`--scaling weak` (default): every rank solves its own batch of that size.  `--scaling strong`: the batch of the config
+is split over the ranks in contiguous blocks (host.shard_bounds) -- how BASELINE.json words configs 4 and 5 ("8xMI355X
+batch-sharded").  No data-path collective either way: the problems are independent.
+Inputs are resident in HBM before the timed region (`value`; the PCIe-inclusive rate of SURVEY.md 8(d) is the named
+extra `pcie_inclusive_traj_per_s`).  Rank 0 prints ONE JSON line.
 
 `value` = strictly serial steps (one batch in flight), so that the kernel time behind `roofline` is that of a lone
 solve.  Named extras in the same line: `overlapped_traj_per_s` (consecutive batches on two handles/streams, the
-steady-state serving rate) and `pcie_inclusive_traj_per_s` (gusto_set_problems from host buffers +
-gusto_solve + gusto_get_traj to host, median of 5).
+steady-state serving rate), `pcie_inclusive_traj_per_s`, `yield` (converged / problems) and, for N > 1,
+`gather_ms_per_step` (host-side time of the final gather inside a step).
 """
 import argparse
 import json
@@ -28,14 +37,42 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_KNOTS = 50
-BATCH = 4096
 MAX_ITER = 30
-# algorithmic bytes (restated in DESIGN.md): one KKT solve of freeflyerSE2 N=50 streams
-# 8*N*(nz(nz+1)/2 + n*nz + 2(nz+n)) bytes; one linearisation 8*N*(2(n+m) + n + n^2) bytes
-BYTES_PER_KKT = 8 * N_KNOTS * (9 * 10 // 2 + 6 * 9 + 2 * (9 + 6))       # 51 600
-BYTES_PER_LINEARIZE = 8 * N_KNOTS * (2 * 9 + 6 + 36)                     # 24 000
 HBM_PEAK_GBS = 8000.0
+
+# BASELINE.json configs (1-based line numbers), the oracle sample per usable host core of the cpu_baseline leg
+# (sized for 10-30 s of CPU work) and the workload names
+CONFIGS = {
+    2: dict(model="FREEFLYER_SE2", N=50, B=4096, cpu_per_core=2048,
+            name="freeflyerSE2 batch=4096 random initial states, N=50, fp64 (BASELINE.json configs[1])"),
+    3: dict(model="DUBINS_CAR", N=30, B=65536, cpu_per_core=4096,
+            name="dubins_car batch=65536, N=30, fp64 (BASELINE.json configs[2])"),
+    4: dict(model="ASTROBEE_SE3", N=50, B=8192, cpu_per_core=512,
+            name="astrobeeSE3 batch=8192, N=50, ISS corner obstacle set, fp64 (BASELINE.json configs[3])"),
+    5: dict(model="ASTROBEE_SE3_MANIFOLD", N=50, B=2048, cpu_per_core=192,
+            name="astrobeeSE3manifold batch=2048, N=50, ISS corner obstacle set, fp64 (BASELINE.json configs[4])"),
+}
+
+
+def algorithmic_bytes(n, m, N):
+    """SURVEY.md 8(d), restated in DESIGN.md: one KKT solve streams 8*N*(nz(nz+1)/2 + n*nz + 2(nz+n)) bytes, one
+    linearisation 8*N*(2(n+m) + n + n^2) bytes (freeflyerSE2 N=50: 51 600 and 24 000)."""
+    nz = n + m
+    return 8 * N * (nz * (nz + 1) // 2 + n * nz + 2 * (nz + n)), 8 * N * (2 * (n + m) + n + n * n)
+
+
+def workload(P, g, cfg, B, first):
+    """(model id, boxes, spheres, (x_init, goal_lo, goal_hi, tf)) of `B` problems of config `cfg` starting at `first`."""
+    c = CONFIGS[cfg]
+    model = getattr(g, c["model"])
+    if cfg == 2:
+        return model, P.freeflyer_env(), None, P.freeflyer_batch(B, first)
+    if cfg == 3:
+        return model, None, None, P.dubins_batch(B, first)
+    bx, sp = P.iss_corner_env(True)
+    if cfg == 4:
+        return model, bx, sp, P.astrobee_se3_batch(B, first)
+    return model, bx, sp, P.astrobee_manifold_batch(B, first)
 
 
 def usable_cores():
@@ -50,14 +87,14 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(problems, env, n_sample, threads):
+def cpu_baseline(P, g, cfg, n_sample, threads):
     """The oracle (a C port, NOT the Julia reference) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gusto_oracle as go
-    x0, glo, ghi, tf = problems.freeflyer_batch(n_sample)
+    model, boxes, spheres, (x0, glo, ghi, tf) = workload(P, g, cfg, n_sample, 0)
     go.lib()
     t0 = time.perf_counter()
-    r = go.solve_batch(go.FREEFLYER_SE2, N_KNOTS, env, None, x0, glo, ghi, tf, MAX_ITER, threads)
+    r = go.solve_batch(model, CONFIGS[cfg]["N"], boxes, spheres, x0, glo, ghi, tf, MAX_ITER, threads)
     dt = time.perf_counter() - t0
     return {"value": float(r["converged"].sum() / dt), "unit": "converged trajectories/s", "cores": threads,
             "kind": "port", "sample": f"first {n_sample} problems of the batch, oracle/libgusto_oracle.so "
@@ -67,17 +104,25 @@ def cpu_baseline(problems, env, n_sample, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=160)     # ~10 s of GPU time in the timed region
+    ap.add_argument("--steps", type=int, default=0, help="0 = about 10 s of GPU time for the config (160 for config 2)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--cpu-sample", type=int, default=0, help="0 = 2048 problems per usable host core (about 15-20 s)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs line (1-based)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak: every rank its own batch; strong: the config's batch split over the ranks")
+    ap.add_argument("--batch", type=int, default=0, help="override the config's batch size")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="0 = the config's sample per usable host core (10-30 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and overlapped extras (profiling runs: "
                     "every launch of the kernel is then one serial step, so rocprofv3's average is the step's)")
     ap.add_argument("--overlap", type=int, default=1,
                     help="batches in flight: consecutive steps alternate between this many handles/streams, so the "
                          "slowest problems of one batch overlap the start of the next (1 = strictly serial steps)")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend of a multi-rank run (nccl = RCCL; gloo: ranks sharing one GPU in tests)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if not args.steps:
+        args.steps = {2: 160, 3: 40, 4: 50, 5: 50}[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -85,62 +130,86 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev_ord = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_ord)
+    dev = torch.device("cuda", dev_ord)
     dist = None
     if "WORLD_SIZE" in os.environ:      # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
+    cdev = dev if (dist is None or args.dist_backend == "nccl") else torch.device("cpu")   # where the collectives run
 
     import gusto_jl_amd as g
     P = g.problems
-    env = P.freeflyer_env()
-    B = args.batch
-    # rank r solves problems [r*B, (r+1)*B): independent shards, no exchange step
-    x0, glo, ghi, tf = P.freeflyer_batch(B, first=rank * B)
+    N_KNOTS = cfg["N"]
+    Btot = args.batch or cfg["B"]
+    if args.scaling == "weak":      # rank r solves problems [r*B, (r+1)*B): independent shards, no exchange step
+        first, B = rank * Btot, Btot
+    else:                           # the batch of the config in contiguous blocks over the ranks
+        first, hi = g.host.shard_bounds(Btot, world, rank)
+        B = hi - first
+    if B <= 0:
+        raise SystemExit(f"rank {rank}: empty shard (batch {Btot} over {world} ranks)")
+    model, boxes, spheres, (x0, glo, ghi, tf) = workload(P, g, args.config, B, first)
+    n, m = g.MODEL_DIMS[model]
     D = max(1, args.overlap)
-    solvers = [g.BatchSolver(g.FREEFLYER_SE2, N_KNOTS, B, hist_cap=MAX_ITER + 34, device=local_rank, boxes=env)
-               for _ in range(D)]
+    mk = lambda: g.BatchSolver(model, N_KNOTS, B, hist_cap=MAX_ITER + 34, device=dev_ord, boxes=boxes, spheres=spheres)
+    solvers = [mk() for _ in range(D)]
     solver = solvers[0]
     # inputs resident in HBM before the timed region
-    dev = torch.device("cuda", local_rank)
     d_x0, d_glo, d_ghi, d_tf = (torch.from_numpy(a).to(dev) for a in (x0, glo, ghi, tf))
     torch.cuda.synchronize()
 
-    import ctypes as C
-
     kernel_ms = []
     timed_in_flight = [False] * D
+    gathered, gather_ok, gather_err, gather_s = [0], [True], [None], [0.0]
 
-    gathered, gather_ok, gather_err = [0], [True], [None]
-
-    def collect(j):
+    def collect(j, had_step):
         solvers[j].wait()
-        if dist is not None and gather_ok[0]:   # final gather of this step's trajectories to rank 0, device tensors -> RCCL
-            try:
-                Xd, Ud = solvers[j].traj_dev()
-                out = g.host.gather_batch_results(dict(X=Xd, U=Ud), world, rank)
-                if rank == 0:
-                    gathered[0] = int(out["X"].shape[0])
-            except Exception as e:      # never lose the scaling measurement to the gather: say so in the JSON line instead
+        if dist is not None and had_step:   # final gather of this step's trajectories to rank 0, device tensors -> RCCL
+            tg = time.perf_counter()
+            # every rank takes the same branch: the ranks agree (MIN over ranks) on whether the gather is still on
+            flag = torch.tensor([1 if gather_ok[0] else 0], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
                 gather_ok[0] = False
-                gather_err[0] = f"{type(e).__name__}: {e}"[:200]
-                print(f"[bench] rank {rank}: final gather failed, continuing without it: {gather_err[0]}", file=sys.stderr)
+            else:
+                try:
+                    Xd, Ud = solvers[j].traj_dev()
+                    if cdev.type == "cpu":
+                        Xd, Ud = Xd.cpu().numpy(), Ud.cpu().numpy()
+                    out = g.host.gather_batch_results(dict(X=Xd, U=Ud), world, rank)
+                    if rank == 0:
+                        gathered[0] = int(out["X"].shape[0])
+                except Exception as e:      # say so in the JSON line; the other ranks learn it at the next step's all_reduce
+                    gather_ok[0] = False
+                    gather_err[0] = f"{type(e).__name__}: {e}"[:200]
+                    print(f"[bench] rank {rank}: final gather failed, continuing without it: {gather_err[0]}", file=sys.stderr)
+            if timed_in_flight[j]:
+                gather_s[0] += time.perf_counter() - tg
         if timed_in_flight[j]:
             kernel_ms.append(solvers[j].last_solve_ms())
             timed_in_flight[j] = False
+
+    in_flight = [False] * D
 
     def step(i, timed):
         # one step = straight-line initialisation of the batch + the whole GuSTO solve of every problem in it.
         # Step i runs on handle i % D; re-using a handle first completes the step it still has in flight.
         j = i % D
-        collect(j)
+        collect(j, in_flight[j])
         solvers[j].set_problems_dev(B, d_x0.data_ptr(), d_glo.data_ptr(), d_ghi.data_ptr(), d_tf.data_ptr())
         solvers[j].solve_async(MAX_ITER)
         timed_in_flight[j] = timed
+        in_flight[j] = True
 
     def drain():
         for j in range(D):
-            collect(j)
+            collect(j, in_flight[j])
+            in_flight[j] = False
 
     def barrier():
         torch.cuda.synchronize()
@@ -164,14 +233,14 @@ def main():
     st = solver.status()
     n_conv, n_succ = int(st["converged"].sum()), int(st["successful"].sum())
     scp_iters, ipm_iters = int(st["iterations"].sum()), int(st["ipm_iters"].sum())
-    tot = torch.tensor([float(n_conv), float(n_succ), float(scp_iters), float(ipm_iters)], device=dev,
+    tot = torch.tensor([float(n_conv), float(n_succ), float(scp_iters), float(ipm_iters), float(B)], device=cdev,
                        dtype=torch.float64)
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([elapsed, gather_s[0]], device=cdev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tot = tot.cpu().numpy()
-    elapsed = float(tmax.item())
+    elapsed, gather_total = float(tmax[0].item()), float(tmax[1].item())
 
     # named extras, outside the timed region, rank 0's GPU only:
     # (a) SURVEY.md 8(d): host buffers in, trajectories out (H2D + solve + D2H), median of 5
@@ -186,7 +255,7 @@ def main():
     # (b) two batches in flight on two handles/streams (the tail of one batch overlaps the head of the next)
     overlapped = None
     if D == 1 and dist is None and not args.no_extras:
-        s2 = [solver, g.BatchSolver(g.FREEFLYER_SE2, N_KNOTS, B, hist_cap=MAX_ITER + 34, device=local_rank, boxes=env)]
+        s2 = [solver, mk()]
         K2 = 12
         for i in range(2):
             s2[i].set_problems_dev(B, d_x0.data_ptr(), d_glo.data_ptr(), d_ghi.data_ptr(), d_tf.data_ptr())
@@ -207,8 +276,10 @@ def main():
 
     if rank == 0:
         value = tot[0] * args.steps / elapsed
+        problems = int(tot[4])
         avg_ms = float(np.mean(kernel_ms))
-        alg_bytes = BYTES_PER_KKT * ipm_iters + BYTES_PER_LINEARIZE * scp_iters      # this rank, one launch
+        b_kkt, b_lin = algorithmic_bytes(n, m, N_KNOTS)
+        alg_bytes = b_kkt * ipm_iters + b_lin * scp_iters      # this rank, one launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM traffic of one solve: NOT measured in this run -- PMC counters need their own rocprofv3 --pmc passes
         # (tools/profile_round.sh); the figure is read from the latest committed summary of the same workload
@@ -216,18 +287,18 @@ def main():
         try:
             import glob
             pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-            if pmc and B == BATCH:
+            if pmc and args.config == 2 and B == CONFIGS[2]["B"]:
                 traffic = json.load(open(pmc[-1]))["traffic_bytes_per_launch"]
                 traffic_src = "profiles/" + os.path.basename(pmc[-1]) + " (separate rocprofv3 --pmc passes, not this run)"
         except Exception:
             traffic = None
         out = {
-            "metric": "converged trajectories/sec (batched SCP), freeflyerSE2 N=50",
+            "metric": f"converged trajectories/sec (batched SCP), {cfg['model'].lower()} N={N_KNOTS}, inputs resident in HBM",
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "freeflyerSE2 batch=4096 random initial states per GPU, N=50, fp64 "
-                                   "(BASELINE.json configs[1])", "batch_per_gpu": B, "N": N_KNOTS,
+            "config": {"workload": cfg["name"] + (" per GPU" if args.scaling == "weak" else " split over the ranks"),
+                       "baseline_config": args.config, "batch_total": problems, "batch_rank0": B, "N": N_KNOTS,
                        "max_iter": MAX_ITER, "sharding": "independent problems per rank; final gather of X,U to rank 0 "
                                                          "over RCCL inside every step (N > 1)",
                        "batches_in_flight": D},
@@ -235,22 +306,25 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          # one gusto_solve = ONE launch of the persistent kernel (device-side longest-first scheduler,
                          # gusto_set_schedule); avg_launch_ms from HIP events on the handle's stream
-                         "kernel": "gusto::scp_kernel<0>", "launches_per_solve": 1, "avg_launch_ms": avg_ms,
+                         "kernel": f"gusto::scp_kernel<{model}>", "launches_per_solve": 1, "avg_launch_ms": avg_ms,
                          "kkt_solves_per_launch": ipm_iters, "scp_iters_per_launch": scp_iters,
+                         "bytes_per_kkt_solve": b_kkt, "bytes_per_linearisation": b_lin,
                          # with D > 1 launches overlap, so a launch's duration spans the batches it shares the GPU
                          # with; the job-level rate is the algorithmic bytes of all launches over the timed region
                          "launches_in_flight": D,
                          "aggregate_achieved": alg_bytes * args.steps / elapsed / 1e9},
-            "converged": int(tot[0]), "successful": int(tot[1]), "problems": B * world,
-            "mean_scp_iters": tot[2] / (B * world), "mean_ipm_iters": tot[3] / (B * world),
+            "converged": int(tot[0]), "successful": int(tot[1]), "problems": problems,
+            "yield": float(tot[0]) / max(1, problems),
+            "mean_scp_iters": tot[2] / max(1, problems), "mean_ipm_iters": tot[3] / max(1, problems),
             "pcie_inclusive_traj_per_s": (n_conv / pcie_s) if pcie else None, "pcie_inclusive_note": "SURVEY.md 8(d): set_problems (host) + "
             "solve + get_traj (host), median of 5, one GPU", "overlapped_traj_per_s": overlapped,
             "gathered_problems_per_step": gathered[0] if dist is not None else None, "gather_error": gather_err[0],
+            "gather_ms_per_step": (1e3 * gather_total / args.steps) if dist is not None else None,
         }
         if not args.no_cpu_baseline:
             threads = usable_cores()
-            n_sample = args.cpu_sample or max(4096, 2048 * threads)
-            out["cpu_baseline"] = cpu_baseline(P, env, n_sample, threads)
+            n_sample = args.cpu_sample or cfg["cpu_per_core"] * max(2, threads)
+            out["cpu_baseline"] = cpu_baseline(P, g, args.config, n_sample, threads)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -235,15 +235,19 @@ def _hist_cap(max_iter):
     return max(64, 4 * max_iter + 16)
 
 
-def solve_gusto_hip(SCPS, SCPP, solver="hip", max_iter=30, force=False, device=0, **kwarg):
+def solve_gusto_hip(SCPS, SCPP, solver="hip", max_iter=30, force=False, device=0, hist_cap=None, **kwarg):
     """Same positional signature as solve_gusto_jump! (scp_gusto.jl:49).  Mutates SCPS / SCPP in place; a second
-    call resumes from SCPS (iter_cap = iterations + max_iter, scp_gusto.jl:67)."""
+    call resumes from SCPS (iter_cap = iterations + max_iter, scp_gusto.jl:67).
+
+    `hist_cap` sizes the history vectors of the handle the FIRST call creates: every call consumes one leading
+    J_true / rho entry plus one entry per trip, so a caller that resumes in short calls (solve_SCPshooting: one trip per
+    call) passes the capacity of its whole iteration budget; the default covers a few resumed calls of `max_iter`."""
     model = SCPP.PD.model
     n, N = model.x_dim, SCPP.N
     bs = SCPS._solver
     if bs is None:
         env = SCPP.PD.env
-        bs = BatchSolver(model.model_id, N, 1, hist_cap=_hist_cap(max_iter), device=device, boxes=env.boxes,
+        bs = BatchSolver(model.model_id, N, 1, hist_cap=hist_cap or _hist_cap(max_iter), device=device, boxes=env.boxes,
                          spheres=env.spheres, scp_params=SCPP.scp_params, model_params=SCPP.model_params)
         lo, hi = _goal_bounds(SCPP.PD.goal_set, n, SCPP.tf_guess)
         bs.set_problems(SCPP.PD.x_init[None], lo[None], hi[None], [SCPP.tf_guess],
@@ -332,6 +336,9 @@ def solve_SCPshooting(TOS, TOP, solve_method, init_method, solver="hip", max_ite
     TOS.SCPS = SCPS = SCPSolution(SCPP, traj_init)
     SP = ShootingProblem(TOP, SCPS)
     TOS.SS = SS = ShootingSolution(SP, Trajectory(traj_init.X.copy(), traj_init.U.copy(), traj_init.Tf))
+    # one-trip calls: each consumes two history entries (its leading J_true / rho entry and the trip), so the handle is
+    # sized for the whole budget here -- the reference's vectors grow without bound (scp_gusto.jl:15-19)
+    kwarg.setdefault("hist_cap", _hist_cap(max_iter))
     solve_method(SCPS, SCPP, solver, 1, **kwarg)
     SS.J_true.append(SCPS.J_true[0])
     while not SCPS.converged and SCPS.iterations < max_iter:

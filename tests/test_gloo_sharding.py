@@ -144,3 +144,54 @@ def test_rccl_gathers_the_handles_own_device_buffers():
     on_gpu, okx, oku, okit = q.get(timeout=600)
     p.join(timeout=120)
     assert p.exitcode == 0 and on_gpu and okx and oku and okit
+
+
+def _run_bench(extra, nproc=0, timeout=900):
+    import json
+    import subprocess
+    cmd = [sys.executable]
+    if nproc:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    cmd += [os.path.join(ROOT, "bench.py")] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_runs_config_4_strong_scaling_on_two_ranks():
+    """BASELINE.json configs[3] ("astrobeeSE3 ... batch-sharded") through bench.py itself: the batch is split over two
+    ranks (both on the one GPU of the test box, gloo carrying the collectives), the final gather sits inside every step
+    and rank 0 reports the whole job."""
+    out = _run_bench(["--gpus", "2", "--config", "4", "--scaling", "strong", "--batch", "96", "--steps", "2", "--warmup", "1",
+                      "--no-cpu-baseline", "--no-extras", "--dist-backend", "gloo"], nproc=2)
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["config"]["baseline_config"] == 4
+    assert out["problems"] == 96 and out["config"]["batch_rank0"] == 48
+    assert out["gathered_problems_per_step"] == 96 and out["gather_error"] is None and out["gather_ms_per_step"] > 0
+    assert 0.5 < out["yield"] <= 1.0 and out["value"] > 0
+    assert out["roofline"]["bytes_per_kkt_solve"] == 8 * 50 * (18 * 19 // 2 + 12 * 18 + 2 * (18 + 12))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,n,m,N", [(3, 3, 1, 30), (5, 13, 6, 50)])
+def test_bench_runs_the_other_configs(cfg, n, m, N):
+    out = _run_bench(["--config", str(cfg), "--batch", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
+    nz = n + m
+    assert out["config"]["baseline_config"] == cfg and out["problems"] == 128 and out["scaling"] == "weak"
+    assert out["roofline"]["bytes_per_kkt_solve"] == 8 * N * (nz * (nz + 1) // 2 + n * nz + 2 * (nz + n))
+    assert 0 < out["yield"] <= 1.0 and out["roofline"]["frac"] > 0
+
+
+def test_bench_config_table_matches_baseline_json():
+    """CPU: the config table of bench.py names the batch sizes / horizons BASELINE.json states."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    for i, c in bench.CONFIGS.items():
+        line = base[i - 1]
+        assert f"batch={c['B']}" in line.replace(" ", "").replace("batch=", "batch=") and f"N={c['N']}" in line, (i, line)
+    assert bench.algorithmic_bytes(6, 3, 50) == (51600, 24000)

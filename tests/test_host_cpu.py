@@ -1,6 +1,7 @@
 """Host-side mirror logic that needs no GPU: goal flattening, the reference's free-final-time and goal-timeline
 semantics, shard bounds, trajectory export."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -71,3 +72,48 @@ def test_trajectory_export_round_trip(tmp_path, ext):
     g.export.write(path, g.FREEFLYER_SE2, X[0], U[0], 200.0)
     d = g.export.read(path)
     assert d["traj"]["x_traj"].shape == (6, N) and d["traj"]["t_traj"].shape == (N,) and d["traj"]["t_traj"][-1] == 200.0
+
+
+def _h5_tool(name):
+    import shutil
+    for c in (shutil.which(name), "/opt/conda/bin/" + name):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def test_trajectory_export_hdf5(tmp_path):
+    """The notebook's own container (cell 6, `h5open(...)`): a real HDF5 file, parsed back by the spec-following reader
+    of the suite and -- when libhdf5's command line tools are installed -- by libhdf5 itself."""
+    import subprocess
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import h5read
+    rng = np.random.default_rng(1)
+    N = 50
+    X, U = rng.standard_normal((N, 6)), rng.standard_normal((N, 3))
+    path = os.path.join(tmp_path, "predefined_trajectory_example.h5")
+    g.export.write(path, g.FREEFLYER_SE2, X, U, 200.0)
+    d = h5read.read_h5(path)
+    assert sorted(d) == ["ind_u", "ind_x", "traj"] and sorted(d["traj"]) == ["t_traj", "u_traj", "x_traj"]
+    # HDF5 dimensions (N, x_dim): HDF5.jl (column-major) presents it as the notebook's x_dim x N matrix TOS.traj.X
+    assert d["traj"]["x_traj"].shape == (N, 6) and np.array_equal(d["traj"]["x_traj"], X)
+    assert d["traj"]["u_traj"].shape == (N, 3) and np.array_equal(d["traj"]["u_traj"], U)
+    assert np.allclose(d["traj"]["t_traj"], np.arange(N) * 200.0 / (N - 1)) and d["traj"]["t_traj"].dtype == np.float64
+    assert {k: int(v) for k, v in d["ind_x"].items()} == dict(x=0, y=1, theta=2, vx=3, vy=4, omega=5)
+    assert {k: int(v) for k, v in d["ind_u"].items()} == dict(Fx=0, Fy=1, M=2)
+    # a batch with status vectors, 13 index entries (more than the default 8 of a symbol table node)
+    Xb, Ub = rng.standard_normal((3, N, 13)), rng.standard_normal((3, N, 6))
+    pb = os.path.join(tmp_path, "batch.h5")
+    g.export.write(pb, g.ASTROBEE_SE3_MANIFOLD, Xb, Ub, np.array([40.0, 41.0, 42.0]),
+                   dict(converged=np.array([1, 0, 1]), iterations=np.array([7, 30, 9], dtype=np.int32)))
+    db = h5read.read_h5(pb)
+    assert np.array_equal(db["traj"]["x_traj"], Xb) and len(db["ind_x"]) == 13 and int(db["ind_x"]["wz"]) == 12
+    assert db["status"]["iterations"].dtype == np.int32 and list(db["status"]["converged"]) == [1, 0, 1]
+    tool = _h5_tool("h5dump")
+    if tool:       # libhdf5 reads what h5lite wrote
+        out = subprocess.run([tool, "-d", "/traj/t_traj", "-d", "/ind_x/omega", path], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert "H5T_IEEE_F64LE" in out.stdout and "( 50 ) / ( 50 )" in out.stdout and "H5T_STD_I64LE" in out.stdout
+        assert "(0): 5" in out.stdout
+        ls = subprocess.run([_h5_tool("h5ls"), "-r", pb], capture_output=True, text=True)
+        assert ls.returncode == 0 and "/traj/x_traj Dataset {3, 50, 13}" in " ".join(ls.stdout.split()), ls.stdout
