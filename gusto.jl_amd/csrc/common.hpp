@@ -230,6 +230,7 @@ struct KParams {
     int* lists;         // [SCHED_LEVELS][list_cap] problems waiting for their next slice, by penalty level; entries start
                         // at -1; an entry is (slices so far << 24) | problem
     int list_cap;       // probe_visits * B: a problem is pushed at most once per probing slice
+    const int* order;   // fresh problems are handed out in this order (hardest first, scp.hpp: sched_key_kernel); null = 0, 1, 2, ...
     gusto_scp_params sp;
     gusto_model_params mp;
     gusto_ipm_opts io;
@@ -258,7 +259,8 @@ constexpr int ST_ITER = 0, ST_CONV = 1, ST_SUCC = 2, ST_STOP = 3, ST_IPM = 4, ST
 // workgroups poll and bump them, and two counters in one line serialise each other's atomics in the L2.
 constexpr int SCHED_LEVELS = 16, SQ_STRIDE = 32;
 constexpr int SQ_HEAD_A = 0, SQ_PROBING = SQ_STRIDE /* problems that may still be pushed */, SQ_TAIL = 2 * SQ_STRIDE /* [level] */,
-              SQ_HEAD = (2 + SCHED_LEVELS) * SQ_STRIDE /* [level] */, SQ_WORDS = (2 + 2 * SCHED_LEVELS) * SQ_STRIDE;
+              SQ_HEAD = (2 + SCHED_LEVELS) * SQ_STRIDE /* [level] */, SQ_ERR = (2 + 2 * SCHED_LEVELS) * SQ_STRIDE /* scheduler gave up */,
+              SQ_WORDS = (3 + 2 * SCHED_LEVELS) * SQ_STRIDE;
 constexpr int SD_TOGGLE = 0, SD_DUAL = 2, SD_ND = 2 + GUSTO_MAXN;
 
 // ---- optional phase timers (compile with -DGUSTO_PROFILE) ---------------------------------------------

@@ -132,6 +132,7 @@ int gusto_destroy(gusto_handle h) {
     for (void* p : {(void*)h->d_shX, (void*)h->d_shU, (void*)h->d_shP, (void*)h->d_shP0, (void*)h->d_shRes, (void*)h->d_shSt, (void*)h->d_shIt}) if (p) hipFree(p);
     if (h->d_order) hipFree(h->d_order);
     if (h->d_queue) hipFree(h->d_queue);
+    if (h->d_sched_ord) hipFree(h->d_sched_ord);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);

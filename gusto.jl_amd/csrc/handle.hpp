@@ -33,6 +33,7 @@ struct gusto_handle_s {
     int* d_order = nullptr;   // waiting lists of the scheduler, [SCHED_LEVELS][probe_iters * batch_cap]
     size_t order_ints = 0;
     int* d_queue = nullptr;   // work-queue heads, one per launch of a gusto_solve call
+    int* d_sched_ord = nullptr;   // [2][batch_cap]: difficulty bucket and hand-out order of the fresh problems (hardest first)
     int slots = 0;            // resident workgroups the last launch used (persistent kernel)
     int lds_bytes = 0, per_cu = 0;   // ... its dynamic LDS per workgroup and workgroups per CU (gusto_dev_launch_info)
     int sched_init[gusto::SQ_WORDS] = {0};   // initial scheduler words of a launch (host side of an async copy)
@@ -69,6 +70,15 @@ static inline int gusto_finish(gusto_handle h) {
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_ms = ms;
     h->pending = false;
+    if (h->d_queue) {   // the device-side scheduler reports a problem it lost instead of leaving it half-solved (scp.hpp: sched_pop)
+        int serr = 0;
+        HIPCHK(h, hipMemcpy(&serr, h->d_queue + gusto::SQ_ERR, sizeof(int), hipMemcpyDeviceToHost));
+        if (serr) {
+            h->err = serr == 1 ? "scheduler: a claimed waiting-list entry never arrived (problem lost)"
+                               : "scheduler: workgroups gave up waiting for problems still in their probing slices";
+            return GUSTO_ERR_STATE;
+        }
+    }
     return GUSTO_OK;
 }
 

@@ -37,6 +37,7 @@ template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B) {
 }
 
 template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_iter, int force) {
+    using T = MT<MODEL>;
     KParams P;
     int rc = fill_params<MODEL>(h, P, h->B);
     if (rc) return rc;
@@ -85,11 +86,23 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
         HIPCHK(h, hipMemsetAsync(h->d_order, 0xFF, (size_t)SCHED_LEVELS * P.list_cap * sizeof(int), h->stream));
     }
     P.queue = h->d_queue; P.lists = h->d_order; P.probe_visits = dyn ? probe : 0;
+    P.order = nullptr;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));   // (the solve's time includes the ordering kernels below)
+    if (dyn && T::HAS_OBS && P.n_obs > 0 && !getenv("GUSTO_DEV_NO_ORDER")) {   // hardest first (scp.hpp: sched_key_kernel)
+        if (!h->d_sched_ord) HIPCHK(h, dalloc(&h->d_sched_ord, (size_t)2 * h->batch_cap));
+        int* bucket = h->d_sched_ord;
+        int* order = h->d_sched_ord + h->batch_cap;
+        HIPCHK(h, hipMemsetAsync(bucket, 0, (size_t)h->B * sizeof(int), h->stream));
+        const int tot = h->B * h->N;
+        hipLaunchKernelGGL(sched_key_kernel<MODEL>, dim3((tot + 255) / 256), dim3(256), 0, h->stream, P, bucket);
+        hipLaunchKernelGGL(sched_order_kernel, dim3(1), dim3(1024), 0, h->stream, h->B, bucket, order);
+        HIPCHK(h, hipGetLastError());
+        P.order = order;
+    }
     if (getenv("GUSTO_DEV_DEBUG"))
         fprintf(stderr, "launch: B %d slots %d dyn %d probe %d list_cap %d queue %p lists %p..%p ws %p..%p X %p st_i %p..%p hist Delta %p\n", h->B, slots,
                 (int)dyn, P.probe_visits, P.list_cap, (void*)P.queue, (void*)P.lists, (void*)(P.lists + h->order_ints), (void*)P.ws,
                 (void*)(P.ws + h->ws_doubles), (void*)P.X, (void*)P.st_i, (void*)(P.st_i + (size_t)h->batch_cap * ST_NI), (void*)P.Delta);
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(kern, dim3(slots), dim3(NT), lds, h->stream, P);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));

@@ -247,6 +247,7 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
 constexpr int SCHED_SPIN_LIMIT = 1 << 20;   // (seconds of sleeping polls: a scheduler bug must not hang the GPU)
 // wave-uniform primitives: every lane of the wave executes them, the result is the same scalar in every lane
 GD int uload(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+GD int uload_acq(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)); }
 GD int uadd(int* p, int v) {
     int r = 0;
     if ((threadIdx.x & 63) == 0) r = atomicAdd(p, v);
@@ -265,10 +266,11 @@ GD int ucas(int* p, int expected, int desired) {   // returns the value found (=
 GD int sched_pop(const KParams& P, bool& cont) {
     int* Q = P.queue;
     for (int spin = 0;; spin++) {
-        const int probing_seen = uload(Q + SQ_PROBING);   // BEFORE the scan: a push is published before SQ_PROBING drops
+        // BEFORE the scan, with acquire: a push is published (tail increment, release) before SQ_PROBING drops
+        const int probing_seen = uload_acq(Q + SQ_PROBING);
         if (uload(Q + SQ_HEAD_A) < P.B) {
             const int q = uadd(Q + SQ_HEAD_A, 1);
-            if (q < P.B) { cont = false; return q; }
+            if (q < P.B) { cont = false; return P.order ? uload(P.order + q) : q; }
         }
         for (int L = SCHED_LEVELS - 1; L >= 0; L--) {
             int h = uload(Q + SQ_HEAD + L * SQ_STRIDE);
@@ -278,7 +280,10 @@ GD int sched_pop(const KParams& P, bool& cont) {
                     int e = -1;
                     for (int w = 0; w < SCHED_SPIN_LIMIT && (e = uload(P.lists + (size_t)L * P.list_cap + h)) < 0; w++)
                         __builtin_amdgcn_s_sleep(2);
-                    if (e < 0) return -1;
+                    if (e < 0) {   // a claimed index whose entry never came: the problem is lost -- say so (gusto_finish)
+                        if ((threadIdx.x & 63) == 0) atomicExch(Q + SQ_ERR, 1);
+                        return -1;
+                    }
                     cont = true;
                     return e;
                 }
@@ -288,7 +293,11 @@ GD int sched_pop(const KParams& P, bool& cont) {
         // Nothing to take.  More can only come from problems still in their probing slices; once there are none, this
         // workgroup retires and frees its slot -- the tail of a batch then overlaps the head of the next one enqueued on
         // another stream.
-        if (probing_seen == 0 || spin > SCHED_SPIN_LIMIT) return -1;
+        if (probing_seen == 0) return -1;
+        if (spin > SCHED_SPIN_LIMIT) {   // problems still probing but nothing arrives: a scheduler bug must not hang the GPU, nor pass
+            if ((threadIdx.x & 63) == 0) atomicExch(Q + SQ_ERR, 2);
+            return -1;
+        }
         // idle polling backs off (8 -> 127 x 64 cycles): pollers share the L2 lines the working groups' pushes need
         if (spin < 4) __builtin_amdgcn_s_sleep(8); else if (spin < 16) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(127);
     }
@@ -346,8 +355,56 @@ scp_kernel(const KParams P) {
                                    __HIP_MEMORY_SCOPE_AGENT);                                                        // ... then the entry
             }
             // this was the problem's last probing slice (or it stopped inside one): it will not be pushed again
-            if (trips == 1 && (lvl < 0 || visits + 1 >= P.probe_visits)) atomicSub(P.queue + SQ_PROBING, 1);
+            // (release: the tail increment and the entry above are visible to whoever sees the counter drop)
+            if (trips == 1 && (lvl < 0 || visits + 1 >= P.probe_visits))
+                __hip_atomic_fetch_sub(P.queue + SQ_PROBING, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+
+// ---- hardest first: the order in which fresh problems are handed out ------------------------------------------------
+// The long problems of a batch are those that start deep inside an obstacle (their penalty weight is raised in the first
+// trips and they run to max_iter): of the 64 longest problems of the freeflyer batch, 62 are among the 1024 with the
+// largest penetration of the initial trajectory.  Handing those out first lets them start at t = 0 instead of wherever
+// their index falls (simulated makespan of the B = 4096 batch: 533 -> 510 KKT units).  Key of a problem = the largest
+// violation clearance - dist over the knots and obstacles of its stored trajectory, quantised to SCHED_BUCKETS levels of
+// the robot size; the order is a counting sort by bucket, largest first.  Affects time only.
+constexpr int SCHED_BUCKETS = 64;
+template <int MODEL> __global__ void sched_key_kernel(const KParams P, int* bucket) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= P.B * P.N) return;
+    if constexpr (T::HAS_OBS) {
+        const int b = gid / P.N;
+        const double* x = P.X + (size_t)gid * n;
+        double xw[T::WS], nh[T::WS], worst = 0.0;
+#pragma unroll
+        for (int j = 0; j < T::WS; j++) xw[j] = x[j];
+        for (int i = 0; i < P.n_obs; i++) worst = fmax(worst, P.mp.clearance - signed_distance<T::WS>(P, 0, xw, i, nh));
+        const double full = 2.0 * (P.mp.radius + P.mp.clearance);      // a robot diameter inside an obstacle: the last bucket
+        const int q = (int)fmin((double)(SCHED_BUCKETS - 1), worst / full * (SCHED_BUCKETS - 1));
+        if (q > 0) atomicMax(bucket + b, q);
+    }
+}
+// one workgroup: counting sort of the problems by bucket, largest first (order inside a bucket: by index)
+static __global__ void sched_order_kernel(int B, const int* bucket, int* order) {
+    __shared__ int cnt[SCHED_BUCKETS], start[SCHED_BUCKETS];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid < SCHED_BUCKETS) cnt[tid] = 0;
+    __syncthreads();
+    for (int b = tid; b < B; b += nt) atomicAdd(&cnt[bucket[b]], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int q = SCHED_BUCKETS - 1; q >= 0; q--) { start[q] = acc; acc += cnt[q]; }
+    }
+    __syncthreads();
+    // stable and deterministic: thread q places the problems of bucket q in index order (B <= a few 10^4: microseconds)
+    if (tid < SCHED_BUCKETS && cnt[tid] > 0) {
+        int at = start[tid];
+        for (int b = 0; b < B; b++)
+            if (bucket[b] == tid) order[at++] = b;
     }
 }
 

@@ -1,0 +1,99 @@
+# GuSTOHIPBatch.jl -- include after GuSTOHIP.jl: the entry points that have no counterpart with the same signature in the
+# reference -- indirect shooting on the GPU for solve_SCPshooting! and the batched / multi-GPU solve.
+
+# solve!(SS, SP) on the GPU (src/shooting.jl:4-49; DubinsCar and AstrobeeSE3Manifold): the handle that holds the SCP state of SP's problem runs the
+# batched indirect shooting from SP.p0 (= SCPS.dual).  Use it in place of `solve!` inside solve_SCPshooting!
+# (src/traj_opt.jl:28): `ss_sol = solve_shooting_hip!(SS, SP, SCPS)`.
+struct GustoShootOpts      # gusto_shoot_opts
+  substeps::Cint; max_newton::Cint; ftol::Cdouble
+end
+function solve_shooting_hip!(SS::ShootingSolution, SP::ShootingProblem, SCPS::SCPSolution; substeps=4, max_newton=100, ftol=1e-3)
+  h = get(GUSTO_HANDLES, SCPS, C_NULL)
+  h == C_NULL && error("solve_shooting_hip!: run solve_gusto_hip! on this SCPSolution first")
+  model, N = SP.PD.model, SP.N
+  n, m = model.x_dim, model.u_dim
+  t0 = time_ns()
+  gusto_check(ccall((:gusto_shoot, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{GustoShootOpts}),
+                    h, Float64.(SP.p0), GustoShootOpts(substeps, max_newton, ftol)), h, "shoot")
+  st, it, res, p0 = zeros(Cint, 1), zeros(Cint, 1), zeros(1), zeros(n)
+  X, U = zeros(n, N), zeros(m, N)
+  gusto_check(ccall((:gusto_get_shoot, libgusto_hip), Cint,
+                    (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), h, st, it, res, p0, X, U), h, "get_shoot")
+  el = (time_ns() - t0) / 10^9
+  if st[1] == 1                                   # sol_newton.f_converged
+    new_traj = Trajectory(X, U, SP.tf)
+    push!(SS.prob_status, :Optimal); push!(SS.J_true, cost_true(new_traj, new_traj, SP))
+    push!(SS.convergence_measure, convergence_metric(new_traj, SS.traj, SP)); copy!(SS.traj, new_traj)
+  else
+    push!(SS.prob_status, :Diverged); push!(SS.J_true, NaN); push!(SS.convergence_measure, NaN)
+  end
+  push!(SS.iter_elapsed_times, el)
+  nothing
+end
+
+# Batch entry point (the reference has none): every TOP must share model, N and environment.  `devices` = GPU ordinals:
+# the problems are split in contiguous blocks of ceil(B/G) (SURVEY.md 8(e)), one handle per entry, every block enqueued
+# with gusto_solve_async so the GPUs run concurrently; the results come back in problem order.
+function solve_SCP_batch!(TOSs::Vector, TOPs::Vector, init_method=init_traj_straightline; max_iter=30, force=false, device=0, devices=nothing)
+  TOP0 = TOPs[1]; model, N = TOP0.PD.model, TOP0.N
+  n, m, B = model.x_dim, model.u_dim, length(TOPs)
+  all(T -> typeof(T.PD.model) == typeof(model) && T.N == N && T.PD.env === TOP0.PD.env, TOPs) ||
+    error("solve_SCP_batch!: all problems must share the model type, N and the environment")
+  devs = devices === nothing ? [device] : collect(devices)
+  G = length(devs); per = cld(B, G)
+  boxes, spheres = gusto_env_tables(TOP0.PD.env)
+  alg0 = SCPParam_GuSTO(model)
+  sp = GustoScpParams(alg0.Δ0, alg0.ω0, alg0.ω_max, alg0.ε, alg0.ρ0, alg0.ρ1, alg0.β_succ, alg0.β_fail, alg0.γ_fail,
+                      SCPParam(model, TOP0.fixed_final_time).convergence_threshold)
+  x0 = hcat((Float64.(T.PD.x_init) for T in TOPs)...)
+  bounds = [gusto_goal_bounds(T.PD.goal_set, n, T.tf_guess) for T in TOPs]
+  lo, hi = hcat(first.(bounds)...), hcat(last.(bounds)...)
+  tf = Float64[T.tf_guess for T in TOPs]
+  inits = [init_method(T) for T in TOPs]
+  X0, U0 = cat((t.X for t in inits)..., dims=3), cat((t.U for t in inits)..., dims=3)   # [n,N,B]: problem slowest
+  shards = Tuple{Int,Int,Ptr{Cvoid}}[]
+  for (r, dv) in enumerate(devs)
+    b0, b1 = min(B, (r - 1) * per) + 1, min(B, r * per)
+    b1 < b0 && continue
+    href = Ref{Ptr{Cvoid}}(C_NULL)
+    gusto_check(ccall((:gusto_create, libgusto_hip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint),
+                      href, gusto_model_id(model), N, b1 - b0 + 1, gusto_hist_cap(max_iter), dv), href[], "create")
+    h = href[]
+    gusto_check(ccall((:gusto_set_params, libgusto_hip), Cint, (Ptr{Cvoid}, Ref{GustoScpParams}, Ref{GustoModelParams}),
+                      h, sp, gusto_model_params(TOP0.PD.robot, model)), h, "set_params")
+    gusto_check(ccall((:gusto_set_env, libgusto_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}),
+                      h, length(boxes) ÷ 6, boxes, length(spheres) ÷ 4, spheres), h, "set_env")
+    gusto_check(ccall((:gusto_set_problems, libgusto_hip), Cint,
+                      (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                      h, b1 - b0 + 1, x0[:, b0:b1], lo[:, b0:b1], hi[:, b0:b1], tf[b0:b1], X0[:, :, b0:b1], U0[:, :, b0:b1]), h, "set_problems")
+    gusto_check(ccall((:gusto_solve_async, libgusto_hip), Cint, (Ptr{Cvoid}, Cint, Cint), h, max_iter, force), h, "solve_async")
+    push!(shards, (b0, b1, h))
+  end
+  for (b0, b1, h) in shards
+    Bs = b1 - b0 + 1
+    gusto_check(ccall((:gusto_wait, libgusto_hip), Cint, (Ptr{Cvoid},), h), h, "wait")
+    X, U = zeros(n, N, Bs), zeros(m, N, Bs)
+    gusto_check(ccall((:gusto_get_traj, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), h, X, U), h, "get_traj")
+    its, conv, succ, stop = zeros(Cint, Bs), zeros(Cint, Bs), zeros(Cint, Bs), zeros(Cint, Bs)
+    gusto_check(ccall((:gusto_get_status, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cvoid}),
+                      h, its, conv, succ, stop, C_NULL), h, "get_status")
+    duals = zeros(n, Bs)
+    gusto_check(ccall((:gusto_get_dual, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), h, duals), h, "get_dual")
+    Hs = gusto_histories(h, Bs)                      # one device -> host copy per shard
+    msec = Ref{Cdouble}(0.)
+    ccall((:gusto_last_solve_ms, libgusto_hip), Cint, (Ptr{Cvoid}, Ref{Cdouble}), h, msec)
+    for b in b0:b1
+      j = b - b0 + 1
+      SCPP = SCPProblem(TOPs[b])
+      SCPP.param.alg = SCPParam_GuSTO(model)
+      SCPS = SCPSolution(SCPP, Trajectory(X[:, :, j], U[:, :, j], TOPs[b].tf_guess))
+      gusto_fill_solution!(SCPS, SCPP.param.alg, Hs, j, its[j], conv[j], succ[j], stop[j], duals[:, j])
+      SCPS.total_time = msec[] / 1e3 / Bs
+      SCPS.iter_elapsed_times = vcat(0., fill(SCPS.total_time / max(1, its[j]), its[j]))
+      SCPP.param.obstacle_toggle_distance = SCPP.param.alg.Δ_vec[end] / 8 + model.clearance
+      TOSs[b].traj, TOSs[b].SCPS = SCPS.traj, SCPS
+    end
+    ccall((:gusto_destroy, libgusto_hip), Cint, (Ptr{Cvoid},), h)
+  end
+  nothing
+end

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libgusto_oracle.so")
+_LIB = os.environ.get("GUSTO_ORACLE_LIB") or os.path.join(_HERE, "libgusto_oracle.so")   # (a sanitizer build: oracle/Makefile asan)
 
 MAXN, MAXM = 13, 6
 FREEFLYER_SE2, DUBINS_CAR, ASTROBEE_SE3, ASTROBEE_SE3_MANIFOLD = 0, 1, 2, 3

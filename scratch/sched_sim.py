@@ -234,3 +234,8 @@ def sim6(order, probe, q, S=1024, hiq=None):
     return done_t
 for q in (1, 2, 3, 4, 6, 8, 1000):
     print('q', q, 'probe1', sim6(o_max, 1, q), 'probe2', sim6(o_max, 2, q), 'id order probe 1:', sim6(ids, 1, q), 'hi also sliced q:', sim6(o_max, 1, q, hiq=q))
+print('--- fmax order with the CURRENT policy:', sim(o_max, 2), 'probe1', sim(o_max, 1), 'probe3', sim(o_max, 3))
+# feature variants for ordering under P5
+for name, f in [('max', f_max), ('sum', f_sum), ('max+0.02sum', f_max + 0.02 * f_sum)]:
+    o = np.argsort(-f, kind='stable')
+    print(name, 'current policy', sim(o, 2), 'P5', sim5(o, 2))

@@ -127,3 +127,56 @@ def test_shard_bounds_cover_the_batch():
                 lo, hi = H.shard_bounds(B, G, r)
                 cover += list(range(lo, hi))
             assert cover == list(range(B))
+
+
+def test_julia_wrapper_matches_the_c_header():
+    """julia/GuSTOHIP*.jl cannot be executed here (no Julia toolchain): check statically what can go wrong silently at
+    a ccall boundary -- every symbol it calls is exported by the library and declared in the header, and the Julia
+    mirrors of the C structs have the header's fields in the header's order and types."""
+    import re
+    jl = "".join(open(os.path.join(ROOT, "gusto.jl_amd", "julia", f)).read() for f in ("GuSTOHIP.jl", "GuSTOHIPBatch.jl"))
+    hdr = open(os.path.join(ROOT, "include", "gusto_hip.h")).read()
+    syms = set(re.findall(r"ccall\(\(:(\w+), libgusto_hip\)", jl))
+    assert {"gusto_create", "gusto_set_params", "gusto_set_env", "gusto_set_problems", "gusto_solve", "gusto_solve_async",
+            "gusto_wait", "gusto_get_traj", "gusto_get_status", "gusto_get_history", "gusto_get_dual", "gusto_shoot"} <= syms
+    L = g.lib()
+    for s in syms:
+        assert hasattr(L, s) and re.search(r"\b%s\(" % s, hdr), s
+
+    def c_fields(name):
+        end = hdr.index("} %s;" % name)
+        body = hdr[hdr.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            ctype, rest = decl.split(None, 1)
+            for v in rest.split(","):
+                v = v.strip()
+                dims = [int(d) if d.isdigit() else {"GUSTO_MAXN": 13, "GUSTO_MAXM": 6}[d] for d in re.findall(r"\[(\w+)\]", v)]
+                out.append((re.sub(r"[\*\[].*", "", v.lstrip("*")), ctype + ("*" if v.startswith("*") else ""), int(np.prod(dims)) if dims else 0))
+        return out
+
+    def jl_fields(name):
+        body = re.search(r"struct %s\b[^\n]*\n(.*?)\nend" % name, jl, re.S).group(1)
+        out = []
+        for f in re.split(r"[;\n]", re.sub(r"#[^\n]*", "", body)):
+            f = f.strip()
+            if f:
+                nm, ty = f.split("::")
+                out.append((nm.strip(), ty.strip()))
+        return out
+
+    def jl_type(ctype, count):
+        base = {"double": "Cdouble", "int": "Cint", "double*": "Ptr{Cdouble}", "int*": "Ptr{Cint}"}[ctype]
+        return f"NTuple{{{count},{base}}}" if count else base
+
+    for cname, jname in (("gusto_scp_params", "GustoScpParams"), ("gusto_model_params", "GustoModelParams"),
+                         ("gusto_history", "GustoHistory"), ("gusto_shoot_opts", "GustoShootOpts")):
+        cf, jf = c_fields(cname), jl_fields(jname)
+        assert [n for n, _, _ in cf] == [n for n, _ in jf], (cname, cf, jf)
+        assert [jl_type(t, c) for _, t, c in cf] == [t for _, t in jf], (cname, cf, jf)
+    # the robot / model scalars reach the library: no C_NULL where gusto_model_params goes
+    assert "Ref{GustoModelParams}" in jl and not re.search(r"gusto_set_params.*C_NULL", jl)

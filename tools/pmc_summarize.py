@@ -22,13 +22,16 @@ for ln in log.splitlines():
 f = per_kernel(os.path.join(src, "pmc", "FETCH_SIZE_counter_collection.csv"))
 w = per_kernel(os.path.join(src, "pmc", "WRITE_SIZE_counter_collection.csv"))
 scp_k = [k for k in f if "scp_kernel" in k][0]
-cal_k = [k for k in f if "vectorized_elementwise" in k][0]
+# calibration: the READ is the (a + 1.0) kernel (CUDAFunctorOnSelf_add: reads 1 GiB, writes 1 GiB); the zeros fill only writes
+cal = [k for k in f if "vectorized_elementwise" in k]
+cal_k = ([k for k in cal if "CUDAFunctorOnSelf_add" in k] or [max(cal, key=lambda k: f[k]["FETCH_SIZE"])])[0]
 out["kernel"] = scp_k.replace("void ", "").split("(")[0]
 out["FETCH_SIZE_kb_raw"], out["WRITE_SIZE_kb_raw"] = f[scp_k]["FETCH_SIZE"], w[scp_k]["WRITE_SIZE"]
 out["calibration"] = {
     "pattern": "torch float64 elementwise over 1 GiB: zeros fill + (a + 1.0)",
     "FETCH_SIZE_kb": f[cal_k]["FETCH_SIZE"], "expected_read_kb": 1048576,
-    "WRITE_SIZE_kb": w[cal_k]["WRITE_SIZE"], "expected_write_kb": 2097152,
+    "kernel": cal_k.split("(")[0][:120],
+    "WRITE_SIZE_kb": sum(w[k]["WRITE_SIZE"] for k in cal), "expected_write_kb": 2097152,
     "note": "FETCH_SIZE reports 1/2 of the bytes read on gfx950 (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE is exact"}
 out["fetch_bytes"] = 2.0 * 1024 * out["FETCH_SIZE_kb_raw"]
 out["write_bytes"] = 1024 * out["WRITE_SIZE_kb_raw"]
