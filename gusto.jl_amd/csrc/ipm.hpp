@@ -1117,6 +1117,222 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
     }
 }
 
+// The factor sweep of the double-integrator model (MT::PG2, one wave, K | D | S^-1 in LDS), software pipelined.
+// A stage has two chains: the value function (P_k -> H -> chol(H_uu) -> W -> P_{k-1}: the critical path, ~45 dependent
+// flops of a wave-uniform 3 x 3 Cholesky in its middle) and the goal sensitivities (Pi_k -> Z -> V = L^-1 Z_u ->
+// Pi_{k-1}, Gd, D), which needs L_k and W_k of the first chain but nothing the first chain waits for.  Written stage by
+// stage (factor_sweep_1w) the second chain sits behind the Cholesky of its own stage and the wave -- one per SIMD, in-order
+// issue -- idles through the factorisation.  Here iteration k runs stage k of the first chain together with the second
+// half of stage k+1 of the second (tail: V, Pi, Gd, D from the L and W kept in registers) and the first half of its stage k
+// (head: Z = [Phi Gam]^T Pi_k, Pi_k^T c_k): independent instruction streams in one basic block.  To keep it ONE basic block
+// nothing is predicated: every LDS / global store is unconditional, lanes without an entry aim at a dummy slot (16 doubles
+// of the T buffer, which this path does not use), the last knot's E term is a select, the not-positive-definite flag is
+// accumulated and stored once after the sweep.  [Phi Gam] is constant over the sweep except at knot 0 ([0 | b_0], x_1 is
+// pinned): its entries live in registers and knot 0 is a peeled copy of the stage.  Same arithmetic as factor_sweep_1w,
+// operation for operation: the results are bit-identical.
+template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, Prof& pf) {
+    using T = MT<MODEL>;
+    using R = Rec<MODEL>;
+    using C = LdsC<MODEL, true>;
+    constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n, NZN = NZ * n, h3 = n / 2,
+                  NH = n * (n + 1) / 2;
+    static_assert(T::PG2 && T::LTI && C::KD_LDS && NQ <= 64 && NZN <= 64 && NN <= 64 && n >= 2 * m, "shape");
+    static_assert(T::pg_r1(0) == T::pg_r0(0) + h3 && T::pg_r1(n) == T::pg_r0(n) + h3 && T::pg_r1(n - 1) == T::pg_r0(n - 1) + h3, "PG2 row pairs");
+    static_assert(NH + NN < R::SNN && !C::BIG, "P | Pi record, dummy slot");
+    const int tid = K.tid, N = K.N;
+    // ---- lane roles ----
+    const int ijh = K.lut[tid < NQ ? tid : 0], hc = ijh >> 8, hj = ijh & 255, i0 = T::pg_r0(hc), j0 = T::pg_r0(hj);   // H[hc][hj]
+    const int zc = tid < NZN ? tid / n : 0, zg = tid < NZN ? tid % n : 0, z0 = T::pg_r0(zc);                       // Z[zc][zg]
+    const int ri = tid < n ? tid : 0;                                                                             // r[ri], Pi^T c [ri]
+    const bool on = tid < NN;
+    const int i = on ? tid / n : 0, j = on ? tid % n : 0;                                                         // P[i][j], Pi[i][j]
+    // ---- LDS operands (offsets in doubles from the base of the dynamic LDS) ----
+    const LPtr<double> L = K.lds;
+    const int dmy = C::sT0 + (tid & 15);             // dummy slot of this lane (+ immediates < 36 stay inside the T buffer)
+    static_assert(n * NZ >= 16 + 36, "dummy slot");
+    const int oPP = C::sP + i0 * n + j0, oPZ = C::sPi + z0 * n + zg, oPr = C::sP + ri, oPir = C::sPi + ri;
+    const int wH1 = tid < NQ ? C::sHh + hc * NZ + hj : dmy, wH2 = tid < NQ ? C::sHh + hj * NZ + hc : dmy;
+    const int wZ = tid < NZN ? C::sZ + tid : dmy;
+    const int oHi = C::sHh + i * NZ + n, oHj = C::sHh + j * NZ + n, oPn = C::sHh + i * NZ + j;
+    const int oZi = C::sZ + n * n + i, oZj = C::sZ + n * n + j, oPin = C::sZ + i * n + j, oGd = C::sGd + (on ? tid : 0);
+    const int wP = on ? C::sP + tid : dmy, wPi = on ? C::sPi + tid : dmy, wGd = on ? C::sGd + tid : dmy;
+    const int vecs = C::vecs, oCv = vecs + 3 * N * n, oRv = vecs + 4 * N * n, oNun = vecs + 6 * N * n;   // (Blk::rebind_lds)
+    const int wRv = tid < n ? oRv + tid : dmy, wNun = tid < n ? oNun + tid : dmy, sRv = tid < n ? n : 0;
+    const int kdo = K.phicl_off;
+    const int wKD = tid < n ? kdo + tid : dmy, sKD = tid < n ? C::KDS : 0;             // K[a][tid] at + a n, D[a][tid] at + (m + a) n
+    const int wSi = tid == 0 ? kdo + 2 * m * n : dmy, sSi = tid == 0 ? C::KDS : 0;     // S^-1, upper triangle
+    const int ep = (on && i <= j) ? sidx(i, j, n) : R::SNN - 1, eq = on ? NH + tid : R::SNN - 1;   // packed P | Pi record
+    // ---- [Phi Gam] entries of this lane: the block of the sweep and the knot-0 block [0 | b_0] ----
+    struct PGC { double a0, a1, b0, b1, zv0, zv1; };
+    double Bd[n * m];
+    Dyn<MODEL>::B(*K.mpp, Bd);
+    auto pg_main = [&](int r_, int c_) { return K.PGk(N - 1)[r_ * NZ + c_]; };
+    auto pg_zero = [&](int r_, int c_) {   // ([0 | dt/2 B], formed as factor_sweep_1w forms it)
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < n * m; q++) if (c_ >= n && q == r_ * m + (c_ - n)) v = 0.5 * K.dt * Bd[q];
+        return v;
+    };
+    PGC cN, c0;
+    cN.a0 = pg_main(i0, hc); cN.a1 = pg_main(i0 + h3, hc); cN.b0 = pg_main(j0, hj); cN.b1 = pg_main(j0 + h3, hj);
+    cN.zv0 = pg_main(z0, zc); cN.zv1 = pg_main(z0 + h3, zc);
+    c0.a0 = pg_zero(i0, hc); c0.a1 = pg_zero(i0 + h3, hc); c0.b0 = pg_zero(j0, hj); c0.b1 = pg_zero(j0 + h3, hj);
+    c0.zv0 = pg_zero(z0, zc); c0.zv1 = pg_zero(z0 + h3, zc);
+    // E = [M^T C^T; b^T M^T C^T] of the last knot, M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
+    const double eterm = pg_main(zg, zc) + ((zc == zg) ? 1.0 : 0.0);
+    const bool egoal = K.is_goal(zg);
+    // ---- start: P = Pi = Gd = 0 after the last knot, Z = 0 (the tail of "stage N" then leaves Pi_{N-1} = 0) ----
+    L[wP] = 0.0; L[wPi] = 0.0; L[wGd] = 0.0; L[wZ] = 0.0;
+    if (tid < R::SNN) K.Paft[(size_t)(N - 1) * R::SNN + tid] = 0.0;
+    double qq = K.kdl[(N - 1) * C::KDS + (tid < NQ ? tid : 0)];
+    double LiP[m * m], wiP[m];   // L^-1 and this lane's column i of W of the stage before (tail operands)
+#pragma unroll
+    for (int e = 0; e < m * m; e++) LiP[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < m; e++) wiP[e] = 0.0;
+    bool okall = true;
+    K.sync();
+
+    // tail of stage kt (V, Pi_{kt-1}, Gd, D_kt) from (LiP, wiP) and Z of that stage in LDS; returns nothing, writes LDS + record
+    auto tail = [&](int kt, const double* zi, const double* zj, double pin, double gd) {
+        double vi[m], vj[m], dj[m];
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+            double s3 = 0, s4 = 0;
+#pragma unroll
+            for (int l = 0; l <= a; l++) { s3 += LiP[a * m + l] * zi[l]; s4 += LiP[a * m + l] * zj[l]; }
+            vi[a] = s3; vj[a] = s4;
+        }
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+            double s2 = 0;
+#pragma unroll
+            for (int l = a; l < m; l++) s2 += LiP[l * m + a] * vj[l];
+            dj[a] = s2;
+        }
+#pragma unroll
+        for (int l = 0; l < m; l++) { pin -= wiP[l] * vj[l]; gd += vi[l] * vj[l]; }
+        L[wPi] = pin; L[wGd] = gd;
+        K.Paft[(size_t)(kt - 1) * R::SNN + eq] = pin;
+#pragma unroll
+        for (int a = 0; a < m; a++) L[wKD + kt * sKD + (m + a) * n] = dj[a];
+    };
+
+    // ordering point for LDS traffic between lanes that leaves the ALU work free to move (one wave: the hardware keeps
+    // its LDS operations in order, only the compiler has to)
+    auto msync = [&]() {
+#ifdef GUSTO_PIPE_FULLSYNC
+        K.sync();
+#else
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
+    };
+    auto stage = [&](int k, const PGC& c, bool last) {
+        // ---- operands of this iteration, one batch ----
+        const double p00 = L[oPP], p01 = L[oPP + h3], p10 = L[oPP + h3 * n], p11 = L[oPP + h3 * n + h3];
+        double ra[n], rb[n];
+#pragma unroll
+        for (int l = 0; l < n; l++) { ra[l] = L[oPr + l * n]; rb[l] = L[oCv + k * n + l]; }
+        double zi[m], zj[m];
+#pragma unroll
+        for (int l = 0; l < m; l++) { zi[l] = L[oZi + l * n]; zj[l] = L[oZj + l * n]; }
+        const double pin_ = L[oPin], gd_ = L[oGd];
+        const double qqn = K.kdl[((k > 0) ? k - 1 : 0) * C::KDS + (tid < NQ ? tid : 0)];   // (slot k-1 still holds QQ_{k-1})
+        // ---- value function chain, first half: H, r_k = P_k c_k ----
+        const double h = qq + c.a0 * (c.b0 * p00 + c.b1 * p01) + c.a1 * (c.b0 * p10 + c.b1 * p11);
+        L[wH1] = h; L[wH2] = h;
+        {
+            double rr = 0;
+#pragma unroll
+            for (int l = 0; l < n; l++) rr += ra[l] * rb[l];
+            L[wRv + k * sRv] = rr;
+        }
+        msync();
+        double S[m * m], Li[m * m];
+#pragma unroll
+        for (int a = 0; a < m; a++)
+#pragma unroll
+            for (int b = 0; b < m; b++) {
+                const int e = sidx(n + (a < b ? a : b), n + (a < b ? b : a), NZ);
+                S[a * m + b] = readlane_f64(h, e);
+            }
+        double hi[m], hjv[m];
+#pragma unroll
+        for (int l = 0; l < m; l++) { hi[l] = L[oHi + l]; hjv[l] = L[oHj + l]; }
+        double pn = L[oPn];
+        // ---- goal chain: tail of the stage before, head of this one (independent of the factorisation below) ----
+        tail(k + 1 < N ? k + 1 : N - 1, zi, zj, pin_, gd_);
+        msync();
+        // (operands of the head first, then the factorisation: its ~45 dependent flops run while they are in flight)
+        const double zb0 = L[oPZ], zb1 = L[oPZ + h3 * n];
+        double pa[n];
+#pragma unroll
+        for (int l = 0; l < n; l++) pa[l] = L[oPir + l * n];
+        // ---- value function chain, second half: L = chol(H_uu), W = L^-1 H_uy, K = L^-T W, P_{k-1} = H_yy - W^T W ----
+        okall = chol_inv<m>(S, Li) && okall;
+        {
+            double z = c.zv0 * zb0 + c.zv1 * zb1;
+            const double zE = fma(0.5, eterm, z);
+            z = (last && egoal) ? zE : z;
+            L[wZ] = z;
+            double rr = 0;
+#pragma unroll
+            for (int l = 0; l < n; l++) rr += pa[l] * rb[l];
+            L[wNun + k * sRv] = rr;
+        }
+        double wi[m], wj[m], kj[m];
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+            double s1 = 0, s2 = 0;
+#pragma unroll
+            for (int l = 0; l <= a; l++) { s1 += Li[a * m + l] * hi[l]; s2 += Li[a * m + l] * hjv[l]; }
+            wi[a] = s1; wj[a] = s2;
+        }
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+            double s1 = 0;
+#pragma unroll
+            for (int l = a; l < m; l++) s1 += Li[l * m + a] * wj[l];
+            kj[a] = s1;
+        }
+#pragma unroll
+        for (int l = 0; l < m; l++) pn -= wi[l] * wj[l];
+        L[wP] = pn;
+        K.Paft[(size_t)(k - 1) * R::SNN + ep] = pn;     // (record -1 exists for k == 0)
+#pragma unroll
+        for (int a = 0; a < m; a++) L[wKD + k * sKD + a * n] = kj[a];
+        {   // S^-1 = L^-T L^-1, upper triangle (wave-uniform values)
+#pragma unroll
+            for (int a = 0; a < m; a++)
+#pragma unroll
+                for (int b = 0; b <= a; b++) {
+                    double s1 = 0;
+#pragma unroll
+                    for (int l = a; l < m; l++) s1 += Li[l * m + a] * Li[l * m + b];
+                    L[wSi + k * sSi + sidx(b, a, m)] = s1;
+                }
+        }
+        qq = qqn;
+#pragma unroll
+        for (int e = 0; e < m * m; e++) LiP[e] = Li[e];
+#pragma unroll
+        for (int e = 0; e < m; e++) wiP[e] = wi[e];
+        msync();
+    };
+
+    for (int k = N - 1; k >= 1; k--) stage(k, cN, k == N - 1);
+    stage(0, c0, false);
+    {   // the goal chain is one half stage behind: tail of stage 0 (Gd, D_0; its Pi lands in record -1)
+        double zi[m], zj[m];
+#pragma unroll
+        for (int l = 0; l < m; l++) { zi[l] = L[oZi + l * n]; zj[l] = L[oZj + l * n]; }
+        tail(0, zi, zj, L[oPin], L[oGd]);
+    }
+    if (!okall) *fail = 1.0;
+    K.sync();
+    (void)pf;
+}
+
 // The factor sweep of the 12/13-state models entirely on the matrix cores (MT::MFMA).  Every matrix of a stage is a
 // 16 x 16 tile in the accumulator layout of v_mfma_f64_16x16x4_f64 -- entry (row, col) in register row >> 2 of lane
 // (row & 3) << 4 | col -- and that layout IS an operand layout: register s of a tile X, used as the A operand of K step
@@ -1520,6 +1736,9 @@ template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof&
     else if constexpr (MT<MODEL>::SWEEP_CALL) factor_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K), &pf);
 #endif
     else if constexpr (MT<MODEL>::MFMA) factor_sweep_mfma<MODEL>(SweepView<MODEL>::make(K), fail, pf);
+#ifndef GUSTO_NO_FACTOR_PIPE
+    else if constexpr (MT<MODEL>::PG2 && LdsC<MODEL, true>::KD_LDS) factor_sweep_pg2<MODEL>(SweepView<MODEL>::make(K), fail, pf);
+#endif
     else factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail, pf);
 }
 template <int MODEL> __device__ __noinline__ void backward_sweep_1w_call(SweepView<MODEL> K) {
