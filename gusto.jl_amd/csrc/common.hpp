@@ -177,7 +177,7 @@ template <int MODEL, bool ONE> struct LdsC {
     static constexpr int sP = 0, sPi = sP + n * n, sPG = sPi + n * n, sT0 = sPG + NPGB * n * NZ,
                          sHh = sT0 + ((ONE && BIG) ? 0 : n * NZ), sZ = sHh + NZ * NZ, sT = (ONE && BIG) ? sZ : sT0,
                          sGd = sZ + NZ * n, misc = sGd + ((ONE && BIG) ? 1 : 2) * n * n, lut = misc + 64,
-                         vecs1w = lut + (NZ * (NZ + 1) / 2 + 1) / 2 + 1,
+                         vecs1w = (lut + (NZ * (NZ + 1) / 2 + 1) / 2 + 1 + 1) & ~1,   // (even: 16-byte aligned rows of the n-vectors, ds_read_b128)
                          sK = vecs1w, sD = sK + m * n, sW = sD + m * n, sV = sW + m * n, vecsmw = sV + m * n,
                          vecs = ONE ? vecs1w : vecsmw;
     // per-knot vectors shared between lanes: n-vectors (Xw dY pv cv rv nu nun) then the m-vector Uw; vectors only

@@ -22,7 +22,7 @@
 namespace gusto {
 
 // the dynamic LDS of the workgroup (the same memory as the `extern __shared__` array of scp_kernel)
-extern __shared__ double gusto_dyn_lds[];
+extern __shared__ __attribute__((aligned(16))) double gusto_dyn_lds[];
 
 struct IpmOut {
     int status, iters;
@@ -1130,6 +1130,12 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
 // accumulated and stored once after the sweep.  [Phi Gam] is constant over the sweep except at knot 0 ([0 | b_0], x_1 is
 // pinned): its entries live in registers and knot 0 is a peeled copy of the stage.  Same arithmetic as factor_sweep_1w,
 // operation for operation: the results are bit-identical.
+// LDS traffic is what bounds a stage (measured: a wave issues one ds_read every ~8 cycles whatever its width up to 128 bits,
+// a ds_read2 costs two, a ds_write ~13, against 4 cycles for an fp64 FMA), so the operands are laid out for 128-bit reads:
+// P is kept with its columns interleaved (j, j + n/2 adjacent: the two entries a lane of H needs from a row are one
+// ds_read_b128) and read by ROWS for r_k = P c (P is exactly symmetric), Pi is kept transposed (the column for Pi^T c is a
+// row), only the upper triangle of H is written, and what a lane reads back from itself (its entry of Gd, its entry of Z)
+// stays in a register.
 template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, Prof& pf) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
@@ -1148,14 +1154,18 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
     const int i = on ? tid / n : 0, j = on ? tid % n : 0;                                                         // P[i][j], Pi[i][j]
     // ---- LDS operands (offsets in doubles from the base of the dynamic LDS) ----
     const LPtr<double> L = K.lds;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    auto ld2 = [&](int off) { return *(const __attribute__((address_space(3))) v2d*)(L.p + off); };   // ds_read_b128 (off even)
     const int dmy = C::sT0 + (tid & 15);             // dummy slot of this lane (+ immediates < 36 stay inside the T buffer)
     static_assert(n * NZ >= 16 + 36, "dummy slot");
-    const int oPP = C::sP + i0 * n + j0, oPZ = C::sPi + z0 * n + zg, oPr = C::sP + ri, oPir = C::sPi + ri;
-    const int wH1 = tid < NQ ? C::sHh + hc * NZ + hj : dmy, wH2 = tid < NQ ? C::sHh + hj * NZ + hc : dmy;
+    auto pcol = [](int j_) { return 2 * (j_ % h3) + j_ / h3; };       // column j of P sits at position pcol(j) of its row
+    static_assert(C::sP % 2 == 0 && C::sPi % 2 == 0 && n % 2 == 0 && C::vecs % 2 == 0, "16-byte aligned rows");
+    const int oPP = C::sP + i0 * n + 2 * j0, oPZ = C::sPi + zg * n + z0, oPr = C::sP + ri * n, oPir = C::sPi + ri * n;
+    const int wH1 = tid < NQ ? C::sHh + hc * NZ + hj : dmy;           // (upper triangle only: hc <= hj)
     const int wZ = tid < NZN ? C::sZ + tid : dmy;
-    const int oHi = C::sHh + i * NZ + n, oHj = C::sHh + j * NZ + n, oPn = C::sHh + i * NZ + j;
-    const int oZi = C::sZ + n * n + i, oZj = C::sZ + n * n + j, oPin = C::sZ + i * n + j, oGd = C::sGd + (on ? tid : 0);
-    const int wP = on ? C::sP + tid : dmy, wPi = on ? C::sPi + tid : dmy, wGd = on ? C::sGd + tid : dmy;
+    const int oHi = C::sHh + i * NZ + n, oHj = C::sHh + j * NZ + n, oPn = C::sHh + (i < j ? i : j) * NZ + (i < j ? j : i);
+    const int oZi = C::sZ + n * n + i, oZj = C::sZ + n * n + j;
+    const int wP = on ? C::sP + i * n + pcol(j) : dmy, wPi = on ? C::sPi + j * n + i : dmy, wGd = on ? C::sGd + tid : dmy;
     const int vecs = C::vecs, oCv = vecs + 3 * N * n, oRv = vecs + 4 * N * n, oNun = vecs + 6 * N * n;   // (Blk::rebind_lds)
     const int wRv = tid < n ? oRv + tid : dmy, wNun = tid < n ? oNun + tid : dmy, sRv = tid < n ? n : 0;
     const int kdo = K.phicl_off;
@@ -1182,7 +1192,8 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
     const double eterm = pg_main(zg, zc) + ((zc == zg) ? 1.0 : 0.0);
     const bool egoal = K.is_goal(zg);
     // ---- start: P = Pi = Gd = 0 after the last knot, Z = 0 (the tail of "stage N" then leaves Pi_{N-1} = 0) ----
-    L[wP] = 0.0; L[wPi] = 0.0; L[wGd] = 0.0; L[wZ] = 0.0;
+    L[wP] = 0.0; L[wPi] = 0.0; L[wZ] = 0.0;
+    double gdR = 0.0, zR = 0.0;   // this lane's entry of Gd (accumulated over the sweep) and of Z (the Pi' term of the next tail)
     if (tid < R::SNN) K.Paft[(size_t)(N - 1) * R::SNN + tid] = 0.0;
     double qq = K.kdl[(N - 1) * C::KDS + (tid < NQ ? tid : 0)];
     double LiP[m * m], wiP[m];   // L^-1 and this lane's column i of W of the stage before (tail operands)
@@ -1194,7 +1205,8 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
     K.sync();
 
     // tail of stage kt (V, Pi_{kt-1}, Gd, D_kt) from (LiP, wiP) and Z of that stage in LDS; returns nothing, writes LDS + record
-    auto tail = [&](int kt, const double* zi, const double* zj, double pin, double gd) {
+    auto tail = [&](int kt, const double* zi, const double* zj) {
+        double pin = zR, gd = gdR;
         double vi[m], vj[m], dj[m];
 #pragma unroll
         for (int a = 0; a < m; a++) {
@@ -1212,7 +1224,7 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
         }
 #pragma unroll
         for (int l = 0; l < m; l++) { pin -= wiP[l] * vj[l]; gd += vi[l] * vj[l]; }
-        L[wPi] = pin; L[wGd] = gd;
+        L[wPi] = pin; gdR = gd;
         K.Paft[(size_t)(kt - 1) * R::SNN + eq] = pin;
 #pragma unroll
         for (int a = 0; a < m; a++) L[wKD + kt * sKD + (m + a) * n] = dj[a];
@@ -1227,26 +1239,42 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #endif
     };
+    // GUSTO_STAGE_PROF (with GUSTO_PROFILE): time stamps INSIDE a stage, read asynchronously -- s_memtime is issued where the
+    // wave is, its result is only waited for at the end of the stage, so the stamps do not drain the LDS queue
+#if defined(GUSTO_PROFILE) && defined(GUSTO_STAGE_PROF)
+#define STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define STAMPS_END() do { pf.acc[PF_FPRE] += (long long)(t1_ - t0_); pf.acc[PF_FAB] += (long long)(t2_ - t1_); \
+                          pf.acc[PF_F4] += (long long)(t3_ - t2_); pf.acc[PF_F5] += (long long)(t4_ - t3_); pf.acc[PF_FCD] += (long long)(t5_ - t4_); } while (0)
+#else
+#define STAMP(v) do {} while (0)
+#define STAMPS_END() do {} while (0)
+#endif
     auto stage = [&](int k, const PGC& c, bool last) {
+        STAMP(t0_);
         // ---- operands of this iteration, one batch ----
-        const double p00 = L[oPP], p01 = L[oPP + h3], p10 = L[oPP + h3 * n], p11 = L[oPP + h3 * n + h3];
+        const v2d pA = ld2(oPP), pB = ld2(oPP + h3 * n);
+        const double p00 = pA.x, p01 = pA.y, p10 = pB.x, p11 = pB.y;
         double ra[n], rb[n];
 #pragma unroll
-        for (int l = 0; l < n; l++) { ra[l] = L[oPr + l * n]; rb[l] = L[oCv + k * n + l]; }
+        for (int l = 0; l < n; l += 2) {
+            const v2d a2 = ld2(oPr + l), b2 = ld2(oCv + k * n + l);
+            // row ri of P holds the columns in the order 0, n/2, 1, n/2 + 1, ...: ra[] back in natural order
+            ra[l / 2] = a2.x; ra[l / 2 + h3] = a2.y; rb[l] = b2.x; rb[l + 1] = b2.y;
+        }
         double zi[m], zj[m];
 #pragma unroll
         for (int l = 0; l < m; l++) { zi[l] = L[oZi + l * n]; zj[l] = L[oZj + l * n]; }
-        const double pin_ = L[oPin], gd_ = L[oGd];
         const double qqn = K.kdl[((k > 0) ? k - 1 : 0) * C::KDS + (tid < NQ ? tid : 0)];   // (slot k-1 still holds QQ_{k-1})
         // ---- value function chain, first half: H, r_k = P_k c_k ----
         const double h = qq + c.a0 * (c.b0 * p00 + c.b1 * p01) + c.a1 * (c.b0 * p10 + c.b1 * p11);
-        L[wH1] = h; L[wH2] = h;
+        L[wH1] = h;
         {
             double rr = 0;
 #pragma unroll
             for (int l = 0; l < n; l++) rr += ra[l] * rb[l];
             L[wRv + k * sRv] = rr;
         }
+        STAMP(t1_);
         msync();
         double S[m * m], Li[m * m];
 #pragma unroll
@@ -1261,25 +1289,29 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
         for (int l = 0; l < m; l++) { hi[l] = L[oHi + l]; hjv[l] = L[oHj + l]; }
         double pn = L[oPn];
         // ---- goal chain: tail of the stage before, head of this one (independent of the factorisation below) ----
-        tail(k + 1 < N ? k + 1 : N - 1, zi, zj, pin_, gd_);
+        tail(k + 1 < N ? k + 1 : N - 1, zi, zj);
+        STAMP(t2_);
         msync();
         // (operands of the head first, then the factorisation: its ~45 dependent flops run while they are in flight)
-        const double zb0 = L[oPZ], zb1 = L[oPZ + h3 * n];
+        const double zb0 = L[oPZ], zb1 = L[oPZ + h3];
         double pa[n];
 #pragma unroll
-        for (int l = 0; l < n; l++) pa[l] = L[oPir + l * n];
+        for (int l = 0; l < n; l += 2) { const v2d a2 = ld2(oPir + l); pa[l] = a2.x; pa[l + 1] = a2.y; }
         // ---- value function chain, second half: L = chol(H_uu), W = L^-1 H_uy, K = L^-T W, P_{k-1} = H_yy - W^T W ----
         okall = chol_inv<m>(S, Li) && okall;
+        STAMP(t3_);
         {
             double z = c.zv0 * zb0 + c.zv1 * zb1;
             const double zE = fma(0.5, eterm, z);
             z = (last && egoal) ? zE : z;
             L[wZ] = z;
+            zR = z;
             double rr = 0;
 #pragma unroll
             for (int l = 0; l < n; l++) rr += pa[l] * rb[l];
             L[wNun + k * sRv] = rr;
         }
+        STAMP(t4_);
         double wi[m], wj[m], kj[m];
 #pragma unroll
         for (int a = 0; a < m; a++) {
@@ -1318,7 +1350,11 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
 #pragma unroll
         for (int e = 0; e < m; e++) wiP[e] = wi[e];
         msync();
+        STAMP(t5_);
+        STAMPS_END();
     };
+#undef STAMP
+#undef STAMPS_END
 
     for (int k = N - 1; k >= 1; k--) stage(k, cN, k == N - 1);
     stage(0, c0, false);
@@ -1326,8 +1362,9 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
         double zi[m], zj[m];
 #pragma unroll
         for (int l = 0; l < m; l++) { zi[l] = L[oZi + l * n]; zj[l] = L[oZj + l * n]; }
-        tail(0, zi, zj, L[oPin], L[oGd]);
+        tail(0, zi, zj);
     }
+    L[wGd] = gdR;
     if (!okall) *fail = 1.0;
     K.sync();
     (void)pf;

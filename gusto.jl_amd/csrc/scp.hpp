@@ -305,7 +305,7 @@ GD int sched_pop(const KParams& P, bool& cont) {
 
 template <int MODEL, bool ONEWAVE> __global__ void __launch_bounds__(ONEWAVE ? 64 : 256, ONEWAVE ? MT<MODEL>::WAVES_PER_EU : 1)
 scp_kernel(const KParams P) {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int slot = blockIdx.x;
     for (;;) {
         int b = 0, ci = 0;

@@ -4,5 +4,5 @@ M=${1:-0}; shift
 cd $GRAFT_REPO_ROOT
 cp gusto.jl_amd/libgusto_hip.so /tmp/lib_keep.so
 tools/build_dev.sh $M -DGUSTO_PROFILE "$@" > /dev/null 2>&1
-python tools/gpu_prof.py 4096 $M 2>&1 | grep -v "^  -\|F[0-9]:\|F:" 
+python tools/gpu_prof.py 4096 $M 2>&1 | cat
 cp /tmp/lib_keep.so gusto.jl_amd/libgusto_hip.so
