@@ -21,8 +21,12 @@
 #endif
 
 #define NX GO_MAXN
-#define NU GO_MAXM
-#define NZ (GO_MAXN + GO_MAXM)
+#define NU (GO_MAXM + GO_MAXN)   /* TrajOpt: controls (u, d), d = the n defect variables of a knot */
+#define NZ (GO_MAXN + GO_MAXM + GO_MAXN)
+/* TrajOpt: the defect variables carry the vanishing quadratic cost REG * dt * |d_k|^2 next to their L1 penalty mu |d_k|_1: an
+ * L1 term alone leaves a defect that is off its kink without curvature, the Newton systems of the interior point method
+ * then lose the goal rows at complementarity 1e-9 (LP-like degeneracy).  DESIGN.md section 4. */
+#define GO_TRAJOPT_DEFECT_REG 1e-4
 #define ROW_HARD 0     /* hard inequality  (scp_gusto.jl:213-221, 236-245)                  */
 #define ROW_PEN 1      /* L1-penalised state inequality, part of the post-check (:281-295)  */
 #define ROW_PEN_TR 2   /* L1-penalised trust region (:265-279), not part of the post-check  */
@@ -71,6 +75,13 @@ struct go_problem {
     double mug[NX], mugn[NX];
     double Gd[NX * NX];
     int warm; /* the previous subproblem of this problem's SCP run ended GO_SOLVER_OPTIMAL */
+    /* TrajOpt variant (scp_trajopt.jl): m = m0 + n, the last n "controls" of a knot are the defect d_k of the interval
+     * (k, k+1): x_{k+1} - x_k - dt/2 (a_k + a_{k+1}) = d_k is a hard row, mu |d_k|_1 the L1 penalty of the dynamics */
+    int trajopt, m0;
+    go_trajopt_params tp;
+    double to_mu, to_s;
+    int n_solves, n_mu, n_xtol, n_ftol, n_ctol, to_cap;
+    double *s_vec, *mu_vec, *xtol_vec, *ftol_vec, *ctol_vec;
 };
 
 /* ------------------------------------------------------------------------------------------ */
@@ -137,7 +148,7 @@ static int inv_gj(double* Ainv, const double* A, int n) {
 }
 /* Cholesky S = L L^T; returns Li = L^{-1} (lower) and Sinv = Li^T Li; 0 ok, -1 not positive definite */
 static int chol_inv(double* Sinv, double* Li, const double* S, int n) {
-    double L[NX * NX];
+    double L[NU * NU];   /* (n <= NU: the control block of the TrajOpt variant is (m + n) x (m + n)) */
     memset(L, 0, sizeof(L));
     for (int j = 0; j < n; j++) {
         double d = S[j * n + j];
@@ -170,7 +181,7 @@ static int chol_inv(double* Sinv, double* Li, const double* S, int n) {
     return 0;
 }
 static int inv_spd(double* Sinv, const double* S, int n) {
-    double Li[NX * NX];
+    double Li[NU * NU];
     return chol_inv(Sinv, Li, S, n);
 }
 
@@ -246,7 +257,7 @@ static void cross3(double* c, const double* a, const double* b) {
     c[2] = a[0] * b[1] - a[1] * b[0];
 }
 void go_dynamics(const go_problem* p, const double* x, const double* u, double* f, double* A, double* B) {
-    const int n = p->n, m = p->m;
+    const int n = p->n, m = p->m;   /* (TrajOpt: B has m = m0 + n columns, the defect columns stay zero) */
     const go_model_params* mp = &p->mp;
     if (A) memset(A, 0, sizeof(double) * n * n);
     if (B) memset(B, 0, sizeof(double) * n * m);
@@ -612,6 +623,69 @@ static void assemble_rows(go_problem* p, const double* Xp, double Delta, double 
     p->row_start[N] = p->nrows;
 }
 
+/* Rows of the TrajOpt subproblem around Xp (scp_trajopt.jl:159-279), same registry, different treatment:
+ *   hard       : state trust region  ||x_k - xp_k||^2 - s <= 0                      (:165-173)
+ *   penalised  : mu * g <= v, v >= 0, cost += v  for convex_state_ineq, nonconvex_state_convexified_ineq AND
+ *                convex_control_ineq (hard in GuSTO)                                (:222-235)
+ *   dynamics   : mu * |d_kj| as the pair  +-mu d_kj <= v  on the defect variables    (:257-275; as written there the pair of
+ *                auxiliary variables is free and the subproblem unbounded below: the L1 form of the equality branch :238-246
+ *                is what it means -- DESIGN.md section 4)
+ * Boundary rows (x_1 = x_init, goals) stay hard as in GuSTO.  `kappa` = 1/max(1, mu) rescales the objective. */
+static void assemble_rows_trajopt(go_problem* p, const double* Xp, double s_tr, double mu, double toggle, double kappa) {
+    const int n = p->n, N = p->N, d = ws_dim(p), m0 = p->m0;
+    const go_model_params* mp = &p->mp;
+    const int is2 = p->model == GO_FREEFLYER_SE2, man = p->model == GO_ASTROBEE_SE3_MANIFOLD;
+    const int nv = is2 ? 2 : 3, iw = is2 ? 5 : (man ? 10 : 9), nw = is2 ? 1 : 3;
+    p->nrows = 0;
+    for (int k = 0; k < N; k++) {
+        p->row_start[k] = p->nrows;
+        const double* xp = Xp + k * n;
+        go_row* r;
+        r = new_row(p, k, 0, ROW_HARD);   /* stri_state_trust_region - s <= 0, normalised by s */
+        for (int j = 0; j < n; j++) row_add(r, j, 1.0, xp[j], 0.0);
+        r->c0 = -s_tr; r->mul = 1.0 / s_tr;
+        r = new_row(p, k, 0, ROW_PEN);    /* csi_translational_velocity_bound */
+        for (int j = 0; j < nv; j++) row_add(r, 3 + j, 1.0, 0.0, 0.0);
+        r->c0 = -mp->hard_limit_vel * mp->hard_limit_vel; r->mul = kappa * mu;
+        r = new_row(p, k, 0, ROW_PEN);    /* csi_angular_velocity_bound */
+        for (int j = 0; j < nw; j++) row_add(r, iw + j, 1.0, 0.0, 0.0);
+        r->c0 = -mp->hard_limit_omega * mp->hard_limit_omega; r->mul = kappa * mu;
+        for (int i = 0; i < p->n_obs; i++) {   /* ncsi_*_convexified, active inside obstacle_toggle_distance = clearance + 1 (:65) */
+            double nh[3];
+            double dist = go_signed_distance(p, 0, xp, i, nh);
+            if (dist < toggle) {
+                r = new_row(p, k, 0, ROW_PEN);
+                double c0 = mp->clearance - dist;
+                for (int j = 0; j < d; j++) { row_add(r, j, 0.0, 0.0, -nh[j]); c0 += nh[j] * xp[j]; }
+                r->c0 = c0; r->mul = kappa * mu;
+            }
+        }
+        if (k < N - 1) {   /* cci_*_accel_bound, penalised here */
+            const int nf = is2 ? 2 : 3, im = is2 ? 2 : 3, nm = is2 ? 1 : 3;
+            r = new_row(p, k, 1, ROW_PEN);
+            for (int j = 0; j < nf; j++) row_add(r, j, 1.0 / (mp->mass * mp->mass), 0.0, 0.0);
+            r->c0 = -mp->hard_limit_accel * mp->hard_limit_accel; r->mul = kappa * mu;
+            r = new_row(p, k, 1, ROW_PEN);
+            for (int j = 0; j < nm; j++) { double ji = 1.0 / mp->Jdiag[is2 ? 2 : j]; row_add(r, im + j, ji * ji, 0.0, 0.0); }
+            r->c0 = -mp->hard_limit_alpha * mp->hard_limit_alpha; r->mul = kappa * mu;
+        }
+        for (int j = 0; j < n; j++) {   /* mu |d_kj|: d_k of the last knot moves nothing and is driven to zero */
+            r = new_row(p, k, 1, ROW_PEN); row_add(r, m0 + j, 0.0, 0.0, 1.0); r->mul = kappa * mu;
+            r = new_row(p, k, 1, ROW_PEN); row_add(r, m0 + j, 0.0, 0.0, -1.0); r->mul = kappa * mu;
+        }
+        if (k == N - 1) {   /* csbci_goal_constraints (BoxGoal): hard, as in GuSTO */
+            for (int i = 0; i < n; i++) {
+                double lo = p->goal_lo[i], hi = p->goal_hi[i];
+                if (lo == hi) continue;
+                double sc = 1.0 / fmax(1e-3, fmin(1.0, (isfinite(hi) && isfinite(lo)) ? 0.5 * (hi - lo) : 1.0));
+                if (isfinite(hi)) { r = new_row(p, k, 0, ROW_HARD); row_add(r, i, 0.0, 0.0, 1.0); r->c0 = -hi; r->mul = sc; }
+                if (isfinite(lo)) { r = new_row(p, k, 0, ROW_HARD); row_add(r, i, 0.0, 0.0, -1.0); r->c0 = lo; r->mul = sc; }
+            }
+        }
+    }
+    p->row_start[N] = p->nrows;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* linearisation: initialize_model_params!/update_model_params! (freeflyer_se2.jl:116-147 etc.)  */
 static void linearize(go_problem* p, const double* Xp, const double* Up) {
@@ -646,6 +720,10 @@ static void linearize(go_problem* p, const double* Xp, const double* Up) {
             mm(Gam, Phi, p->bm + k * n * m, n, n, m);
             for (int i = 0; i < n * m; i++) Gam[i] += p->bm[k * n * m + i];
         }
+        /* TrajOpt: y_k := F_k x_k + b_k u_k + d_k, so the defect moves dy_k directly (Gam_d = I) and not x_k (b_d = 0) */
+        if (p->trajopt)
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < n; j++) Gam[i * m + p->m0 + j] = (i == j) ? 1.0 : 0.0;
     }
     if (ek != e) free(ek);
 }
@@ -912,7 +990,8 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
         if (p->goal_lo[i] == p->goal_hi[i]) { gidx[ng] = i; gval[ng] = p->goal_lo[i]; ng++; }
 
     linearize(p, Xp, Up);
-    assemble_rows(p, Xp, Delta, omega, toggle, kappa);
+    if (p->trajopt) assemble_rows_trajopt(p, Xp, Delta /* s */, omega /* mu */, toggle, kappa);
+    else assemble_rows(p, Xp, Delta, omega, toggle, kappa);
     const int nr = p->nrows;
     double *X = p->Xw, *U = p->Uw;
     memcpy(X, Xp, sizeof(double) * n * N);
@@ -963,6 +1042,7 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
                 double s = p->hk[k * n + i];
                 for (int j = 0; j < n; j++) s += F[i * n + j] * X[(k - 1) * n + j] - G[i * n + j] * X[k * n + j];
                 for (int j = 0; j < m; j++) s += b0[i * m + j] * U[(k - 1) * m + j] + b1[i * m + j] * U[k * m + j];
+                if (p->trajopt) s += U[(k - 1) * m + p->m0 + i];   /* + d_{k-1}: the defect of the interval (k-1, k) */
                 p->rd[k * n + i] = s;
                 if (fabs(s) > res_p) res_p = fabs(s);
             }
@@ -987,13 +1067,23 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
             if (fabs(p->rrp[i]) > res_p) res_p = fabs(p->rrp[i]);
         }
         mu = ncomp ? comp / ncomp : 0.0;
+        if (getenv("GO_DEBUG_IPM")) {
+            double mrd = 0, mrp = 0; int arg = -1;
+            for (int i = n; i < n * N; i++) if (fabs(p->rd[i]) > mrd) mrd = fabs(p->rd[i]);
+            for (int i = 0; i < nr; i++) if (fabs(p->rrp[i]) > mrp) { mrp = fabs(p->rrp[i]); arg = i; }
+            fprintf(stderr, "it %d: rd %.3e rp %.3e (row %d k %d kind %d isu %d g %.3e t %.3e s %.3e lam %.3e lamb %.3e) mu %.3e\n", it, mrd, mrp, arg,
+                    arg >= 0 ? p->rows[arg].k : -1, arg >= 0 ? p->rows[arg].kind : -1, arg >= 0 ? p->rows[arg].isu : -1, arg >= 0 ? p->rg[arg] : 0,
+                    arg >= 0 ? p->rt[arg] : 0, arg >= 0 ? p->rs[arg] : 0, arg >= 0 ? p->rlam[arg] : 0, arg >= 0 ? p->rlamb[arg] : 0, mu);
+        }
         /* dual residual: grad f + J^T lam + E^T nu ------------------------------------------ */
         res_d = 0;
         double numax = 0;
         for (int k = 0; k < N; k++) {
             double dx[NX], du[NU];
             memset(dx, 0, sizeof(dx));
-            for (int i = 0; i < m; i++) du[i] = 2 * wk[k] * U[k * m + i];
+            for (int i = 0; i < m; i++) du[i] = 2 * wk[k] * ((i < p->m0) ? 1.0 : GO_TRAJOPT_DEFECT_REG) * U[k * m + i];
+            if (p->trajopt && k + 1 < N)
+                for (int i = 0; i < n; i++) du[p->m0 + i] += p->nu[(k + 1) * n + i];
             for (int i = p->row_start[k]; i < p->row_start[k + 1]; i++) {
                 go_row* r = &p->rows[i];
                 const double* v = (r->isu ? U + k * m : X + k * n);
@@ -1013,11 +1103,20 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
             }
             if (k == N - 1)
                 for (int j = 0; j < ng; j++) dx[gidx[j]] += p->mug[j];
+            if (getenv("GO_DEBUG_IPM")) {
+                static double mx, mu_, md; static int kx, ku, kd;
+                if (k == 0) { mx = mu_ = md = 0; kx = ku = kd = -1; }
+                if (k > 0) for (int i = 0; i < n; i++) if (fabs(dx[i]) > mx) { mx = fabs(dx[i]); kx = k; }
+                for (int i = 0; i < p->m0; i++) if (fabs(du[i]) > mu_) { mu_ = fabs(du[i]); ku = k; }
+                for (int i = p->m0; i < m; i++) if (fabs(du[i]) > md) { md = fabs(du[i]); kd = k; }
+                if (k == N - 1) fprintf(stderr, "   res_d: x %.3e (k %d)  u %.3e (k %d)  d %.3e (k %d)\n", mx, kx, mu_, ku, md, kd);
+            }
             if (k > 0)
                 for (int i = 0; i < n; i++) if (fabs(dx[i]) > res_d) res_d = fabs(dx[i]);
             for (int i = 0; i < m; i++) if (fabs(du[i]) > res_d) res_d = fabs(du[i]);
             for (int i = 0; i < n; i++) if (fabs(p->nu[k * n + i]) > numax) numax = fabs(p->nu[k * n + i]);
         }
+        if (getenv("GO_DEBUG_IPM")) fprintf(stderr, "   test: res_p %.3e res_d %.3e numax %.3e mu %.3e tol %.3e\n", res_p, res_d, numax, mu, io->tol);
         if (res_p <= io->tol && res_d <= io->tol * (1 + numax) && mu <= 0.1 * io->tol) { status = GO_SOLVER_OPTIMAL; break; }
         if (it >= io->max_iter) {
             if (res_p <= io->tol_acc && res_d <= io->tol_acc * (1 + numax) && mu <= io->tol_acc) status = GO_SOLVER_ALMOST;
@@ -1029,7 +1128,7 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
         memset(p->Hx, 0, sizeof(double) * n * n * N);
         memset(p->Hu, 0, sizeof(double) * m * m * N);
         for (int k = 0; k < N; k++)
-            for (int i = 0; i < m; i++) p->Hu[k * m * m + i * m + i] = 2 * wk[k];
+            for (int i = 0; i < m; i++) p->Hu[k * m * m + i * m + i] = 2 * wk[k] * ((i < p->m0) ? 1.0 : GO_TRAJOPT_DEFECT_REG);
         for (int i = 0; i < nr; i++) {
             go_row* r = &p->rows[i];
             const int k = r->k, dim = r->isu ? m : n;
@@ -1055,7 +1154,7 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
             /* pass 0: affine-scaling predictor (mu_t = 0); pass 1: centred corrector */
             memset(p->gx, 0, sizeof(double) * n * N);
             for (int k = 0; k < N; k++)
-                for (int i = 0; i < m; i++) p->gu[k * m + i] = 2 * wk[k] * U[k * m + i];
+                for (int i = 0; i < m; i++) p->gu[k * m + i] = 2 * wk[k] * ((i < p->m0) ? 1.0 : GO_TRAJOPT_DEFECT_REG) * U[k * m + i];
             for (int i = 0; i < nr; i++) {
                 go_row* r = &p->rows[i];
                 const int k = r->k;
@@ -1117,6 +1216,7 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
             }
             alpha = a_max;
         }
+        if (getenv("GO_DEBUG_IPM")) fprintf(stderr, "      alpha %.3e sigma %.3e\n", alpha, sigma);
         /* update */
         for (int i = 0; i < n * N; i++) X[i] += alpha * p->dX[i];
         for (int i = 0; i < m * N; i++) U[i] += alpha * p->dU[i];
@@ -1131,7 +1231,7 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
     }
     double obj = 0;
     for (int k = 0; k < N; k++)
-        for (int i = 0; i < m; i++) obj += wk[k] * U[k * m + i] * U[k * m + i];
+        for (int i = 0; i < m; i++) obj += wk[k] * ((i < p->m0) ? 1.0 : GO_TRAJOPT_DEFECT_REG) * U[k * m + i] * U[k * m + i];
     for (int i = 0; i < nr; i++)
         if (!(p->rows[i].kind == ROW_HARD || p->rows[i].kind == ROW_HARD_EQ)) obj += p->rs[i];
     info->obj = obj / kappa;
@@ -1145,7 +1245,7 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
 double go_cost_true(const go_problem* p, const double* U) { /* freeflyer_se2.jl:66-76 */
     double J = 0;
     for (int k = 1; k < p->N; k++)
-        for (int j = 0; j < p->m; j++)
+        for (int j = 0; j < p->m0; j++)   /* (TrajOpt: U rows hold (u, d); only u is costed) */
             J += 0.5 * p->dt * (U[(k - 1) * p->m + j] * U[(k - 1) * p->m + j] + U[k * p->m + j] * U[k * p->m + j]);
     return J;
 }
@@ -1235,11 +1335,13 @@ void go_init_straightline(const go_problem* p, double* X, double* U) { /* freefl
 
 /* ------------------------------------------------------------------------------------------ */
 #define ALLOC(ptr, count) ptr = calloc((size_t)(count), sizeof(*(ptr)))
-go_problem* go_create(int model, int N, const go_scp_params* sp, const go_model_params* mp, int n_box,
-                      const double* box, int n_sph, const double* sph) {
+static go_problem* create_impl(int model, int N, const go_scp_params* sp, const go_model_params* mp, int n_box,
+                               const double* box, int n_sph, const double* sph, int trajopt) {
     int n, m;
     if (go_model_dims(model, &n, &m) || N < 3 || N > 256) return NULL;
     go_problem* p = calloc(1, sizeof(*p));
+    p->m0 = m; p->trajopt = trajopt;
+    if (trajopt) m += n;   /* controls (u, d) */
     p->model = model; p->n = n; p->m = m; p->N = N;
     p->sp = *sp; p->mp = *mp;
     go_default_ipm_opts(&p->io);
@@ -1266,6 +1368,10 @@ go_problem* go_create(int model, int N, const go_scp_params* sp, const go_model_
     ALLOC(p->dX, n * N); ALLOC(p->dU, m * N); ALLOC(p->nun, n * N); ALLOC(p->nu, n * N); ALLOC(p->Xw, n * N); ALLOC(p->Uw, m * N);
     return p;
 }
+go_problem* go_create(int model, int N, const go_scp_params* sp, const go_model_params* mp, int n_box,
+                      const double* box, int n_sph, const double* sph) {
+    return create_impl(model, N, sp, mp, n_box, box, n_sph, sph, 0);
+}
 static void free_hist(go_problem* p) {
     free(p->J_true); free(p->J_full); free(p->conv); free(p->Delta); free(p->omega); free(p->rho);
     free(p->accept); free(p->scp_status); free(p->solver_status); free(p->tr_sat); free(p->cvx_sat); free(p->ipm_it);
@@ -1284,6 +1390,7 @@ void go_destroy(go_problem* p) {
     free(p->Ps); free(p->ps); free(p->Pis); free(p->Ks); free(p->Sinv); free(p->Ds); free(p->d0s);
     free(p->dX); free(p->dU); free(p->nun); free(p->nu); free(p->Xw); free(p->Uw);
     free(p->trXp); free(p->trUp); free(p->trXn); free(p->trUn);
+    free(p->s_vec); free(p->mu_vec); free(p->xtol_vec); free(p->ftol_vec); free(p->ctol_vec);
     free(p);
 }
 void go_set_ipm_opts(go_problem* p, const go_ipm_opts* o) { p->io = *o; }
@@ -1651,6 +1758,227 @@ int go_subproblem(go_problem* p, const double* Xp, const double* Up, double Delt
     if (dual) memcpy(dual, p->dual, sizeof(double) * p->n);
     return st;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* TrajOpt (src/scp/scp_trajopt.jl)                                                               */
+void go_default_trajopt_params(int model, go_trajopt_params* tp) {
+    memset(tp, 0, sizeof(*tp));
+    tp->mu0 = 1.0; tp->c = 10.0; tp->tau_plus = 2.0; tp->tau_minus = 0.5; tp->k = 5.0; tp->ftol = 0.01; tp->ctol = 0.01;
+    tp->max_penalty_iteration = 5; tp->max_convex_iteration = 5; tp->max_trust_iteration = 5;
+    if (model == GO_FREEFLYER_SE2) { tp->s0 = 1.0; tp->xtol = 0.1; }   /* freeflyer_se2.jl:49-64 */
+    else { tp->s0 = 10.0; tp->xtol = 0.01; }                            /* astrobee_se3.jl:50-65  */
+}
+go_problem* go_create_trajopt(int model, int N, const go_model_params* mp, const go_trajopt_params* tp, int n_box,
+                              const double* box, int n_sph, const double* sph) {
+    if (model != GO_FREEFLYER_SE2 && model != GO_ASTROBEE_SE3) return NULL;
+    go_scp_params sp; go_model_params dmp;
+    go_default_params(model, &sp, &dmp);
+    go_problem* p = create_impl(model, N, &sp, mp ? mp : &dmp, n_box, box, n_sph, sph, 1);
+    if (!p) return NULL;
+    if (tp) p->tp = *tp; else go_default_trajopt_params(model, &p->tp);
+    return p;
+}
+int go_trajopt_subproblem(go_problem* p, const double* Xp, const double* Up, double mu, double s, double* Xn, double* Un,
+                          double* dual, go_sub_info* info) {
+    if (!p->trajopt) return -1;
+    p->warm = 0;
+    int st = ipm_solve(p, Xp, Up, s, mu, p->mp.clearance + 1.0, info);
+    memcpy(Xn, p->Xw, sizeof(double) * p->n * p->N);
+    memcpy(Un, p->Uw, sizeof(double) * p->m * p->N);
+    if (dual) memcpy(dual, p->dual, sizeof(double) * p->n);
+    return st;
+}
+/* trust_region_ratio_trajopt (freeflyer_se2.jl:429-467, astrobee_se3.jl:419-460).  As written the dynamics terms read
+ * (Xp[:,k]-Xp[:,k])/dtp -- zero -- and call a 5-argument dynamics_constraints that does not exist; what is meant is the
+ * forward difference (X[:,k+1]-X[:,k])/dt and the linearised trapezoid defect of interval k.  The obstacle terms take the
+ * linearisation at traj_prev, as in trust_region_ratio_gusto (the file evaluates distance and normal at the new point). */
+double go_trajopt_ratio(go_problem* p, const double* X, const double* U, const double* Xp, const double* Up) {
+    const int n = p->n, m = p->m, N = p->N, d = ws_dim(p);
+    double num = 0, den = 0;
+    double f[NX], fp[NX], fp1[NX], A[NX * NX], A1[NX * NX], B[NX * NU], B1[NX * NU], a0[NX], a1[NX];
+    for (int k = 0; k < N - 1; k++) {
+        go_dynamics(p, Xp + k * n, Up + k * m, fp, A, B);
+        go_dynamics(p, Xp + (k + 1) * n, Up + (k + 1) * m, fp1, A1, B1);
+        go_dynamics(p, X + k * n, U + k * m, f, NULL, NULL);
+        double po = 0, pn = 0, ph = 0;
+        for (int i = 0; i < n; i++) {
+            a0[i] = fp[i]; a1[i] = fp1[i];
+            for (int j = 0; j < n; j++) {
+                a0[i] += A[i * n + j] * (X[k * n + j] - Xp[k * n + j]);
+                a1[i] += A1[i * n + j] * (X[(k + 1) * n + j] - Xp[(k + 1) * n + j]);
+            }
+            for (int j = 0; j < p->m0; j++) {
+                a0[i] += B[i * m + j] * (U[k * m + j] - Up[k * m + j]);
+                a1[i] += B1[i * m + j] * (U[(k + 1) * m + j] - Up[(k + 1) * m + j]);
+            }
+        }
+        for (int i = 0; i < n; i++) {
+            po += fabs(fp[i] - (Xp[(k + 1) * n + i] - Xp[k * n + i]) / p->dt);
+            pn += fabs(f[i] - (X[(k + 1) * n + i] - X[k * n + i]) / p->dt);
+            ph += fabs(X[(k + 1) * n + i] - X[k * n + i] - 0.5 * p->dt * (a0[i] + a1[i]));
+        }
+        num += po - pn; den += po - ph;
+    }
+    for (int k = 0; k < N; k++) {
+        const double *r0 = Xp + k * n, *r = X + k * n;
+        for (int c = 0; c < p->mp.n_robot_comp; c++)
+            for (int i = 0; i < p->n_obs; i++) {
+                double nh[3];
+                const double d0 = go_signed_distance(p, c, r0, i, nh), d1 = go_signed_distance(p, c, r, i, NULL);
+                double lin = d0;
+                for (int j = 0; j < d; j++) lin += nh[j] * (r[j] - r0[j]);
+                const double po = p->mp.clearance - d0, pn = p->mp.clearance - d1, ph = p->mp.clearance - lin;
+                num += po - pn; den += po - ph;
+            }
+    }
+    return num / den;
+}
+/* evaluate_ctol (scp_trajopt.jl:289-312): per class of constraints the largest change and the largest value over its
+ * members, summed over the classes.  (As written the class entered last is never added; every class counts here.) */
+static void defect_true(go_problem* p, const double* X, const double* U, int k, double* F) {
+    double f0[NX], f1[NX];
+    go_dynamics(p, X + k * p->n, U + k * p->m, f0, NULL, NULL);
+    go_dynamics(p, X + (k + 1) * p->n, U + (k + 1) * p->m, f1, NULL, NULL);
+    for (int i = 0; i < p->n; i++) F[i] = X[(k + 1) * p->n + i] - X[k * p->n + i] - 0.5 * p->dt * (f0[i] + f1[i]);
+}
+double go_trajopt_ctol(go_problem* p, const double* X, const double* U, const double* Xp, const double* Up) {
+    const int n = p->n, N = p->N;
+    const int is2 = p->model == GO_FREEFLYER_SE2, nv = is2 ? 2 : 3, iw = is2 ? 5 : 9, nw = is2 ? 1 : 3;
+    double JN = 0, JD = 0, tn, td;
+    /* csi_translational_velocity_bound, csi_angular_velocity_bound */
+    for (int cls = 0; cls < 2; cls++) {
+        tn = td = 0;
+        const int i0 = cls ? iw : 3, cnt = cls ? nw : nv;
+        const double lim = cls ? p->mp.hard_limit_omega : p->mp.hard_limit_vel;
+        for (int k = 0; k < N; k++) {
+            double g = -lim * lim, gp = -lim * lim;
+            for (int j = 0; j < cnt; j++) { g += X[k * n + i0 + j] * X[k * n + i0 + j]; gp += Xp[k * n + i0 + j] * Xp[k * n + i0 + j]; }
+            tn = fmax(tn, fabs(g - gp)); td = fmax(td, fabs(g));
+        }
+        JN += tn; JD += td;
+    }
+    /* ncsi_body_obstacle_avoidance_constraints: clearance - dist */
+    if (p->n_obs > 0) {
+        tn = td = 0;
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < p->n_obs; i++) {
+                const double g = p->mp.clearance - go_signed_distance(p, 0, X + k * n, i, NULL);
+                const double gp = p->mp.clearance - go_signed_distance(p, 0, Xp + k * n, i, NULL);
+                tn = fmax(tn, fabs(g - gp)); td = fmax(td, fabs(g));
+            }
+        JN += tn; JD += td;
+    }
+    /* csbci_goal_constraints (BoxGoal rows, :array) */
+    {
+        double a = 0, b = 0; int any = 0;
+        for (int i = 0; i < n; i++) {
+            const double lo = p->goal_lo[i], hi = p->goal_hi[i];
+            if (lo == hi) continue;
+            const double x = X[(N - 1) * n + i], xq = Xp[(N - 1) * n + i];
+            if (isfinite(hi)) { a += (x - xq) * (x - xq); b += (x - hi) * (x - hi); any = 1; }
+            if (isfinite(lo)) { a += (x - xq) * (x - xq); b += (lo - x) * (lo - x); any = 1; }
+        }
+        if (any) { JN += sqrt(a); JD += sqrt(b); }
+    }
+    /* dynamics_constraints(traj, traj, k): the trapezoid defect of the trajectory itself */
+    tn = td = 0;
+    for (int k = 0; k < N - 1; k++) {
+        double F[NX], Fp[NX], a = 0, b = 0;
+        defect_true(p, X, U, k, F); defect_true(p, Xp, Up, k, Fp);
+        for (int i = 0; i < n; i++) { a += (F[i] - Fp[i]) * (F[i] - Fp[i]); b += F[i] * F[i]; }
+        tn = fmax(tn, sqrt(a)); td = fmax(td, sqrt(b));
+    }
+    JN += tn; JD += td;
+    return JN / JD;
+}
+static void to_grow(go_problem* p, int need) {
+    if (need <= p->to_cap) return;
+    const int c = need + 64;
+    p->s_vec = realloc(p->s_vec, sizeof(double) * c); p->mu_vec = realloc(p->mu_vec, sizeof(double) * c);
+    p->xtol_vec = realloc(p->xtol_vec, sizeof(double) * c); p->ftol_vec = realloc(p->ftol_vec, sizeof(double) * c);
+    p->ctol_vec = realloc(p->ctol_vec, sizeof(double) * c);
+    p->to_cap = c;
+}
+int go_solve_trajopt(go_problem* p, int max_iter) {
+    if (!p->trajopt) return -1;
+    const int n = p->n, m = p->m, N = p->N;
+    const go_trajopt_params* tp = &p->tp;
+    const int total = tp->max_penalty_iteration * tp->max_convex_iteration * tp->max_trust_iteration;
+    const size_t nx = sizeof(double) * n * N, nu = sizeof(double) * m * N;
+    grow_hist(p, p->n_hist + p->nJ_true + total + 8);
+    to_grow(p, 2 * total + 16);
+    /* SCPParam_TrajOpt ctor (:25-28): rho_vec = [0.], mu_vec = [mu0], s_vec = [s0], xtol_vec = ftol_vec = ctol_vec = [0.] */
+    p->n_solves = 0; p->n_mu = 1; p->n_xtol = 1; p->n_ftol = 1; p->n_ctol = 1;
+    p->mu_vec[0] = tp->mu0; p->s_vec[0] = tp->s0; p->xtol_vec[0] = p->ftol_vec[0] = p->ctol_vec[0] = 0.0;
+    p->n_rho = 1; p->rho[0] = 0.0;
+    double *Xn = malloc(nx), *Un = malloc(nu), *Xpen = malloc(nx), *Upen = malloc(nu), *Xcvx = malloc(nx), *Ucvx = malloc(nu);
+    p->J_true[p->nJ_true++] = go_cost_true(p, p->U);                                   /* :63 */
+    p->toggle = p->mp.clearance + 1.0;                                                  /* :64 */
+    int constraints_satisfied = 0, xtol_satisfied = 0, solves = 0, stop = 0;
+    p->stop_reason = GO_STOP_MAXITER;
+    for (int pi = 0; pi < tp->max_penalty_iteration && !stop; pi++) {
+        if (constraints_satisfied) break;
+        memcpy(Xpen, p->X, nx); memcpy(Upen, p->U, nu);                                /* :73 (old_penalty_traj: a copy, not the alias of :67) */
+        for (int ci = 0; ci < tp->max_convex_iteration && !stop; ci++) {
+            memcpy(Xcvx, p->X, nx); memcpy(Ucvx, p->U, nu);                            /* :76 */
+            if (constraints_satisfied) break;
+            if (xtol_satisfied) { xtol_satisfied = 0; break; }
+            for (int ti = 0; ti < tp->max_trust_iteration; ti++) {
+                if (solves >= max_iter) { stop = 1; break; }
+                const double mu = p->mu_vec[p->n_mu - 1], s = p->s_vec[p->n_solves];
+                go_sub_info info;
+                p->warm = 0;
+                const int st = ipm_solve(p, p->X, p->U, s, mu, p->toggle, &info);      /* :98-110 */
+                const int h = p->n_hist;
+                p->solver_status[h] = st; p->ipm_it[h] = info.iters; p->total_ipm += info.iters;
+                if (st != GO_SOLVER_OPTIMAL && st != GO_SOLVER_ALMOST) {                /* (:113-116 warns and goes on with the values) */
+                    p->stop_reason = GO_STOP_SUBPROBLEM_FAILED; stop = 1; break;
+                }
+                memcpy(Xn, p->Xw, nx); memcpy(Un, p->Uw, nu);
+                const double xt = go_convergence_metric(p, Xn, Xcvx);                   /* evaluate_xtol :120-121 */
+                p->xtol_vec[p->n_xtol++] = xt; p->conv[h] = xt;
+                p->J_full[p->nJ_full++] = info.obj;                                     /* :122 */
+                const double rho = go_trajopt_ratio(p, Xn, Un, Xcvx, Ucvx);             /* :127 */
+                p->rho[p->n_rho++] = rho;
+                p->s_vec[p->n_solves + 1] = (rho > tp->c) ? tp->tau_plus * s : tp->tau_minus * s;   /* :128-132 */
+                memcpy(p->X, Xn, nx); memcpy(p->U, Un, nu);                             /* :134: every step is taken */
+                p->J_true[p->nJ_true++] = go_cost_true(p, p->U);
+                p->n_hist = h + 1; p->n_solves++; p->iterations++; solves++;
+                if (p->s_vec[p->n_solves] < tp->xtol) { xtol_satisfied = 1; break; }    /* :140-143 */
+            }
+            if (stop) break;
+            const double Jn = go_cost_true(p, p->U), Jo = go_cost_true(p, Ucvx);
+            p->ftol_vec[p->n_ftol++] = fabs(Jn - Jo) / fabs(Jn);                        /* evaluate_ftol :146 */
+            p->xtol_vec[p->n_xtol++] = go_convergence_metric(p, p->X, Xcvx);            /* :147 */
+            if (p->ftol_vec[p->n_ftol - 1] < tp->ftol || p->xtol_vec[p->n_xtol - 1] < tp->xtol) {   /* :148 (`xtol[end]` means xtol_vec[end]) */
+                constraints_satisfied = 1; break;
+            }
+        }
+        if (stop) break;
+        const double ct = go_trajopt_ctol(p, p->X, p->U, Xpen, Upen);                   /* :155 */
+        p->ctol_vec[p->n_ctol++] = ct;
+        if (ct < tp->ctol) { constraints_satisfied = 1; p->converged = 1; p->stop_reason = GO_STOP_CONVERGED; break; }
+        p->mu_vec[p->n_mu] = p->mu_vec[p->n_mu - 1] * tp->k; p->n_mu++;                 /* :161 */
+    }
+    free(Xn); free(Un); free(Xpen); free(Upen); free(Xcvx); free(Ucvx);
+    return solves;
+}
+int go_get_trajopt_history(const go_problem* p, double* s_vec, int* n_s, double* mu_vec, int* n_mu, double* xtol_vec, int* n_xtol,
+                           double* ftol_vec, int* n_ftol, double* ctol_vec, int* n_ctol) {
+    if (!p->trajopt) return -1;
+    if (n_s) *n_s = p->n_solves + 1;
+    if (n_mu) *n_mu = p->n_mu;
+    if (n_xtol) *n_xtol = p->n_xtol;
+    if (n_ftol) *n_ftol = p->n_ftol;
+    if (n_ctol) *n_ctol = p->n_ctol;
+    if (s_vec) memcpy(s_vec, p->s_vec, sizeof(double) * (p->n_solves + 1));
+    if (mu_vec) memcpy(mu_vec, p->mu_vec, sizeof(double) * p->n_mu);
+    if (xtol_vec) memcpy(xtol_vec, p->xtol_vec, sizeof(double) * p->n_xtol);
+    if (ftol_vec) memcpy(ftol_vec, p->ftol_vec, sizeof(double) * p->n_ftol);
+    if (ctol_vec) memcpy(ctol_vec, p->ctol_vec, sizeof(double) * p->n_ctol);
+    return 0;
+}
+
 int go_rows_count(const go_problem* p) { return p->nrows; }
 int go_rows_get(const go_problem* p, int i, int* k, int* isu, int* kind, int* nnz, int* idx, double* a, double* v0,
                 double* b, double* c0, double* mul, double* off, double* slack, double* lam) {

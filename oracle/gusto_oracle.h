@@ -83,6 +83,12 @@ typedef struct {
     int iters, status; /* GO_SOLVER_*                                            */
 } go_sub_info;
 
+/* SCPParam_TrajOpt (scp_trajopt.jl:3-30; per-model values freeflyer_se2.jl:49-64, astrobee_se3.jl:50-65) */
+typedef struct {
+    double mu0, s0, c, tau_plus, tau_minus, k, ftol, xtol, ctol;
+    int max_penalty_iteration, max_convex_iteration, max_trust_iteration;
+} go_trajopt_params;
+
 typedef struct go_problem go_problem;
 
 void go_default_params(int model, go_scp_params* sp, go_model_params* mp);
@@ -143,6 +149,26 @@ double go_cost_true(const go_problem* p, const double* U);
 double go_convergence_metric(const go_problem* p, const double* X, const double* Xp);
 int go_convex_ineq_satisfied(go_problem* p, const double* X, const double* Xp, const double* Up, double toggle_dist);
 void go_init_straightline(const go_problem* p, double* X, double* U);
+
+/* ---- TrajOpt (src/scp/scp_trajopt.jl), the second SCP algorithm behind the same solve_method! seam -------------------
+ * FreeflyerSE2 and AstrobeeSE3.  A TrajOpt problem keeps (u_k, d_k) per knot: U arrays have m + n columns, the last n being
+ * the defect of the interval (k, k+1) (the L1-penalised dynamics); go_model_dims still reports the model's m.
+ * What the file means where it cannot run as written is listed in DESIGN.md section 4 (intended L1 dynamics penalty,
+ * hard x_1 = x_init, index typos of trust_region_ratio_trajopt, the dropped last class of evaluate_ctol, max_iter). */
+void go_default_trajopt_params(int model, go_trajopt_params* tp);
+go_problem* go_create_trajopt(int model, int N, const go_model_params* mp, const go_trajopt_params* tp,
+                              int n_box, const double* box_min_max, int n_sph, const double* sph_c_r);
+/* one convex subproblem (:159-279) around (Xp, Up) with penalty mu and trust region s */
+int go_trajopt_subproblem(go_problem* p, const double* Xp, const double* Up, double mu, double s, double* Xn, double* Un,
+                          double* dual, go_sub_info* info);
+/* solve_trajopt_jump! (:33-157); max_iter caps the number of subproblem solves (the reference computes iter_cap and never
+ * uses it).  Returns the number of solves. */
+int go_solve_trajopt(go_problem* p, int max_iter);
+/* rho_vec / s_vec (one leading entry + one per solve), mu_vec, xtol_vec, ftol_vec, ctol_vec; any pointer may be NULL */
+int go_get_trajopt_history(const go_problem* p, double* s_vec, int* n_s, double* mu_vec, int* n_mu, double* xtol_vec, int* n_xtol,
+                           double* ftol_vec, int* n_ftol, double* ctol_vec, int* n_ctol);
+double go_trajopt_ratio(go_problem* p, const double* X, const double* U, const double* Xp, const double* Up);
+double go_trajopt_ctol(go_problem* p, const double* X, const double* U, const double* Xp, const double* Up);
 
 /* batch driver for the CPU baseline: B independent problems, OpenMP over problems.
  * x_init/goal_lo/goal_hi: [B][n]; tf: [B]; X,U out: [B][N][n], [B][N][m]; flags out [B]. */

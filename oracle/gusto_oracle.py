@@ -46,6 +46,12 @@ class DistModel(C.Structure):
                 ("pen_value", C.c_double), ("pen_band", C.c_double)]
 
 
+class TrajOptParams(C.Structure):
+    """go_trajopt_params = SCPParam_TrajOpt (scp_trajopt.jl:3-30)"""
+    _fields_ = [(k, C.c_double) for k in ("mu0", "s0", "c", "tau_plus", "tau_minus", "k", "ftol", "xtol", "ctol")] + \
+               [(k, C.c_int) for k in ("max_penalty_iteration", "max_convex_iteration", "max_trust_iteration")]
+
+
 class SubInfo(C.Structure):
     _fields_ = [("obj", C.c_double), ("res_p", C.c_double), ("res_d", C.c_double), ("mu", C.c_double),
                 ("iters", C.c_int), ("status", C.c_int)]
@@ -89,6 +95,17 @@ def lib():
                                C.POINTER(C.c_double)]
         L.go_subproblem.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp,
                                     C.POINTER(SubInfo)]
+        L.go_default_trajopt_params.argtypes = [C.c_int, C.POINTER(TrajOptParams)]
+        L.go_create_trajopt.restype = C.c_void_p
+        L.go_create_trajopt.argtypes = [C.c_int, C.c_int, C.POINTER(ModelParams), C.POINTER(TrajOptParams), C.c_int, C.c_void_p,
+                                        C.c_int, C.c_void_p]
+        L.go_trajopt_subproblem.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, C.POINTER(SubInfo)]
+        L.go_solve_trajopt.argtypes = [C.c_void_p, C.c_int]
+        L.go_get_trajopt_history.argtypes = [C.c_void_p] + [C.c_void_p] * 10
+        L.go_trajopt_ratio.restype = C.c_double
+        L.go_trajopt_ratio.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.go_trajopt_ctol.restype = C.c_double
+        L.go_trajopt_ctol.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
         L.go_rows_count.argtypes = [C.c_void_p]
         L.go_rows_get.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 13
         L.go_dynamics.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
@@ -272,6 +289,80 @@ class Oracle:
         X, U = np.zeros((self.N, self.n)), np.zeros((self.N, self.m))
         self.L.go_init_straightline(self.h, X, U)
         return X, U
+
+
+def default_trajopt_params(model):
+    tp = TrajOptParams()
+    lib().go_default_trajopt_params(C.c_int(model), C.byref(tp))
+    return tp
+
+
+class OracleTrajOpt(Oracle):
+    """One TrajOpt problem instance (src/scp/scp_trajopt.jl).  Internally a knot carries (u_k, d_k), d_k = the defect of the
+    interval (k, k+1) (the L1-penalised dynamics): `self.m` is m0 + n, and results come back split into U [N, m0] and D [N, n]."""
+
+    def __init__(self, model, N, boxes=None, spheres=None, model_params=None, trajopt_params=None, ipm_opts=None):
+        self.L = lib()
+        self.model, self.N = model, N
+        self.n, self.m0 = MODEL_DIMS[model]
+        self.m = self.m0 + self.n
+        sp, mp = default_params(model)
+        self.sp, self.mp = sp, model_params or mp
+        self.tp = trajopt_params or default_trajopt_params(model)
+        self.boxes = _arr(boxes if boxes is not None else np.zeros((0, 6))).reshape(-1, 6)
+        self.spheres = _arr(spheres if spheres is not None else np.zeros((0, 4))).reshape(-1, 4)
+        self.h = self.L.go_create_trajopt(model, N, C.byref(self.mp), C.byref(self.tp), len(self.boxes), self.boxes.ctypes.data,
+                                          len(self.spheres), self.spheres.ctypes.data)
+        if not self.h:
+            raise RuntimeError("go_create_trajopt failed (FreeflyerSE2 and AstrobeeSE3 have a TrajOpt variant)")
+        if ipm_opts is not None:
+            self.L.go_set_ipm_opts(self.h, C.byref(ipm_opts))
+
+    def ext(self, U, D=None):
+        """[N, m0] (+ defects [N, n], default 0) -> the library's [N, m0 + n]"""
+        Ue = np.zeros((self.N, self.m))
+        Ue[:, :self.m0] = U
+        if D is not None:
+            Ue[:, self.m0:] = D
+        return Ue
+
+    def set_problem(self, x_init, goal_lo, goal_hi, tf, X0=None, U0=None):
+        super().set_problem(x_init, goal_lo, goal_hi, tf, X0, None if U0 is None else self.ext(U0))
+
+    def init_straightline(self):
+        X, Ue = super().init_straightline()
+        return X, Ue[:, :self.m0].copy()
+
+    def subproblem(self, Xp, Up, mu, s, Dp=None):
+        Xn, Un, dual = np.zeros((self.N, self.n)), np.zeros((self.N, self.m)), np.zeros(self.n)
+        info = SubInfo()
+        st = self.L.go_trajopt_subproblem(self.h, _arr(Xp), self.ext(Up, Dp), float(mu), float(s), Xn, Un, dual, C.byref(info))
+        return dict(X=Xn, U=Un[:, :self.m0].copy(), D=Un[:, self.m0:].copy(), dual=dual, status=st, obj=info.obj, iters=info.iters,
+                    res_p=info.res_p, res_d=info.res_d, mu=info.mu)
+
+    def ratio(self, X, U, Xp, Up):
+        return self.L.go_trajopt_ratio(self.h, _arr(X), self.ext(U), _arr(Xp), self.ext(Up))
+
+    def ctol(self, X, U, Xp, Up):
+        return self.L.go_trajopt_ctol(self.h, _arr(X), self.ext(U), _arr(Xp), self.ext(Up))
+
+    def solve_trajopt(self, max_iter=125):
+        solves = self.L.go_solve_trajopt(self.h, int(max_iter))
+        r = self.result()
+        r["D"] = r["U"][:, self.m0:].copy()
+        r["U"] = r["U"][:, :self.m0].copy()
+        r["solves"] = solves
+        cap = 4 * max(1, solves) + 64
+        v = {k: np.zeros(cap) for k in ("s_vec", "mu_vec", "xtol_vec", "ftol_vec", "ctol_vec")}
+        n = {k: C.c_int() for k in v}
+        args = []
+        for k in ("s_vec", "mu_vec", "xtol_vec", "ftol_vec", "ctol_vec"):
+            args += [v[k].ctypes.data, C.addressof(n[k])]
+        self.L.go_get_trajopt_history(self.h, *args)
+        for k in v:
+            r[k] = v[k][:n[k].value].copy()
+        r["rho_vec"] = r["rho"]
+        return r
 
 
 def solve_batch(model, N, boxes, spheres, x_init, goal_lo, goal_hi, tf, max_iter=30, nthreads=0, scp_params=None,
