@@ -5,6 +5,7 @@ driver interface (host.py: solve_SCP!, solve_gusto_hip!).  Import it through the
 repository root (the directory name contains a dot)."""
 from . import _capi, problems  # noqa: F401
 from ._capi import (ASTROBEE_SE3, ASTROBEE_SE3_MANIFOLD, DUBINS_CAR, FREEFLYER_SE2, BatchSolver, GustoError,  # noqa: F401
-                    IpmOpts, MODEL_DIMS, ModelParams, ScpParams, build, default_ipm_opts, default_params, lib)
+                    IpmOpts, MODEL_DIMS, ModelParams, ScpParams, TrajOptParams, TrajOptSolver, build, default_ipm_opts,
+                    default_params, default_trajopt_params, lib)
 from . import host  # noqa: F401,E402
 from . import export  # noqa: F401,E402

@@ -25,6 +25,8 @@ SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims",
            "gusto_last_solve_ms", "gusto_get_traj",
            "gusto_get_traj_dev", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_get_hist_cap",
            "gusto_set_trust_state", "gusto_subproblem", "gusto_default_shoot_opts", "gusto_shoot", "gusto_get_shoot",
+           "gusto_default_trajopt_params", "gusto_create_trajopt", "gusto_set_trajopt_params", "gusto_solve_trajopt",
+           "gusto_get_trajopt_history", "gusto_subproblem_trajopt",
            "gusto_dev_get_prof", "gusto_dev_launch_info"]
 
 
@@ -51,6 +53,18 @@ class ShootOpts(C.Structure):
     _fields_ = [("substeps", C.c_int), ("max_newton", C.c_int), ("ftol", C.c_double)]
 
 
+class TrajOptParams(C.Structure):
+    """gusto_trajopt_params = SCPParam_TrajOpt (scp_trajopt.jl:3-30)"""
+    _fields_ = [(k, C.c_double) for k in ("mu0", "s0", "c", "tau_plus", "tau_minus", "k", "ftol", "xtol", "ctol")] + \
+               [(k, C.c_int) for k in ("max_penalty_iteration", "max_convex_iteration", "max_trust_iteration")]
+
+
+class TrajOptHistory(C.Structure):
+    _fields_ = [("hist_cap", C.c_int)] + [(k, C.c_void_p) for k in
+                ("n_solves", "n_mu", "n_xtol", "n_ftol", "n_ctol", "rho_vec", "s_vec", "mu_vec", "xtol_vec", "ftol_vec",
+                 "ctol_vec", "J_true", "J_full", "convergence_measure", "solver_status", "ipm_iters")]
+
+
 class History(C.Structure):
     _fields_ = [("hist_cap", C.c_int), ("n_hist", C.c_void_p), ("nJ", C.c_void_p), ("n_rho", C.c_void_p),
                 ("J_true", C.c_void_p), ("J_full", C.c_void_p), ("convergence_measure", C.c_void_p),
@@ -70,7 +84,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(_ROOT, "include"), "-fPIC",
              "-Wno-unused-value", "-Wno-pass-failed"]
-    units = ["gusto_hip", "shoot", "model_0", "model_1", "model_2", "model_3"]
+    units = ["gusto_hip", "shoot", "model_0", "model_1", "model_2", "model_3", "model_4", "model_5"]
     bdir = os.path.join(_HERE, "build")
     os.makedirs(bdir, exist_ok=True)
 
@@ -80,7 +94,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
 
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(cc, units))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(bdir, u + ".o") for u in units] + \
           ["-o", LIB_PATH]
@@ -133,6 +147,12 @@ def lib():
         L.gusto_shoot.argtypes = [vp, vp, C.POINTER(ShootOpts)]
         L.gusto_get_shoot.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.gusto_subproblem.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.gusto_default_trajopt_params.argtypes = [ci, C.POINTER(TrajOptParams)]
+        L.gusto_create_trajopt.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci]
+        L.gusto_set_trajopt_params.argtypes = [vp, C.POINTER(TrajOptParams)]
+        L.gusto_solve_trajopt.argtypes = [vp, ci]
+        L.gusto_get_trajopt_history.argtypes = [vp, C.POINTER(TrajOptHistory)]
+        L.gusto_subproblem_trajopt.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -143,6 +163,14 @@ def default_params(model):
     if rc:
         raise ValueError(f"gusto_default_params({model}) -> {rc}")
     return sp, mp
+
+
+def default_trajopt_params(model):
+    tp = TrajOptParams()
+    rc = lib().gusto_default_trajopt_params(model, C.byref(tp))
+    if rc:
+        raise ValueError(f"gusto_default_trajopt_params({model}) -> {rc}: the model has no TrajOpt variant")
+    return tp
 
 
 def default_ipm_opts():
@@ -168,7 +196,7 @@ class BatchSolver:
         self.model, self.N, self.batch_cap, self.hist_cap, self.device = model, N, batch_cap, hist_cap, device
         self.n, self.m = MODEL_DIMS[model]
         self.h = C.c_void_p()
-        rc = self.L.gusto_create(C.byref(self.h), model, N, batch_cap, hist_cap, device)
+        rc = self._create(model, N, batch_cap, hist_cap, device)
         if rc:
             msg = self.L.gusto_last_error(self.h if self.h else None)
             self.h = C.c_void_p()
@@ -180,6 +208,9 @@ class BatchSolver:
         if ipm_opts is not None:
             self._chk(self.L.gusto_set_ipm_opts(self.h, C.byref(ipm_opts)), "set_ipm_opts")
         self.set_env(boxes, spheres)
+
+    def _create(self, model, N, batch_cap, hist_cap, device):
+        return self.L.gusto_create(C.byref(self.h), model, N, batch_cap, hist_cap, device)
 
     def _chk(self, rc, what):
         if rc:
@@ -322,3 +353,52 @@ class BatchSolver:
                                           omega.ctypes.data, toggle.ctypes.data, Xn.ctypes.data, Un.ctypes.data,
                                           obj.ctypes.data, st.ctypes.data, it.ctypes.data), "subproblem")
         return dict(X=Xn, U=Un, obj=obj, status=st, iters=it, dual=self.dual())
+
+
+class TrajOptSolver(BatchSolver):
+    """A gusto_handle created by gusto_create_trajopt: the TrajOpt algorithm (src/scp/scp_trajopt.jl) for a batch of problems
+    of FreeflyerSE2 or AstrobeeSE3.  set_env / set_problems / traj / status / dual / last_solve_ms as for BatchSolver."""
+
+    def __init__(self, model, N, batch_cap, hist_cap=272, device=0, boxes=None, spheres=None, model_params=None,
+                 trajopt_params=None, ipm_opts=None):
+        super().__init__(model, N, batch_cap, hist_cap, device, boxes, spheres, None, model_params, ipm_opts)
+        if trajopt_params is not None:
+            self._chk(self.L.gusto_set_trajopt_params(self.h, C.byref(trajopt_params)), "set_trajopt_params")
+
+    def _create(self, model, N, batch_cap, hist_cap, device):
+        return self.L.gusto_create_trajopt(C.byref(self.h), model, N, batch_cap, hist_cap, device)
+
+    def solve(self, max_iter=125, force=False):
+        self._chk(self.L.gusto_solve_trajopt(self.h, int(max_iter)), "solve_trajopt")
+
+    def solve_async(self, *a, **k):
+        raise GustoError("TrajOptSolver: gusto_solve_trajopt is synchronous")
+
+    def history(self):
+        B, H = self.B, self.hist_cap
+        dk = ("rho_vec", "s_vec", "mu_vec", "xtol_vec", "ftol_vec", "ctol_vec", "J_true", "J_full", "convergence_measure")
+        out = {k: np.zeros((B, H)) for k in dk}
+        out.update({k: np.zeros((B, H), dtype=np.int32) for k in ("solver_status", "ipm_iters")})
+        cnt = {k: np.zeros(B, dtype=np.int32) for k in ("n_solves", "n_mu", "n_xtol", "n_ftol", "n_ctol")}
+        hs = TrajOptHistory()
+        hs.hist_cap = H
+        for k, v in list(out.items()) + list(cnt.items()):
+            setattr(hs, k, v.ctypes.data)
+        self._chk(self.L.gusto_get_trajopt_history(self.h, C.byref(hs)), "get_trajopt_history")
+        out.update(cnt)
+        return out
+
+    def subproblem(self, Xp, Up, mu, s):
+        """gusto_subproblem_trajopt: one convex subproblem per problem around (Xp, Up) with penalty mu and trust region s."""
+        B = self.B
+        Xp, Up = _arr(Xp).reshape(B, self.N, self.n), _arr(Up).reshape(B, self.N, self.m)
+        mu, s = (_arr(np.broadcast_to(np.asarray(v, dtype=np.float64), (B,))) for v in (mu, s))
+        Xn, Un, Dn, obj = np.zeros_like(Xp), np.zeros_like(Up), np.zeros_like(Xp), np.zeros(B)
+        st, it = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        self._chk(self.L.gusto_subproblem_trajopt(self.h, B, Xp.ctypes.data, Up.ctypes.data, mu.ctypes.data, s.ctypes.data,
+                                                  Xn.ctypes.data, Un.ctypes.data, Dn.ctypes.data, obj.ctypes.data,
+                                                  st.ctypes.data, it.ctypes.data), "subproblem_trajopt")
+        return dict(X=Xn, U=Un, D=Dn, obj=obj, status=st, iters=it, dual=self.dual())
+
+    def shoot(self, *a, **k):
+        raise GustoError("TrajOptSolver: shooting belongs to the GuSTO path")

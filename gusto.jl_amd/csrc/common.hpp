@@ -30,8 +30,16 @@ constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5,
 #ifndef GUSTO_USE_MFMA
 #define GUSTO_USE_MFMA true   // -DGUSTO_USE_MFMA=false: the VALU two-step contraction instead (A/B measurements)
 #endif
+// TrajOpt variants of two models (src/scp/scp_trajopt.jl; internal ids, not part of gusto_model_id): a knot carries the
+// controls (u_k, d_k), d_k = the n defect variables of the interval (k, k+1) -- the L1-penalised dynamics.  In the LQR form
+// of the Newton system a defect moves y_k = F_k x_k + b_k u_k + d_k directly (Gam_d = I) and not x_k (b_d = 0); MT::NDEF
+// marks the few places that differ (ipm.hpp).  They run the generic multi-wave phases (one wave of them for N <= 64).
+constexpr int GUSTO_TO_FREEFLYER_SE2 = 4, GUSTO_TO_ASTROBEE_SE3 = 5;
+// vanishing quadratic cost on the defects next to their L1 penalty (the oracle's GO_TRAJOPT_DEFECT_REG)
+constexpr double TRAJOPT_DEFECT_REG = 1e-4;
 template <int MODEL> struct MT;
 template <> struct MT<GUSTO_FREEFLYER_SE2> {
+    static constexpr int NDEF = 0;   // (no defect controls: the dynamics are hard rows)
     static constexpr int n = 6, m = 3, WS = 2, NFIX = 3, NHU = 2;
     static constexpr int WAVES_PER_EU = GUSTO_WAVES_PER_EU;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
@@ -54,6 +62,7 @@ template <> struct MT<GUSTO_FREEFLYER_SE2> {
     static constexpr bool Hnz(int, int) { return true; }   // (the trust region row couples every pair of states)
 };
 template <> struct MT<GUSTO_DUBINS_CAR> {
+    static constexpr int NDEF = 0;   // (no defect controls: the dynamics are hard rows)
     static constexpr int n = 3, m = 1, WS = 2, NFIX = 6, NHU = 2;
     static constexpr int WAVES_PER_EU = 2;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
@@ -70,6 +79,7 @@ template <> struct MT<GUSTO_DUBINS_CAR> {
     static constexpr bool Hnz(int, int) { return true; }
 };
 template <> struct MT<GUSTO_ASTROBEE_SE3> {
+    static constexpr int NDEF = 0;   // (no defect controls: the dynamics are hard rows)
     static constexpr int n = 12, m = 6, WS = 3, NFIX = 3, NHU = 2;
     static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true;   // factor sweep as a function call (ipm.hpp:factor_sweep)
@@ -91,6 +101,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3> {
     static constexpr bool Hnz(int i, int j) { return i / 3 == j / 3; }
 };
 template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
+    static constexpr int NDEF = 0;   // (no defect controls: the dynamics are hard rows)
     static constexpr int n = 13, m = 6, WS = 3, NFIX = 5, NHU = 2;
     static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true ;   // factor sweep as a function call (ipm.hpp:factor_sweep)
@@ -117,6 +128,33 @@ template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr bool Hnz(int i, int j) { return hblk(i) == hblk(j); }
 };
 
+template <> struct MT<GUSTO_TO_FREEFLYER_SE2> {
+    using G = MT<GUSTO_FREEFLYER_SE2>;
+    static constexpr int NDEF = 6, n = 6, m = 3 + NDEF, WS = 2, NFIX = 3, NHU = 2 + 2 * NDEF;
+    static constexpr int WAVES_PER_EU = 1, SCHED_PROBE = 0;
+    static constexpr bool SWEEP_CALL = false, MFMA = false, LTI = false, HAS_OBS = true, PG2 = false;
+    static constexpr int pg_r0(int) { return 0; }
+    static constexpr int pg_r1(int) { return 0; }
+    static constexpr bool Anz(int i, int j) { return G::Anz(i, j); }
+    static constexpr bool Mnz(int i, int j) { return G::Mnz(i, j); }
+    static constexpr bool Bnz(int i, int j) { return j < G::m && G::Bnz(i, j); }
+    static constexpr bool Gnz(int i, int j) { return j < G::m ? G::Gnz(i, j) : i == j - G::m; }
+    static constexpr bool Hnz(int, int) { return true; }
+};
+template <> struct MT<GUSTO_TO_ASTROBEE_SE3> {
+    using G = MT<GUSTO_ASTROBEE_SE3>;
+    static constexpr int NDEF = 12, n = 12, m = 6 + NDEF, WS = 3, NFIX = 3, NHU = 2 + 2 * NDEF;
+    static constexpr int WAVES_PER_EU = 1, SCHED_PROBE = 0;
+    static constexpr bool SWEEP_CALL = false, MFMA = false, LTI = false, HAS_OBS = true, PG2 = false;
+    static constexpr int pg_r0(int) { return 0; }
+    static constexpr int pg_r1(int) { return 0; }
+    static constexpr bool Anz(int i, int j) { return G::Anz(i, j); }
+    static constexpr bool Mnz(int i, int j) { return G::Mnz(i, j); }
+    static constexpr bool Bnz(int i, int j) { return j < G::m && G::Bnz(i, j); }
+    static constexpr bool Gnz(int i, int j) { return j < G::m ? G::Gnz(i, j) : i == j - G::m; }
+    static constexpr bool Hnz(int, int) { return true; }   // (the hard trust region row couples every pair of states)
+};
+
 // symmetric packed index (upper triangle, row-major)
 GD constexpr int sidx(int i, int j, int n) {
     return i <= j ? i * n - i * (i - 1) / 2 + (j - i) : j * n - j * (j - 1) / 2 + (i - j);
@@ -138,7 +176,7 @@ template <int MODEL> struct Rec {
 // per-problem global workspace, offsets in doubles
 struct WsLayout {
     int nslot;
-    size_t rowstate, obs_nh, obs_c0, obs_mask, PG, QQ, Paft, Piaft, KD, Phicl, pvt, total;
+    size_t rowstate, obs_nh, obs_c0, obs_mask, PG, QQ, Paft, Piaft, KD, Phicl, pvt, to_traj, total;
 };
 template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     using T = MT<MODEL>;
@@ -159,6 +197,7 @@ template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     L.KD = take((size_t)N * R::SKD);
     L.Phicl = take((size_t)N * R::SNN);
     L.pvt = take((size_t)N * (5 * n + 5 * m));   // rd qrd dXs | dUs qu dv | gAx gBx gAu gBu (corrector row sums)
+    L.to_traj = take(T::NDEF > 0 ? (size_t)2 * N * (n + m) : 0);   // TrajOpt: old_penalty_traj and old_convex_traj (X | U each)
     L.total = o;
     return L;
 }
@@ -248,13 +287,17 @@ struct KParams {
     double* st_d;  // [B][2+MAXN]: toggle, spare, dual[n]
     double *J_true, *J_full, *conv, *Delta, *omega, *rho;                       // [B][hist_cap]
     int *accept, *scp_status, *solver_status, *tr_sat, *cvx_sat, *ipm_it;      // [B][hist_cap]
+    // TrajOpt (scp_trajopt.jl): parameters and the vectors GuSTO has no counterpart of; rho / Delta hold rho_vec / s_vec
+    gusto_trajopt_params tp;
+    double *to_mu, *to_xtol, *to_ftol, *to_ctol;                                // [B][hist_cap]
     double* ws;
     long long* prof;  // [B][PROF_N] phase cycle counters (GUSTO_PROFILE builds only)
     WsLayout wl;
     LdsLayout ll;
 };
 constexpr int ST_ITER = 0, ST_CONV = 1, ST_SUCC = 2, ST_STOP = 3, ST_IPM = 4, ST_NHIST = 5, ST_NJ = 6, ST_NRHO = 7, ST_WARM = 8,
-              ST_CAP = 9 /* iter_cap of the running gusto_solve call */, ST_VISITS = 10 /* time slices so far */, ST_NI = 11;
+              ST_CAP = 9 /* iter_cap of the running gusto_solve call */, ST_VISITS = 10 /* time slices so far */,
+              ST_NMU = 11, ST_NXTOL = 12, ST_NFTOL = 13, ST_NCTOL = 14 /* TrajOpt: entries of mu_vec / xtol_vec / ftol_vec / ctol_vec */, ST_NI = 16;
 // scheduler words in KParams::queue.  Every counter sits in its own 128-byte line (SQ_STRIDE ints apart): thousands of
 // workgroups poll and bump them, and two counters in one line serialise each other's atomics in the L2.
 constexpr int SCHED_LEVELS = 16, SQ_STRIDE = 32;

@@ -85,7 +85,7 @@ int gusto_default_ipm_opts(gusto_ipm_opts* o) {
 
 const char* gusto_last_error(gusto_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
 
-int gusto_create(gusto_handle* out, int model, int N, int batch_cap, int hist_cap, int device) {
+static int create_impl(gusto_handle* out, int model, int N, int batch_cap, int hist_cap, int device, bool trajopt) {
     int n, m;
     if (!out || gusto_model_dims(model, &n, &m) || N < 3 || N > 256 || batch_cap < 1 || hist_cap < 4) {
         g_err = "gusto_create: bad argument (need 3 <= N <= 256, batch_cap >= 1, hist_cap >= 4)";
@@ -96,9 +96,19 @@ int gusto_create(gusto_handle* out, int model, int N, int batch_cap, int hist_ca
         g_err = "gusto_create: no usable HIP device (libgusto_hip has no CPU fallback)";
         return GUSTO_ERR_NO_DEVICE;
     }
+    if (trajopt && model != GUSTO_FREEFLYER_SE2 && model != GUSTO_ASTROBEE_SE3) {
+        g_err = "gusto_create_trajopt: FreeflyerSE2 and AstrobeeSE3 have a TrajOpt variant";
+        return GUSTO_ERR_ARG;
+    }
     gusto_handle h = new gusto_handle_s();
     h->model = model; h->n = n; h->m = m; h->N = N; h->batch_cap = batch_cap; h->hist_cap = hist_cap; h->device = device;
+    h->model_pub = model; h->m_pub = m; h->trajopt = trajopt;
     gusto_default_params(model, &h->sp, &h->mp);
+    if (trajopt) {   // internal variant: controls (u, d), d = the n defect variables of a knot
+        h->model = model == GUSTO_FREEFLYER_SE2 ? gusto::GUSTO_TO_FREEFLYER_SE2 : gusto::GUSTO_TO_ASTROBEE_SE3;
+        h->m = m = m + n;
+        gusto_default_trajopt_params(model, &h->tp);
+    }
     gusto_default_ipm_opts(&h->io);
     *out = h;
     HIPCHK(h, hipSetDevice(device));
@@ -119,6 +129,24 @@ int gusto_create(gusto_handle* out, int model, int N, int batch_cap, int hist_ca
     HIPCHK(h, dalloc(&h->d_subX, B * N * n)); HIPCHK(h, dalloc(&h->d_subU, B * N * m)); HIPCHK(h, dalloc(&h->d_subObj, B));
     HIPCHK(h, dalloc(&h->d_subSt, B)); HIPCHK(h, dalloc(&h->d_subIt, B));
     HIPCHK(h, dalloc(&h->d_box, 1)); HIPCHK(h, dalloc(&h->d_sph, 1));
+    if (trajopt) {
+        HIPCHK(h, dalloc(&h->d_to_mu, B * H)); HIPCHK(h, dalloc(&h->d_to_xtol, B * H));
+        HIPCHK(h, dalloc(&h->d_to_ftol, B * H)); HIPCHK(h, dalloc(&h->d_to_ctol, B * H));
+    }
+    return GUSTO_OK;
+}
+int gusto_create(gusto_handle* out, int model, int N, int batch_cap, int hist_cap, int device) {
+    return create_impl(out, model, N, batch_cap, hist_cap, device, false);
+}
+int gusto_create_trajopt(gusto_handle* out, int model, int N, int batch_cap, int hist_cap, int device) {
+    return create_impl(out, model, N, batch_cap, hist_cap, device, true);
+}
+int gusto_default_trajopt_params(int model, gusto_trajopt_params* tp) {   // freeflyer_se2.jl:49-64, astrobee_se3.jl:50-65
+    if (!tp || (model != GUSTO_FREEFLYER_SE2 && model != GUSTO_ASTROBEE_SE3)) return GUSTO_ERR_ARG;
+    memset(tp, 0, sizeof(*tp));
+    tp->mu0 = 1.0; tp->c = 10.0; tp->tau_plus = 2.0; tp->tau_minus = 0.5; tp->k = 5.0; tp->ftol = 0.01; tp->ctol = 0.01;
+    tp->max_penalty_iteration = 5; tp->max_convex_iteration = 5; tp->max_trust_iteration = 5;
+    if (model == GUSTO_FREEFLYER_SE2) { tp->s0 = 1.0; tp->xtol = 0.1; } else { tp->s0 = 10.0; tp->xtol = 0.01; }
     return GUSTO_OK;
 }
 
@@ -127,7 +155,8 @@ int gusto_destroy(gusto_handle h) {
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_X, h->d_U, h->d_xinit, h->d_glo, h->d_ghi, h->d_tf, h->d_sti, h->d_std, h->d_Jt, h->d_Jf, h->d_conv,
                     h->d_Delta, h->d_omega, h->d_rho, h->d_acc, h->d_scp, h->d_sol, h->d_tr, h->d_cvx, h->d_ipm, h->d_ws,
-                    h->d_prof, h->d_subD, h->d_subW, h->d_subT, h->d_subX, h->d_subU, h->d_subObj, h->d_subSt, h->d_subIt, h->d_box, h->d_sph};
+                    h->d_prof, h->d_subD, h->d_subW, h->d_subT, h->d_subX, h->d_subU, h->d_subObj, h->d_subSt, h->d_subIt, h->d_box, h->d_sph,
+                    h->d_to_mu, h->d_to_xtol, h->d_to_ftol, h->d_to_ctol};
     for (void* p : ptrs) if (p) hipFree(p);
     for (void* p : {(void*)h->d_shX, (void*)h->d_shU, (void*)h->d_shP, (void*)h->d_shP0, (void*)h->d_shRes, (void*)h->d_shSt, (void*)h->d_shIt}) if (p) hipFree(p);
     if (h->d_order) hipFree(h->d_order);
@@ -199,10 +228,32 @@ static int do_init(gusto_handle h, bool straight) {
     case 1: return gusto_launch_init_m1(h, straight);
     case 2: return gusto_launch_init_m2(h, straight);
     case 3: return gusto_launch_init_m3(h, straight);
+    case 4: return gusto_launch_init_m4(h, straight);
+    case 5: return gusto_launch_init_m5(h, straight);
     }
     return GUSTO_ERR_ARG;
 }
+static int do_trajopt(gusto_handle h, int mode, int max_iter) {
+    switch (h->model) {
+    case 4: return gusto_launch_trajopt_m4(h, mode, max_iter);
+    case 5: return gusto_launch_trajopt_m5(h, mode, max_iter);
+    }
+    h->err = "not a TrajOpt handle (gusto_create_trajopt)";
+    return GUSTO_ERR_STATE;
+}
+// U between the caller (u_dim columns) and the device (TrajOpt handles keep u | defect per knot: m columns)
+static hipError_t copy_U(gusto_handle h, double* dst, const double* src, bool to_device, hipMemcpyKind kind) {
+    const size_t rows = (size_t)h->B * h->N;
+    if (!h->trajopt) return hipMemcpyAsync(dst, src, sizeof(double) * rows * h->m, kind, h->stream);
+    if (to_device) {
+        hipError_t e = hipMemsetAsync(dst, 0, sizeof(double) * rows * h->m, h->stream);   // defects start at 0
+        if (e != hipSuccess) return e;
+        return hipMemcpy2DAsync(dst, sizeof(double) * h->m, src, sizeof(double) * h->m_pub, sizeof(double) * h->m_pub, rows, kind, h->stream);
+    }
+    return hipMemcpy2DAsync(dst, sizeof(double) * h->m_pub, src, sizeof(double) * h->m, sizeof(double) * h->m_pub, rows, kind, h->stream);
+}
 static int do_scp(gusto_handle h, int mode, int max_iter, int force) {
+    if (h->trajopt) { h->err = "TrajOpt handle: use gusto_solve_trajopt / gusto_subproblem_trajopt"; return GUSTO_ERR_STATE; }
     switch (h->model) {
     case 0: return gusto_launch_scp_m0(h, mode, max_iter, force);
     case 1: return gusto_launch_scp_m1(h, mode, max_iter, force);
@@ -230,7 +281,7 @@ static int set_problems_impl(gusto_handle h, int B, const double* x_init, const 
     HIPCHK(h, hipMemcpyAsync(h->d_tf, tf, sizeof(double) * B, kind, h->stream));
     if (X0) {
         HIPCHK(h, hipMemcpyAsync(h->d_X, X0, sizeof(double) * B * N * n, kind, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_U, U0, sizeof(double) * B * N * m, kind, h->stream));
+        HIPCHK(h, copy_U(h, h->d_U, U0, true, kind));
     }
     int rc = do_init(h, X0 == nullptr);
     if (rc) return rc;
@@ -301,7 +352,10 @@ int gusto_get_traj(gusto_handle h, double* X, double* U) {
     if (!h || !h->have_problems) return GUSTO_ERR_STATE;
     HIPCHK(h, hipSetDevice(h->device));
     if (X) HIPCHK(h, hipMemcpy(X, h->d_X, sizeof(double) * h->B * h->N * h->n, hipMemcpyDeviceToHost));
-    if (U) HIPCHK(h, hipMemcpy(U, h->d_U, sizeof(double) * h->B * h->N * h->m, hipMemcpyDeviceToHost));
+    if (U) {
+        HIPCHK(h, copy_U(h, U, h->d_U, false, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     return GUSTO_OK;
 }
 int gusto_get_traj_dev(gusto_handle h, const double** X, const double** U) {
@@ -411,5 +465,78 @@ int gusto_subproblem(gusto_handle h, int B, const double* Xp, const double* Up, 
     if (iters) HIPCHK(h, hipMemcpy(iters, h->d_subIt, sizeof(int) * B, hipMemcpyDeviceToHost));
     return GUSTO_OK;
 }
+
+int gusto_set_trajopt_params(gusto_handle h, const gusto_trajopt_params* tp) {
+    if (!h || !tp || !h->trajopt) return GUSTO_ERR_ARG;
+    { int rc = setter_enter(h); if (rc) return rc; }
+    h->tp = *tp;
+    return GUSTO_OK;
+}
+
+int gusto_solve_trajopt(gusto_handle h, int max_iter) {
+    if (!h || max_iter < 0) return GUSTO_ERR_ARG;
+    if (!h->trajopt) { h->err = "gusto_solve_trajopt: not a TrajOpt handle (gusto_create_trajopt)"; return GUSTO_ERR_STATE; }
+    if (!h->have_problems) { h->err = "gusto_solve_trajopt: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
+    const int total = h->tp.max_penalty_iteration * h->tp.max_convex_iteration * h->tp.max_trust_iteration;
+    if (h->hist_cap < 2 * std::min(total, max_iter) + 8) {
+        h->err = "gusto_solve_trajopt: hist_cap of the handle is below 2 * min(max_iter, max_penalty * max_convex * max_trust) + 8";
+        return GUSTO_ERR_ARG;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = gusto_finish(h);
+    if (rc) return rc;
+    rc = do_trajopt(h, 0, max_iter);
+    return rc ? rc : gusto_finish(h);
+}
+
+int gusto_get_trajopt_history(gusto_handle h, gusto_trajopt_history* o) {
+    if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
+    if (!h || !o || !h->trajopt || !h->have_problems) return GUSTO_ERR_STATE;
+    if (o->hist_cap < h->hist_cap) { h->err = "gusto_get_trajopt_history: hist_cap of the output arrays is smaller than the handle's"; return GUSTO_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<int> st((size_t)h->B * ST_NI);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_sti, sizeof(int) * st.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->B; b++) {
+        const int* q = st.data() + (size_t)b * ST_NI;
+        if (o->n_solves) o->n_solves[b] = q[ST_ITER];
+        if (o->n_mu) o->n_mu[b] = q[ST_NMU];
+        if (o->n_xtol) o->n_xtol[b] = q[ST_NXTOL];
+        if (o->n_ftol) o->n_ftol[b] = q[ST_NFTOL];
+        if (o->n_ctol) o->n_ctol[b] = q[ST_NCTOL];
+    }
+    const size_t H = h->hist_cap, Ho = o->hist_cap;
+#define CPD(dst, src) if (dst) HIPCHK(h, hipMemcpy2D(dst, sizeof(*(dst)) * Ho, src, sizeof(*(dst)) * H, sizeof(*(dst)) * H, h->B, hipMemcpyDeviceToHost))
+    CPD(o->rho_vec, h->d_rho); CPD(o->s_vec, h->d_Delta); CPD(o->mu_vec, h->d_to_mu); CPD(o->xtol_vec, h->d_to_xtol);
+    CPD(o->ftol_vec, h->d_to_ftol); CPD(o->ctol_vec, h->d_to_ctol); CPD(o->J_true, h->d_Jt); CPD(o->J_full, h->d_Jf);
+    CPD(o->convergence_measure, h->d_conv); CPD(o->solver_status, h->d_sol); CPD(o->ipm_iters, h->d_ipm);
+#undef CPD
+    return GUSTO_OK;
+}
+
+int gusto_subproblem_trajopt(gusto_handle h, int B, const double* Xp, const double* Up, const double* mu, const double* s,
+                             double* Xn, double* Un, double* Dn, double* obj, int* status, int* iters) {
+    if (!h || !h->trajopt || !h->have_problems || B != h->B || !Xp || !Up || !mu || !s) {
+        if (h) h->err = "gusto_subproblem_trajopt: TrajOpt handle and gusto_set_problems with the same B first";
+        return GUSTO_ERR_STATE;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcw = gusto_finish(h); if (rcw) return rcw; }
+    const size_t n = h->n, m = h->m, mp = h->m_pub, N = h->N, rows = (size_t)B * N;
+    HIPCHK(h, hipMemcpy(h->d_X, Xp, sizeof(double) * rows * n, hipMemcpyHostToDevice));
+    HIPCHK(h, copy_U(h, h->d_U, Up, true, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpyAsync(h->d_subD, s, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_subW, mu, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    int rc = do_trajopt(h, 1, 0);
+    if (!rc) rc = gusto_finish(h);
+    if (rc) return rc;
+    if (Xn) HIPCHK(h, hipMemcpy(Xn, h->d_subX, sizeof(double) * rows * n, hipMemcpyDeviceToHost));
+    if (Un) HIPCHK(h, hipMemcpy2D(Un, sizeof(double) * mp, h->d_subU, sizeof(double) * m, sizeof(double) * mp, rows, hipMemcpyDeviceToHost));
+    if (Dn) HIPCHK(h, hipMemcpy2D(Dn, sizeof(double) * n, h->d_subU + mp, sizeof(double) * m, sizeof(double) * n, rows, hipMemcpyDeviceToHost));
+    if (obj) HIPCHK(h, hipMemcpy(obj, h->d_subObj, sizeof(double) * B, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(h, hipMemcpy(status, h->d_subSt, sizeof(int) * B, hipMemcpyDeviceToHost));
+    if (iters) HIPCHK(h, hipMemcpy(iters, h->d_subIt, sizeof(int) * B, hipMemcpyDeviceToHost));
+    return GUSTO_OK;
+}
+
 
 }  // extern "C"

@@ -8,6 +8,12 @@
 
 struct gusto_handle_s {
     int model = 0, n = 0, m = 0, N = 0, batch_cap = 0, hist_cap = 0, device = 0, B = 0;
+    // TrajOpt handles (gusto_create_trajopt): `model` is the internal variant (common.hpp: GUSTO_TO_*), `m` its control
+    // dimension u_dim + x_dim (u | defect); the C ABI moves U with the model's u_dim columns, `m_pub`
+    bool trajopt = false;
+    int m_pub = 0, model_pub = 0;
+    gusto_trajopt_params tp{};
+    double *d_to_mu = nullptr, *d_to_xtol = nullptr, *d_to_ftol = nullptr, *d_to_ctol = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     gusto_scp_params sp{};
@@ -91,3 +97,7 @@ int gusto_launch_scp_m0(gusto_handle h, int mode, int max_iter, int force);
 int gusto_launch_scp_m1(gusto_handle h, int mode, int max_iter, int force);
 int gusto_launch_scp_m2(gusto_handle h, int mode, int max_iter, int force);
 int gusto_launch_scp_m3(gusto_handle h, int mode, int max_iter, int force);
+int gusto_launch_init_m4(gusto_handle h, bool straight);
+int gusto_launch_init_m5(gusto_handle h, bool straight);
+int gusto_launch_trajopt_m4(gusto_handle h, int mode, int max_iter);
+int gusto_launch_trajopt_m5(gusto_handle h, int mode, int max_iter);

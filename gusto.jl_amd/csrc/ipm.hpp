@@ -236,7 +236,7 @@ template <class BLK> GD void load_M_Gam(const BLK& K, int k, double* M, double* 
         }
         return;
     }
-    if constexpr (!T::LTI && n > 8) {
+    if constexpr (!T::LTI && n > 8 && T::NDEF == 0) {
         // recomputed with the operations of linearize() (and the round trip M -> Phi = 2 M - I -> M of the stored block),
         // so the values are those of the record
         double Mx[n * n], Bx[n * m];
@@ -293,6 +293,10 @@ template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
 #pragma unroll
                     for (int l = 0; l < n; l++) s += M[i * n + l] * (h * B[l * m + j]);
                     pg[i * NZ + n + j] = knot0 ? h * B[i * m + j] : 2.0 * s;
+                }
+                if constexpr (T::NDEF > 0) {   // a defect moves y_k directly: Gam_d = I (common.hpp)
+#pragma unroll
+                    for (int j = 0; j < T::NDEF; j++) pg[i * NZ + n + (m - T::NDEF) + j] = (i == j) ? 1.0 : 0.0;
                 }
             }
         }
@@ -376,7 +380,10 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
 #pragma unroll
                 for (int l = 0; l < n; l++) { a[l] = PGs[l * NZ + j]; bb[l] = K.sPi[l * n + g]; }
                 // E = [M^T C^T; b^T M^T C^T], M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
-                if (k == N - 1 && K.is_goal(g)) add = 0.5 * (PGs[g * NZ + j] + ((j == g) ? 1.0 : 0.0));
+                // (the u part of E is b^T M^T C^T = Gam^T / 2 for a model control; a defect control of the TrajOpt variants does not
+                //  move x_N at all -- b_d = 0 although Gam_d = I)
+                if (k == N - 1 && K.is_goal(g) && !(T::NDEF > 0 && j >= NZ - T::NDEF))
+                    add = 0.5 * (PGs[g * NZ + j] + ((j == g) ? 1.0 : 0.0));
             }
             __builtin_amdgcn_sched_barrier(0);
             double s = 0;
@@ -503,6 +510,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
                 double v = 0.0;
 #pragma unroll
                 for (int q = 0; q < n * m; q++) if (j >= n && q == i * m + (j - n)) v = 0.5 * K.dt * B[q];
+                if constexpr (T::NDEF > 0) { if (j >= n + (m - T::NDEF) && j - n - (m - T::NDEF) == i) v = 1.0; }
                 K.sPG[0 * NPG + e] = v;
             }
         }
@@ -1863,7 +1871,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
     if (act) {
         double tt[n], lu[m], Gamk[n * m];
         if (k >= 1) {
-            if constexpr (T::PG2 || (!T::LTI && n > 8)) {
+            if constexpr (T::PG2 || (!T::LTI && n > 8 && T::NDEF == 0)) {
                 double Mk_[n * n];
                 load_M_Gam(K, k, Mk_, Gamk);
             } else {
@@ -1877,6 +1885,10 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
             Dyn<MODEL>::B(K.P.mp, Gamk);
 #pragma unroll
             for (int i = 0; i < n * m; i++) Gamk[i] *= hdt;
+            if constexpr (T::NDEF > 0) {
+#pragma unroll
+                for (int i = 0; i < T::NDEF; i++) Gamk[i * m + (m - T::NDEF) + i] = 1.0;
+            }
         }
 #pragma unroll
         for (int i = 0; i < n; i++) tt[i] = K.pv[k * n + i];   // pt_k = p_k + r_k
@@ -1965,7 +1977,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         }
         double Gamk[n * m];
         if (k >= 1) {
-            if constexpr (T::PG2 || (!T::LTI && n > 8)) {
+            if constexpr (T::PG2 || (!T::LTI && n > 8 && T::NDEF == 0)) {
                 double Mk_[n * n];
                 load_M_Gam(K, k, Mk_, Gamk);
             } else {
@@ -1979,6 +1991,10 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
             Dyn<MODEL>::B(K.P.mp, Gamk);
 #pragma unroll
             for (int i = 0; i < n * m; i++) Gamk[i] *= hdt;
+            if constexpr (T::NDEF > 0) {
+#pragma unroll
+                for (int i = 0; i < T::NDEF; i++) Gamk[i * m + (m - T::NDEF) + i] = 1.0;
+            }
         }
 #pragma unroll
         for (int i = 0; i < n; i++) {
@@ -2072,7 +2088,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         for (int i = 0; i < m; i++) { gAu[i] = 0; gBu[i] = 0; }
         // (small models: the state of the rows every knot has, in one batch of loads -- row by row, each row's loads wait
         // behind the stores of the row before it and the pass pays one memory round trip per row)
-        constexpr int NP = (n <= 8) ? T::NFIX + T::NHU : 0;
+        constexpr int NP = (n <= 8 && T::NDEF == 0) ? T::NFIX + T::NHU : 0;
         RowPre<NP> pre;
         if constexpr (NP > 0) {
             const int slot_u = T::NFIX + K.P.n_obs + 2 * n;
@@ -2157,6 +2173,7 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
 #pragma unroll
             for (int i = 0; i < n; i++) {
                 rdk[i] = K.Xw[(k - 1) * n + i] - xs[i] + hdt * (K.pv[(k - 1) * n + i] + K.pv[k * n + i]);
+                if constexpr (T::NDEF > 0) rdk[i] += K.Uw[(k - 1) * m + (m - T::NDEF) + i];   // + d_{k-1}: the defect of the interval
                 l_resp = nanmax(l_resp, fabs(rdk[i]));
             }
         }
@@ -2169,7 +2186,7 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
         for (int i = 0; i < m; i++) gu0[i] = 0;
         // (small models only: the 12/13-state kernels are far beyond the register file already -- 5 KB of scratch
         // per lane and > 1200 spilled SGPRs -- and more live values there have produced wrong code)
-        constexpr int NP = (n <= 8) ? T::NFIX + T::NHU : 0;
+        constexpr int NP = (n <= 8 && T::NDEF == 0) ? T::NFIX + T::NHU : 0;
         RowPre<NP> pre;
         if constexpr (NP > 0) {
             const int slot_u = T::NFIX + K.P.n_obs + 2 * n;
@@ -2190,7 +2207,10 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
         l_comp = op.comp;
         l_resp = nanmax(l_resp, op.maxrp);
 #pragma unroll
-        for (int i = 0; i < m; i++) { Hu[sidx(i, i, m)] += 2 * wk; rdu[i] += 2 * wk * us[i]; }
+        for (int i = 0; i < m; i++) {   // (TrajOpt: the defects carry REG times the control cost)
+            const double wi_ = (i < m - T::NDEF) ? wk : TRAJOPT_DEFECT_REG * wk;
+            Hu[sidx(i, i, m)] += 2 * wi_; rdu[i] += 2 * wi_ * us[i];
+        }
         // + E^T nu: F_k^T nu_{k+1} - G_k^T nu_k on x, b_k^T (nu_{k+1} + nu_k) on u
         {
             double vs[n], vd[n];
@@ -2213,6 +2233,10 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
 #pragma unroll
                 for (int j = 0; j < n; j++) if (T::Bnz(j, i)) s += hdt * Bd[j * m + i] * vs[j];
                 rdu[i] += s;
+            }
+            if constexpr (T::NDEF > 0) {   // d_k sits in the trapezoid row of the interval (k, k+1) only: + nu_{k+1}
+#pragma unroll
+                for (int i = 0; i < T::NDEF; i++) rdu[(m - T::NDEF) + i] += (k + 1 < N) ? K.nu[(k + 1) * n + i] : 0.0;
             }
         }
         if (k == N - 1) {
@@ -2466,7 +2490,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
 #pragma unroll
                 for (int i = 0; i < n; i++) { gx[i] = 0; gy[i] = 0; }
 #pragma unroll
-                for (int i = 0; i < m; i++) gu[i] = 2 * wk * us[i];
+                for (int i = 0; i < m; i++) gu[i] = 2 * ((i < m - T::NDEF) ? wk : TRAJOPT_DEFECT_REG * wk) * us[i];
                 pf.tick(PF_F1);
                 if (pass == 0) {   // the predictor's row sums were accumulated by the residual pass
 #pragma unroll
@@ -2575,7 +2599,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         double xs[n], us[m];
         load_iter(xs, us);
 #pragma unroll
-        for (int i = 0; i < m; i++) l_obj += wk * us[i] * us[i];
+        for (int i = 0; i < m; i++) l_obj += ((i < m - T::NDEF) ? wk : TRAJOPT_DEFECT_REG * wk) * us[i] * us[i];
         OpSlackSum op{rs};
         visit_rows<MODEL>(ctx, xs, us, op);
         l_obj += op.sum;

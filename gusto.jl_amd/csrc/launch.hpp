@@ -26,6 +26,7 @@ template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B) {
     P.J_true = h->d_Jt; P.J_full = h->d_Jf; P.conv = h->d_conv; P.Delta = h->d_Delta; P.omega = h->d_omega; P.rho = h->d_rho;
     P.accept = h->d_acc; P.scp_status = h->d_scp; P.solver_status = h->d_sol; P.tr_sat = h->d_tr; P.cvx_sat = h->d_cvx;
     P.ipm_it = h->d_ipm;
+    P.tp = h->tp; P.to_mu = h->d_to_mu; P.to_xtol = h->d_to_xtol; P.to_ftol = h->d_to_ftol; P.to_ctol = h->d_to_ctol;
     P.wl = make_ws_layout<MODEL>(h->N, P.n_obs);
     P.ll = make_lds_layout<MODEL>(h->N);
     if (!h->d_queue) HIPCHK(h, dalloc(&h->d_queue, (size_t)SQ_WORDS));
@@ -107,6 +108,39 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->pending = true;   // completed by gusto_finish (handle.hpp)
+    return GUSTO_OK;
+}
+
+// TrajOpt: every problem of the batch through trajopt_kernel (scp.hpp); mode 1 = one subproblem per problem (parity hook)
+template <int MODEL> static int launch_trajopt(gusto_handle h, int mode, int max_iter) {
+    KParams P;
+    int rc = fill_params<MODEL>(h, P, h->B);
+    if (rc) return rc;
+    P.mode = mode; P.max_iter = max_iter; P.force = 0;
+    const int NT = 64 * ((h->N + 63) / 64);
+    const size_t lds = (size_t)P.ll.total * sizeof(double);
+    if (lds > 160 * 1024) { h->err = "problem does not fit the 160 KiB LDS of a CU"; return GUSTO_ERR_ARG; }
+    auto kern = &trajopt_kernel<MODEL>;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0, cus = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NT, lds));
+    HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    const int slots = std::min(std::max(1, per_cu) * std::max(1, cus), h->B);
+    h->slots = slots; h->lds_bytes = (int)lds; h->per_cu = per_cu;
+    const size_t need = P.wl.total * (size_t)slots;
+    if (need > h->ws_doubles) {
+        if (h->d_ws) hipFree(h->d_ws);
+        h->d_ws = nullptr; h->ws_doubles = 0;
+        HIPCHK(h, dalloc(&h->d_ws, need));
+        h->ws_doubles = need;
+    }
+    P.ws = h->d_ws;
+    if (h->d_queue) HIPCHK(h, hipMemsetAsync(h->d_queue, 0, SQ_WORDS * sizeof(int), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(slots), dim3(NT), lds, h->stream, P);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->pending = true;
     return GUSTO_OK;
 }
 

@@ -197,6 +197,25 @@ template <int WS> GD double sdf_box(const double* q, const double* lo, const dou
 // global pointers hipcc cannot prove that none of the kernel's stores aliases them and emits one global_load +
 // s_waitcnt vmcnt(0) per obstacle for all 64 lanes -- 14 (freeflyer) to 32 (ISS corner) serial memory round trips per
 // distance loop, and rho alone walks that loop four times per trip.
+// TrajOpt variants: the dynamics of the base model; B carries zero columns for the defect controls (they do not enter
+// xdot: a defect belongs to ONE trapezoid row, ipm.hpp)
+template <int MODEL, int BASE> struct DynTO {
+    using D0 = Dyn<BASE>;
+    static constexpr int n = D0::n, m0 = D0::m, m = m0 + n;
+    GD static void f(const gusto_model_params& mp, const double* x, const double* u, double* f) { D0::f(mp, x, u, f); }
+    GD static void A(const gusto_model_params& mp, const double* x, const double* u, double* A) { D0::A(mp, x, u, A); }
+    GD static void B(const gusto_model_params& mp, double* B) {
+        double B0[n * m0];
+        D0::B(mp, B0);
+#pragma unroll
+        for (int i = 0; i < n; i++)
+#pragma unroll
+            for (int j = 0; j < m; j++) B[i * m + j] = j < m0 ? B0[i * m0 + j] : 0.0;
+    }
+};
+template <> struct Dyn<GUSTO_TO_FREEFLYER_SE2> : DynTO<GUSTO_TO_FREEFLYER_SE2, GUSTO_FREEFLYER_SE2> {};
+template <> struct Dyn<GUSTO_TO_ASTROBEE_SE3> : DynTO<GUSTO_TO_ASTROBEE_SE3, GUSTO_ASTROBEE_SE3> {};
+
 typedef const __attribute__((address_space(4))) double cdouble;
 GD const cdouble* as_constant(const double* p) { return (const cdouble*)(uintptr_t)p; }
 

@@ -85,6 +85,42 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
 #pragma unroll
     for (int j = 0; j < n; j++) one[j] = 1.0;
 
+    if constexpr (T::NDEF > 0) {
+        // TrajOpt subproblem (scp_trajopt.jl:159-279): the same registry treated differently -- state trust region HARD
+        // (||x - xp||^2 - s <= 0, :165-173; c.Delta = s, normalised by s), state, obstacle AND control rows L1-penalised with
+        // weight mu (:222-235; c.omega = mu), the dynamics as mu |d_kj| on the defect controls (:257-275, the pair +-mu d <= v)
+        constexpr bool is2 = MODEL == GUSTO_TO_FREEFLYER_SE2;
+        constexpr int nv = is2 ? 2 : 3, iw = is2 ? 5 : 9, nw = is2 ? 1 : 3, m0 = T::m - T::NDEF;
+        quad_row<false, 0, n>(op, 0, ROW_HARD, xs, one, c.xp, -c.Delta, 1.0 / c.Delta, 0.0);
+        quad_row<false, 3, nv>(op, 1, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
+        quad_row<false, iw, nw>(op, 2, ROW_PEN, xs, one, nullptr, -mp.hard_limit_omega * mp.hard_limit_omega, kw, 0.0);
+        uint64_t mk = c.mask;
+        while (mk) {   // (one at a time: this path is not tuned)
+            const int oi = __ffsll((unsigned long long)mk) - 1;
+            mk &= mk - 1;
+            double ob[T::WS];
+#pragma unroll
+            for (int j = 0; j < T::WS; j++) ob[j] = -(c.obs_nh + (size_t)(oi * T::WS + j) * (size_t)c.N)[c.k];
+            const double oc = (c.obs_c0 + (size_t)oi * (size_t)c.N)[c.k];
+            lin_row<false, 0, T::WS>(op, slot_obs + oi, ROW_PEN, xs, ob, oc, kw, 0.0);
+        }
+        if (c.k < c.N - 1) {
+            constexpr int nf = is2 ? 2 : 3, im = is2 ? 2 : 3, nm = is2 ? 1 : 3;
+            double af[nf], am[nm];
+#pragma unroll
+            for (int j = 0; j < nf; j++) af[j] = 1.0 / (mp.mass * mp.mass);
+#pragma unroll
+            for (int j = 0; j < nm; j++) { const double ji = 1.0 / mp.Jdiag[is2 ? 2 : j]; am[j] = ji * ji; }
+            quad_row<true, 0, nf>(op, slot_u, ROW_PEN, us, af, nullptr, -mp.hard_limit_accel * mp.hard_limit_accel, kw, 0.0);
+            quad_row<true, im, nm>(op, slot_u + 1, ROW_PEN, us, am, nullptr, -mp.hard_limit_alpha * mp.hard_limit_alpha, kw, 0.0);
+        }
+        static_for<0, T::NDEF>([&](auto J) {   // mu |d_kj| (the defect of the last knot moves nothing and is driven to zero)
+            constexpr int j = decltype(J)::value;
+            const double p1 = 1.0, m1 = -1.0;
+            lin_row<true, m0 + j, 1>(op, slot_u + 2 + 2 * j, ROW_PEN, us, &p1, 0.0, kw, 0.0);
+            lin_row<true, m0 + j, 1>(op, slot_u + 3 + 2 * j, ROW_PEN, us, &m1, 0.0, kw, 0.0);
+        });
+    } else
     if constexpr (MODEL == GUSTO_FREEFLYER_SE2 || MODEL == GUSTO_ASTROBEE_SE3 || MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD) {
         constexpr bool is2 = MODEL == GUSTO_FREEFLYER_SE2, man = MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD;
         constexpr int nv = is2 ? 2 : 3, iw = is2 ? 5 : (man ? 10 : 9), nw = is2 ? 1 : 3;

@@ -12,12 +12,12 @@ namespace gusto {
 
 // cost_true: trapezoid control effort (freeflyer_se2.jl:66-76)
 template <class BLK> GD double cost_true(BLK& K, const double* U) {
-    constexpr int m = BLK::m;
+    constexpr int m = BLK::m, mc = m - BLK::T::NDEF;   // (TrajOpt: U rows hold (u, d); only u is costed)
     const int k = K.tid;
     double l = 0;
     if (k >= 1 && k < K.N) {
 #pragma unroll
-        for (int j = 0; j < m; j++) l += 0.5 * K.dt * (U[(k - 1) * m + j] * U[(k - 1) * m + j] + U[k * m + j] * U[k * m + j]);
+        for (int j = 0; j < mc; j++) l += 0.5 * K.dt * (U[(k - 1) * m + j] * U[(k - 1) * m + j] + U[k * m + j] * U[k * m + j]);
     }
     return block_reduce(l, OpSum(), K.misc);
 }
@@ -359,6 +359,254 @@ scp_kernel(const KParams P) {
             if (trips == 1 && (lvl < 0 || visits + 1 >= P.probe_visits))
                 __hip_atomic_fetch_sub(P.queue + SQ_PROBING, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+
+
+// ---- TrajOpt (src/scp/scp_trajopt.jl) -----------------------------------------------------------------------------------
+// convergence_metric (traj_opt.jl:74-85) = evaluate_xtol (scp_trajopt.jl:281-283)
+template <class BLK> GD double convergence_metric_blk(BLK& K, const double* X, const double* Xq) {
+    constexpr int n = BLK::n;
+    const int k = K.tid;
+    double dn = 0, xn = 0;
+    if (k < K.N) {
+#pragma unroll
+        for (int i = 0; i < n; i++) { const double e = X[k * n + i] - Xq[k * n + i]; dn += e * e; xn += X[k * n + i] * X[k * n + i]; }
+    }
+    const double a = block_reduce(dn, OpMax(), K.misc), b = block_reduce(xn, OpMax(), K.misc);
+    return sqrt(a) / sqrt(b);
+}
+// trust_region_ratio_trajopt (freeflyer_se2.jl:429-467, astrobee_se3.jl:419-460) with the index typos of its dynamics terms
+// read as meant -- the forward difference (X[:,k+1]-X[:,k])/dt and the linearised trapezoid defect of interval k -- and the
+// obstacle terms linearised at traj_prev as in trust_region_ratio_gusto (the oracle's go_trajopt_ratio)
+template <int MODEL, class BLK> GD double trajopt_ratio(BLK& K, const double* X, const double* U, const double* Xq, const double* Uq) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n, m = T::m, m0 = m - T::NDEF;
+    const int k = K.tid, N = K.N;
+    double num = 0, den = 0;
+    if (k < N - 1) {
+        double x0[n], x1[n], q0[n], q1[n], u0[m], u1[m], v0[m], v1[m], f[n], fp[n], fp1[n], A[n * n], A1[n * n], B[n * m];
+#pragma unroll
+        for (int i = 0; i < n; i++) { x0[i] = X[k * n + i]; x1[i] = X[(k + 1) * n + i]; q0[i] = Xq[k * n + i]; q1[i] = Xq[(k + 1) * n + i]; }
+#pragma unroll
+        for (int i = 0; i < m; i++) { u0[i] = U[k * m + i]; u1[i] = U[(k + 1) * m + i]; v0[i] = Uq[k * m + i]; v1[i] = Uq[(k + 1) * m + i]; }
+        Dyn<MODEL>::f(K.P.mp, q0, v0, fp); Dyn<MODEL>::A(K.P.mp, q0, v0, A);
+        Dyn<MODEL>::f(K.P.mp, q1, v1, fp1); Dyn<MODEL>::A(K.P.mp, q1, v1, A1);
+        Dyn<MODEL>::f(K.P.mp, x0, u0, f); Dyn<MODEL>::B(K.P.mp, B);
+        double po = 0, pn = 0, ph = 0;
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            double a0 = fp[i], a1 = fp1[i];
+#pragma unroll
+            for (int j = 0; j < n; j++) { a0 += A[i * n + j] * (x0[j] - q0[j]); a1 += A1[i * n + j] * (x1[j] - q1[j]); }
+#pragma unroll
+            for (int j = 0; j < m0; j++) { a0 += B[i * m + j] * (u0[j] - v0[j]); a1 += B[i * m + j] * (u1[j] - v1[j]); }
+            po += fabs(fp[i] - (q1[i] - q0[i]) / K.dt);
+            pn += fabs(f[i] - (x1[i] - x0[i]) / K.dt);
+            ph += fabs(x1[i] - x0[i] - 0.5 * K.dt * (a0 + a1));
+        }
+        num += po - pn; den += po - ph;
+    }
+    if (k < N) {
+        double xw[T::WS], qw[T::WS];
+#pragma unroll
+        for (int j = 0; j < T::WS; j++) { xw[j] = X[k * n + j]; qw[j] = Xq[k * n + j]; }
+        for (int c = 0; c < K.P.mp.n_robot_comp; c++)
+            for (int i = 0; i < K.P.n_obs; i++) {
+                double nh[T::WS], nh1[T::WS];
+                const double d0 = signed_distance<T::WS>(K.P, c, qw, i, nh), d1 = signed_distance<T::WS>(K.P, c, xw, i, nh1);
+                double lin = d0;
+#pragma unroll
+                for (int j = 0; j < T::WS; j++) lin += nh[j] * (xw[j] - qw[j]);
+                const double cl = K.P.mp.clearance;
+                num += (cl - d0) - (cl - d1); den += (cl - d0) - (cl - lin);
+            }
+    }
+    num = block_reduce(num, OpSum(), K.misc);
+    den = block_reduce(den, OpSum(), K.misc);
+    return num / den;
+}
+// evaluate_ctol (scp_trajopt.jl:289-312): per class of constraints the largest change and the largest value over its members,
+// summed over the classes (every class counts: as written the class entered last is dropped)
+template <int MODEL, class BLK> GD double trajopt_ctol(BLK& K, const double* X, const double* U, const double* Xq, const double* Uq) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n, m = T::m;
+    constexpr bool is2 = MODEL == GUSTO_TO_FREEFLYER_SE2;
+    constexpr int nv = is2 ? 2 : 3, iw = is2 ? 5 : 9, nw = is2 ? 1 : 3;
+    const int k = K.tid, N = K.N;
+    const gusto_model_params& mp = K.P.mp;
+    double JN = 0, JD = 0;
+    auto cls = [&](double a, double b) {
+        JN += block_reduce(a, OpMax(), K.misc); JD += block_reduce(b, OpMax(), K.misc);
+    };
+    double x[n], q[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) { x[i] = (k < N) ? X[k * n + i] : 0.0; q[i] = (k < N) ? Xq[k * n + i] : 0.0; }
+    {   // csi_translational_velocity_bound, csi_angular_velocity_bound
+        double g = -mp.hard_limit_vel * mp.hard_limit_vel, gq = g;
+#pragma unroll
+        for (int j = 0; j < nv; j++) { g += x[3 + j] * x[3 + j]; gq += q[3 + j] * q[3 + j]; }
+        cls(k < N ? fabs(g - gq) : 0.0, k < N ? fabs(g) : 0.0);
+        g = -mp.hard_limit_omega * mp.hard_limit_omega; gq = g;
+#pragma unroll
+        for (int j = 0; j < nw; j++) { g += x[iw + j] * x[iw + j]; gq += q[iw + j] * q[iw + j]; }
+        cls(k < N ? fabs(g - gq) : 0.0, k < N ? fabs(g) : 0.0);
+    }
+    if (K.P.n_obs > 0) {   // ncsi_body_obstacle_avoidance_constraints: clearance - dist
+        double a = 0, b = 0;
+        if (k < N) {
+            double xw[T::WS], qw[T::WS], nh[T::WS];
+#pragma unroll
+            for (int j = 0; j < T::WS; j++) { xw[j] = x[j]; qw[j] = q[j]; }
+            for (int i = 0; i < K.P.n_obs; i++) {
+                const double g = mp.clearance - signed_distance<T::WS>(K.P, 0, xw, i, nh);
+                const double gq = mp.clearance - signed_distance<T::WS>(K.P, 0, qw, i, nh);
+                a = fmax(a, fabs(g - gq)); b = fmax(b, fabs(g));
+            }
+        }
+        cls(a, b);
+    }
+    {   // csbci_goal_constraints (BoxGoal rows, :array): wave-uniform, every lane forms it from the last knot
+        double a = 0, b = 0;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            const double lo = K.goal_lo[i], hi = K.goal_hi[i];
+            if (lo == hi) continue;
+            const double xv = X[(N - 1) * n + i], xq = Xq[(N - 1) * n + i];
+            if (isfinite(hi)) { a += (xv - xq) * (xv - xq); b += (xv - hi) * (xv - hi); any = true; }
+            if (isfinite(lo)) { a += (xv - xq) * (xv - xq); b += (lo - xv) * (lo - xv); any = true; }
+        }
+        if (any) { JN += sqrt(a); JD += sqrt(b); }
+    }
+    {   // dynamics_constraints(traj, traj, k): the trapezoid defect of the trajectory itself
+        double a = 0, b = 0;
+        if (k < N - 1) {
+            double x1[n], q1[n], u0[m], u1[m], v0[m], v1[m], f0[n], f1[n], g0[n], g1[n];
+#pragma unroll
+            for (int i = 0; i < n; i++) { x1[i] = X[(k + 1) * n + i]; q1[i] = Xq[(k + 1) * n + i]; }
+#pragma unroll
+            for (int i = 0; i < m; i++) { u0[i] = U[k * m + i]; u1[i] = U[(k + 1) * m + i]; v0[i] = Uq[k * m + i]; v1[i] = Uq[(k + 1) * m + i]; }
+            Dyn<MODEL>::f(mp, x, u0, f0); Dyn<MODEL>::f(mp, x1, u1, f1);
+            Dyn<MODEL>::f(mp, q, v0, g0); Dyn<MODEL>::f(mp, q1, v1, g1);
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                const double F = x1[i] - x[i] - 0.5 * K.dt * (f0[i] + f1[i]), Fq = q1[i] - q[i] - 0.5 * K.dt * (g0[i] + g1[i]);
+                a += (F - Fq) * (F - Fq); b += F * F;
+            }
+        }
+        cls(sqrt(a), sqrt(b));
+    }
+    return JN / JD;
+}
+
+// solve_trajopt_jump! (scp_trajopt.jl:33-157) of one problem: the oracle's go_solve_trajopt, statement for statement
+template <int MODEL> GD void trajopt_problem(const KParams& P, double* lds, int b_, int slot) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n, m = T::m;
+    Blk<MODEL, false> K(P, lds, b_, slot);
+    Prof pf;
+    const int b = K.b, tid = K.tid, N = K.N;
+    const gusto_trajopt_params& tp = P.tp;
+    int* sti = P.st_i + (size_t)b * ST_NI;
+    const size_t hb = (size_t)b * P.hist_cap;
+    const double toggle = P.mp.clearance + 1.0;                                   // :64
+    if (P.mode == 1) {   // one subproblem around the stored (Xp, Up) (parity hook)
+        linearize<MODEL>(K, toggle);
+        IpmOut io;
+        ipm_solve<MODEL>(K, P.sub_Delta[b] /* s */, P.sub_omega[b] /* mu */, 0.0, io, pf);
+        store_traj(K, K.Xw, K.Uw, P.sub_X + (size_t)b * N * n, P.sub_U + (size_t)b * N * m);
+        if (tid == 0) {
+            P.sub_obj[b] = io.obj; P.sub_status[b] = io.status; P.sub_iters[b] = io.iters;
+            for (int i = 0; i < n; i++) P.st_d[(size_t)b * SD_ND + SD_DUAL + i] = K.nu[i] * fmax(1.0, P.sub_omega[b]);
+        }
+        return;
+    }
+    double* w = P.ws + (size_t)slot * P.wl.total + P.wl.to_traj;
+    double *Xpen = w, *Upen = Xpen + N * n, *Xcvx = Upen + N * m, *Ucvx = Xcvx + N * n;
+    // SCPParam_TrajOpt ctor (:25-28): rho_vec = [0.], mu_vec = [mu0], s_vec = [s0], xtol_vec = ftol_vec = ctol_vec = [0.]
+    int n_solves = 0, n_mu = 1, n_xtol = 1, n_ftol = 1, n_ctol = 1, nJ = 0, n_hist = 1, total_ipm = 0;
+    int stop = GUSTO_STOP_MAXITER, converged = 0;
+    if (tid == 0) {
+        P.to_mu[hb] = tp.mu0; P.Delta[hb] = tp.s0; P.to_xtol[hb] = 0.0; P.to_ftol[hb] = 0.0; P.to_ctol[hb] = 0.0; P.rho[hb] = 0.0;
+        P.solver_status[hb] = GUSTO_SOLVER_NA; P.ipm_it[hb] = 0; P.conv[hb] = 0.0;
+    }
+    double mu = tp.mu0, s = tp.s0;
+    double Jt = cost_true(K, K.Up);                                               // :63
+    if (tid == 0) P.J_true[hb + nJ] = Jt;
+    nJ++;
+    auto copy_traj = [&](double* Xd, double* Ud, const double* Xs, const double* Us) {
+        K.sync();
+        for (int e = tid; e < N * n; e += K.nt()) Xd[e] = Xs[e];
+        for (int e = tid; e < N * m; e += K.nt()) Ud[e] = Us[e];
+        K.sync();
+    };
+    const int room = P.hist_cap - 2;   // every vector gets at most one entry per solve plus the leading one
+    bool constraints_satisfied = false, xtol_satisfied = false, halt = false;
+    for (int pi = 0; pi < tp.max_penalty_iteration && !halt; pi++) {
+        if (constraints_satisfied) break;
+        copy_traj(Xpen, Upen, K.Xp, K.Up);                                        // :73 (a copy, not the alias of :67)
+        for (int ci = 0; ci < tp.max_convex_iteration && !halt; ci++) {
+            copy_traj(Xcvx, Ucvx, K.Xp, K.Up);                                    // :76
+            if (constraints_satisfied) break;
+            if (xtol_satisfied) { xtol_satisfied = false; break; }
+            for (int ti = 0; ti < tp.max_trust_iteration; ti++) {
+                if (n_solves >= P.max_iter) { halt = true; break; }
+                if (n_solves >= room || n_xtol >= room) { halt = true; stop = GUSTO_STOP_HIST_FULL; break; }
+                linearize<MODEL>(K, toggle);                                      // :94 update_model_params!
+                IpmOut io;
+                ipm_solve<MODEL>(K, s, mu, 0.0, io, pf);                          // :95-110
+                total_ipm += io.iters;
+                const int h = n_hist;
+                if (tid == 0) { P.solver_status[hb + h] = io.status; P.ipm_it[hb + h] = io.iters; }
+                if (io.status != GUSTO_SOLVER_OPTIMAL && io.status != GUSTO_SOLVER_ALMOST) {   // (:113-116 warns and goes on)
+                    stop = GUSTO_STOP_SUBPROBLEM_FAILED; halt = true; break;
+                }
+                const double xt = convergence_metric_blk(K, K.Xw, Xcvx);           // evaluate_xtol :120-121
+                const double rho = trajopt_ratio<MODEL>(K, K.Xw, K.Uw, Xcvx, Ucvx);  // :127
+                const double s_n = (rho > tp.c) ? tp.tau_plus * s : tp.tau_minus * s;   // :128-132
+                copy_traj(K.Xp, K.Up, K.Xw, K.Uw);                                // :134: every step is taken
+                Jt = cost_true(K, K.Up);
+                if (tid == 0) {
+                    P.to_xtol[hb + n_xtol] = xt; P.conv[hb + h] = xt; P.J_full[hb + n_solves] = io.obj;
+                    P.rho[hb + n_solves + 1] = rho; P.Delta[hb + n_solves + 1] = s_n; P.J_true[hb + nJ] = Jt;
+                    for (int i = 0; i < n; i++) P.st_d[(size_t)b * SD_ND + SD_DUAL + i] = K.nu[i] * fmax(1.0, mu);
+                }
+                n_xtol++; nJ++; n_hist = h + 1; n_solves++;
+                s = s_n;
+                if (s < tp.xtol) { xtol_satisfied = true; break; }                // :140-143
+            }
+            if (halt) break;
+            const double Jn = cost_true(K, K.Up), Jo = cost_true(K, Ucvx);
+            const double ft = fabs(Jn - Jo) / fabs(Jn);                           // evaluate_ftol :146
+            const double xt = convergence_metric_blk(K, K.Xp, Xcvx);              // :147
+            if (tid == 0) { P.to_ftol[hb + n_ftol] = ft; P.to_xtol[hb + n_xtol] = xt; }
+            n_ftol++; n_xtol++;
+            if (ft < tp.ftol || xt < tp.xtol) { constraints_satisfied = true; break; }   // :148 (`xtol[end]` means xtol_vec[end])
+        }
+        if (halt) break;
+        const double ct = trajopt_ctol<MODEL>(K, K.Xp, K.Up, Xpen, Upen);          // :155
+        if (tid == 0) P.to_ctol[hb + n_ctol] = ct;
+        n_ctol++;
+        if (ct < tp.ctol) { constraints_satisfied = true; converged = 1; stop = GUSTO_STOP_CONVERGED; break; }
+        mu *= tp.k;                                                               // :161
+        if (tid == 0) P.to_mu[hb + n_mu] = mu;
+        n_mu++;
+    }
+    pf.flush(P.prof, b, false);
+    if (tid == 0) {
+        sti[ST_ITER] = n_solves; sti[ST_CONV] = converged; sti[ST_SUCC] = 0; sti[ST_STOP] = stop; sti[ST_IPM] = total_ipm;
+        sti[ST_NHIST] = n_hist; sti[ST_NJ] = nJ; sti[ST_NRHO] = n_solves + 1; sti[ST_NMU] = n_mu; sti[ST_NXTOL] = n_xtol;
+        sti[ST_NFTOL] = n_ftol; sti[ST_NCTOL] = n_ctol;
+    }
+}
+// problems in a static round robin over the resident workgroups (no device-side scheduler: TrajOpt problems take 5-25 solves)
+template <int MODEL> __global__ void __launch_bounds__(256, 1) trajopt_kernel(const KParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
+        __syncthreads();
+        trajopt_problem<MODEL>(P, lds, b, blockIdx.x);
+        __syncthreads();
     }
 }
 

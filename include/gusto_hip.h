@@ -176,6 +176,41 @@ int gusto_subproblem(gusto_handle h, int B, const double* Xp, const double* Up, 
                      const double* omega, const double* toggle, double* Xn, double* Un, double* obj, int* status,
                      int* iters);
 
+/* ---- TrajOpt: solve_trajopt_jump!(SCPS, SCPP, solver, max_iter, force) (src/scp/scp_trajopt.jl:33-157), the second SCP
+ * algorithm the reference passes through the same `solve_method!` argument of solve_SCP! (src/traj_opt.jl:47-72) ----------
+ * FreeflyerSE2 and AstrobeeSE3 (the models of this library with a SCPParam_TrajOpt: freeflyer_se2.jl:49-64,
+ * astrobee_se3.jl:50-65).  A TrajOpt handle is a gusto_handle created by gusto_create_trajopt: gusto_set_env,
+ * gusto_set_problems(_dev), gusto_get_traj, gusto_get_status, gusto_get_dual, gusto_last_solve_ms work on it unchanged
+ * (U has the model's u_dim columns on the host side).  Where the file cannot run as written the math it states is built;
+ * the list is in DESIGN.md section 4 (intended L1 dynamics penalty, hard x_1 = x_init, index typos of
+ * trust_region_ratio_trajopt, the class evaluate_ctol drops, max_iter as a cap on the subproblem solves). */
+/* SCPParam_TrajOpt (scp_trajopt.jl:3-30) */
+typedef struct {
+    double mu0, s0, c, tau_plus, tau_minus, k, ftol, xtol, ctol;
+    int max_penalty_iteration, max_convex_iteration, max_trust_iteration;
+} gusto_trajopt_params;
+int gusto_default_trajopt_params(int model_id, gusto_trajopt_params* tp);
+/* SCPProblem(TOP) + SCPParam_TrajOpt(model) for a batch; hist_cap >= 2 * max_penalty * max_convex * max_trust + 8 entries */
+int gusto_create_trajopt(gusto_handle* h, int model_id, int N, int batch_cap, int hist_cap, int device);
+int gusto_set_trajopt_params(gusto_handle h, const gusto_trajopt_params* tp);
+/* the whole three-loop schedule (penalty mu x k, convex iterations, trust region s x tau+-) for every problem of the batch;
+ * max_iter caps the number of convex subproblems per problem (the reference computes iter_cap and never reads it) */
+int gusto_solve_trajopt(gusto_handle h, int max_iter);
+/* SCPParam_TrajOpt vectors as [B][hist_cap] arrays with their lengths [B]: rho_vec and s_vec have 1 + iterations entries,
+ * J_true 1 + iterations, J_full / convergence_measure / solver_status iterations (solver_status, ipm_iters and
+ * convergence_measure start at row 1 like the GuSTO histories).  Any pointer may be NULL. */
+typedef struct {
+    int hist_cap; /* IN: row capacity of the arrays below, >= the handle's */
+    int *n_solves, *n_mu, *n_xtol, *n_ftol, *n_ctol;
+    double *rho_vec, *s_vec, *mu_vec, *xtol_vec, *ftol_vec, *ctol_vec, *J_true, *J_full, *convergence_measure;
+    int *solver_status, *ipm_iters;
+} gusto_trajopt_history;
+int gusto_get_trajopt_history(gusto_handle h, gusto_trajopt_history* out);
+/* One TrajOpt subproblem (:159-279) per problem around (Xp, Up)[b] with penalty mu[b] and trust region s[b] (parity tests).
+ * Up, Un: [B][N][u_dim]; Dn (may be NULL): the defect variables of the optimum, [B][N][x_dim]. */
+int gusto_subproblem_trajopt(gusto_handle h, int B, const double* Xp, const double* Up, const double* mu, const double* s,
+                             double* Xn, double* Un, double* Dn, double* obj, int* status, int* iters);
+
 /* Development hook (libraries built with -DGUSTO_PROFILE only, otherwise GUSTO_ERR_STATE): per-problem cycle counters of
  * the kernel's phases, [B][32] (tools/gpu_prof.py).  Stands in for SCPS.iter_elapsed_times at a finer grain. */
 int gusto_dev_get_prof(gusto_handle h, long long* out);
