@@ -254,10 +254,12 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     using C1 = LdsC<MODEL, true>;
     using CM = LdsC<MODEL, false>;
     LdsLayout L;
-    L.total = (N <= 64 ? C1::vecs : CM::vecs) + N * (C1::NVN * C1::n + C1::NVM * C1::m);
+    // (the TrajOpt variants run the multi-wave phases whatever N: their layout is the multi-wave one)
+    const bool one = N <= 64 && MT<MODEL>::NDEF == 0;
+    L.total = (one ? C1::vecs : CM::vecs) + N * (C1::NVN * C1::n + C1::NVM * C1::m);
     L.phicl = -1;
-    if (C1::KD_LDS && N <= 64) { L.phicl = L.total; L.total += N * C1::KDS; }
-    else if (C1::PHICL_LDS && N <= 64) { L.phicl = L.total; L.total += N * C1::n * C1::n; }
+    if (C1::KD_LDS && one) { L.phicl = L.total; L.total += N * C1::KDS; }
+    else if (C1::PHICL_LDS && one) { L.phicl = L.total; L.total += N * C1::n * C1::n; }
     return L;
 }
 

@@ -267,6 +267,45 @@ def solve_SCP(TOS, TOP, solve_method, init_method, solver="hip", max_iter=30, fo
     return SCPS
 
 
+# ---- TrajOpt behind the same seam: solve_trajopt_jump! -> solve_trajopt_hip! (src/scp/scp_trajopt.jl:33) ------------------
+def solve_trajopt_hip(SCPS, SCPP, solver="hip", max_iter=125, force=False, device=0, trajopt_params=None, **kwarg):
+    """Same positional signature as solve_trajopt_jump! (scp_trajopt.jl:33): solve_SCP!(TOS, TOP, solve_trajopt_hip!, init,
+    "hip").  FreeflyerSE2 and AstrobeeSE3.  Fills the SCPSolution vectors the reference pushes (J_true, J_full,
+    convergence_measure, solver_status, dual, iterations, converged) and SCPP.param.alg's rho_vec / mu_vec / s_vec /
+    xtol_vec / ftol_vec / ctol_vec (here: attributes of SCPP).  `max_iter` caps the convex subproblems (the reference
+    computes iter_cap and never reads it); `force` is unused there too."""
+    model = SCPP.PD.model
+    n, N = model.x_dim, SCPP.N
+    env = SCPP.PD.env
+    tp = trajopt_params or _capi.default_trajopt_params(model.model_id)
+    total = tp.max_penalty_iteration * tp.max_convex_iteration * tp.max_trust_iteration
+    bs = _capi.TrajOptSolver(model.model_id, N, 1, hist_cap=2 * total + 16, device=device, boxes=env.boxes, spheres=env.spheres,
+                             model_params=SCPP.model_params, trajopt_params=tp)
+    lo, hi = _goal_bounds(SCPP.PD.goal_set, n, SCPP.tf_guess)
+    bs.set_problems(SCPP.PD.x_init[None], lo[None], hi[None], [SCPP.tf_guess], SCPS.traj.X.T[None].copy(), SCPS.traj.U.T[None].copy())
+    bs.solve(max_iter)
+    X, U = bs.traj()
+    st, h = bs.status(), bs.history()
+    ns = int(st["iterations"][0])
+    SCPS.traj.X, SCPS.traj.U = X[0].T.copy(), U[0].T.copy()
+    SCPS.J_true = list(h["J_true"][0, :ns + 1])
+    SCPS.J_full = list(h["J_full"][0, :ns])
+    SCPS.convergence_measure = [0.0] + list(h["convergence_measure"][0, 1:ns + 1])
+    stop = int(st["stop_reason"][0])
+    SCPS.solver_status = [SOLVER_STATUS[int(v)] for v in h["solver_status"][0, :ns + 1 + (stop == 2)]]
+    SCPS.iterations, SCPS.converged, SCPS.successful = ns, bool(st["converged"][0]), False
+    SCPS.stop_reason = _capi.STOP_REASON[stop]
+    SCPS.dual = bs.dual()[0].copy()
+    SCPS.total_time += bs.last_solve_ms() * 1e-3
+    SCPS.iter_elapsed_times = [0.0] + [SCPS.total_time / max(1, ns)] * ns
+    SCPP.rho_vec, SCPP.s_vec = list(h["rho_vec"][0, :ns + 1]), list(h["s_vec"][0, :ns + 1])
+    SCPP.mu_vec = list(h["mu_vec"][0, :h["n_mu"][0]])
+    SCPP.xtol_vec, SCPP.ftol_vec = list(h["xtol_vec"][0, :h["n_xtol"][0]]), list(h["ftol_vec"][0, :h["n_ftol"][0]])
+    SCPP.ctol_vec = list(h["ctol_vec"][0, :h["n_ctol"][0]])
+    SCPP.obstacle_toggle_distance = SCPP.model_params.clearance + 1.0      # scp_trajopt.jl:64
+    SCPS._solver = bs
+
+
 # ---- indirect shooting seeded by the SCP dual (src/shooting.jl, src/traj_opt.jl:4-45, src/types.jl:187-227) --------------
 class ShootingProblem:
     """types.jl:219-227: p0 = SCPS.dual, tf = SCPS.traj.Tf, x_goal = centre of the goals at the final time (zeros

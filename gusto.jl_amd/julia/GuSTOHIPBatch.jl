@@ -97,3 +97,74 @@ function solve_SCP_batch!(TOSs::Vector, TOPs::Vector, init_method=init_traj_stra
   end
   nothing
 end
+
+# ---- TrajOpt behind the same seam: solve_SCP!(TOS, TOP, solve_trajopt_hip!, init_traj_straightline, "hip") -----------------
+# positional signature of solve_trajopt_jump! (src/scp/scp_trajopt.jl:33); FreeflyerSE2 and AstrobeeSE3
+struct GustoTrajOptParams      # gusto_trajopt_params
+  mu0::Cdouble; s0::Cdouble; c::Cdouble; tau_plus::Cdouble; tau_minus::Cdouble; k::Cdouble; ftol::Cdouble; xtol::Cdouble; ctol::Cdouble
+  max_penalty_iteration::Cint; max_convex_iteration::Cint; max_trust_iteration::Cint
+end
+
+mutable struct GustoTrajOptHistory  # gusto_trajopt_history
+  hist_cap::Cint
+  n_solves::Ptr{Cint}; n_mu::Ptr{Cint}; n_xtol::Ptr{Cint}; n_ftol::Ptr{Cint}; n_ctol::Ptr{Cint}
+  rho_vec::Ptr{Cdouble}; s_vec::Ptr{Cdouble}; mu_vec::Ptr{Cdouble}; xtol_vec::Ptr{Cdouble}; ftol_vec::Ptr{Cdouble}; ctol_vec::Ptr{Cdouble}
+  J_true::Ptr{Cdouble}; J_full::Ptr{Cdouble}; convergence_measure::Ptr{Cdouble}
+  solver_status::Ptr{Cint}; ipm_iters::Ptr{Cint}
+end
+
+function solve_trajopt_hip!(SCPS::SCPSolution, SCPP::SCPProblem, solver="hip", max_iter=125, force=false; device=0, kwarg...)
+  model, N = SCPP.PD.model, SCPP.N
+  n, m = model.x_dim, model.u_dim
+  SCPP.param.alg = SCPParam_TrajOpt(model)                       # :44
+  a = SCPP.param.alg
+  tp = GustoTrajOptParams(a.mu0, a.s0, a.c, a.τ_plus, a.τ_minus, a.k, a.ftol, a.xtol, a.ctol,
+                          a.max_penalty_iteration, a.max_convex_iteration, a.max_trust_iteration)
+  cap = 2 * a.max_penalty_iteration * a.max_convex_iteration * a.max_trust_iteration + 16
+  href = Ref{Ptr{Cvoid}}(C_NULL)
+  gusto_check(ccall((:gusto_create_trajopt, libgusto_hip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint),
+                    href, gusto_model_id(model), N, 1, cap, device), href[], "create_trajopt")
+  h = href[]
+  gusto_check(ccall((:gusto_set_params, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{GustoModelParams}),
+                    h, C_NULL, gusto_model_params(SCPP.PD.robot, model)), h, "set_params")
+  gusto_check(ccall((:gusto_set_trajopt_params, libgusto_hip), Cint, (Ptr{Cvoid}, Ref{GustoTrajOptParams}), h, tp), h, "set_trajopt_params")
+  boxes, spheres = gusto_env_tables(SCPP.PD.env)
+  gusto_check(ccall((:gusto_set_env, libgusto_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}),
+                    h, length(boxes) ÷ 6, boxes, length(spheres) ÷ 4, spheres), h, "set_env")
+  lo, hi = gusto_goal_bounds(SCPP.PD.goal_set, n, SCPP.tf_guess)
+  gusto_check(ccall((:gusto_set_problems, libgusto_hip), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                    h, 1, Float64.(SCPP.PD.x_init), lo, hi, [Float64(SCPP.tf_guess)], Matrix{Float64}(SCPS.traj.X), Matrix{Float64}(SCPS.traj.U)), h, "set_problems")
+  t0 = time_ns()
+  gusto_check(ccall((:gusto_solve_trajopt, libgusto_hip), Cint, (Ptr{Cvoid}, Cint), h, max_iter), h, "solve_trajopt")
+  elapsed = (time_ns() - t0) / 10^9
+  X, U = zeros(n, N), zeros(m, N)
+  gusto_check(ccall((:gusto_get_traj, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), h, X, U), h, "get_traj")
+  SCPS.traj.X, SCPS.traj.U = X, U
+  its, conv, stop = zeros(Cint, 1), zeros(Cint, 1), zeros(Cint, 1)
+  gusto_check(ccall((:gusto_get_status, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cvoid}),
+                    h, its, conv, C_NULL, stop, C_NULL), h, "get_status")
+  d() = zeros(Cdouble, cap); ns, nm, nx, nf, nc = (zeros(Cint, 1) for _ in 1:5)
+  rho, sv, muv, xt, ft, ct, Jt, Jf, cm = (d() for _ in 1:9)
+  sol, ipi = zeros(Cint, cap), zeros(Cint, cap)
+  hist = GustoTrajOptHistory(cap, pointer(ns), pointer(nm), pointer(nx), pointer(nf), pointer(nc), pointer(rho), pointer(sv), pointer(muv),
+                             pointer(xt), pointer(ft), pointer(ct), pointer(Jt), pointer(Jf), pointer(cm), pointer(sol), pointer(ipi))
+  GC.@preserve ns nm nx nf nc rho sv muv xt ft ct Jt Jf cm sol ipi begin
+    gusto_check(ccall((:gusto_get_trajopt_history, libgusto_hip), Cint, (Ptr{Cvoid}, Ref{GustoTrajOptHistory}), h, hist), h, "get_trajopt_history")
+  end
+  S = Int(ns[1])
+  SCPS.J_true, SCPS.J_full = Jt[1:S+1], Jf[1:S]
+  SCPS.convergence_measure = vcat(0., cm[2:S+1])
+  SCPS.solver_status = [GUSTO_SOLVER_STATUS[s+1] for s in sol[1:S+1]]
+  SCPS.iterations, SCPS.converged = S, conv[1] != 0
+  SCPS.total_time += elapsed
+  SCPS.iter_elapsed_times = vcat(0., fill(SCPS.total_time / max(1, S), S))
+  dual = zeros(n)
+  gusto_check(ccall((:gusto_get_dual, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), h, dual), h, "get_dual")
+  SCPS.dual = dual
+  a.ρ_vec, a.s_vec, a.mu_vec = rho[1:S+1], sv[1:S+1], muv[1:nm[1]]
+  a.xtol_vec, a.ftol_vec, a.ctol_vec = xt[1:nx[1]], ft[1:nf[1]], ct[1:nc[1]]
+  SCPP.param.obstacle_toggle_distance = model.clearance + 1.     # :64
+  ccall((:gusto_destroy, libgusto_hip), Cint, (Ptr{Cvoid},), h)
+  nothing
+end

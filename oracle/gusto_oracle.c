@@ -1931,6 +1931,13 @@ int go_solve_trajopt(go_problem* p, int max_iter) {
                 const int st = ipm_solve(p, p->X, p->U, s, mu, p->toggle, &info);      /* :98-110 */
                 const int h = p->n_hist;
                 p->solver_status[h] = st; p->ipm_it[h] = info.iters; p->total_ipm += info.iters;
+                p->Delta[h] = s; p->omega[h] = mu;   /* (the trip's own s and mu, for the lock-step tests) */
+                p->accept[h] = 1; p->scp_status[h] = GO_SCP_NA; p->tr_sat[h] = 1; p->cvx_sat[h] = 0;
+                if (p->n_trace < p->trace_cap) {     /* go_set_trace: (traj before the trip, its optimum) */
+                    const size_t t = p->n_trace++;
+                    memcpy(p->trXp + t * n * N, p->X, nx); memcpy(p->trUp + t * m * N, p->U, nu);
+                    memcpy(p->trXn + t * n * N, p->Xw, nx); memcpy(p->trUn + t * m * N, p->Uw, nu);
+                }
                 if (st != GO_SOLVER_OPTIMAL && st != GO_SOLVER_ALMOST) {                /* (:113-116 warns and goes on with the values) */
                     p->stop_reason = GO_STOP_SUBPROBLEM_FAILED; stop = 1; break;
                 }

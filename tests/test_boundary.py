@@ -138,7 +138,8 @@ def test_julia_wrapper_matches_the_c_header():
     hdr = open(os.path.join(ROOT, "include", "gusto_hip.h")).read()
     syms = set(re.findall(r"ccall\(\(:(\w+), libgusto_hip\)", jl))
     assert {"gusto_create", "gusto_set_params", "gusto_set_env", "gusto_set_problems", "gusto_solve", "gusto_solve_async",
-            "gusto_wait", "gusto_get_traj", "gusto_get_status", "gusto_get_history", "gusto_get_dual", "gusto_shoot"} <= syms
+            "gusto_wait", "gusto_get_traj", "gusto_get_status", "gusto_get_history", "gusto_get_dual", "gusto_shoot",
+            "gusto_create_trajopt", "gusto_set_trajopt_params", "gusto_solve_trajopt", "gusto_get_trajopt_history"} <= syms
     L = g.lib()
     for s in syms:
         assert hasattr(L, s) and re.search(r"\b%s\(" % s, hdr), s
@@ -174,7 +175,8 @@ def test_julia_wrapper_matches_the_c_header():
         return f"NTuple{{{count},{base}}}" if count else base
 
     for cname, jname in (("gusto_scp_params", "GustoScpParams"), ("gusto_model_params", "GustoModelParams"),
-                         ("gusto_history", "GustoHistory"), ("gusto_shoot_opts", "GustoShootOpts")):
+                         ("gusto_history", "GustoHistory"), ("gusto_shoot_opts", "GustoShootOpts"),
+                         ("gusto_trajopt_params", "GustoTrajOptParams"), ("gusto_trajopt_history", "GustoTrajOptHistory")):
         cf, jf = c_fields(cname), jl_fields(jname)
         assert [n for n, _, _ in cf] == [n for n, _ in jf], (cname, cf, jf)
         assert [jl_type(t, c) for _, t, c in cf] == [t for _, t in jf], (cname, cf, jf)

@@ -1,0 +1,186 @@
+"""GPU parity of TrajOpt behind the seam (src/scp/scp_trajopt.jl -> gusto_solve_trajopt): the HIP path through the C ABI
+against the CPU oracle on identical seeded problems -- subproblem by subproblem, trip by trip of whole runs (lock-step:
+the oracle's own (traj, mu, s) of every trip goes to the device), whole runs, and properties at a larger batch.
+Tolerances: both sides run the same interior point algorithm to a 1e-8 residual of the problem scaled by 1/max(1, mu).
+The L1-penalised dynamics make the subproblem nearly a linear programme in the defect directions (their only curvature is
+the 1e-4 regularisation), so its optimum is determined less sharply than GuSTO's: X, U, defects
+within 5e-5 * max(1, mu) (measured: 1e-14 ... 1.5e-5), objective 1e-6 relative, rho and the tolerance measures 1e-4 relative (rho is a ratio of
+differences), schedules (s_vec, mu_vec, counts, statuses) exact."""
+import numpy as np
+import pytest
+
+import gusto_jl_amd as g
+import gusto_oracle as go
+
+pytestmark = pytest.mark.gpu
+P = g.problems
+H = g.host
+
+
+def _setup(model, B):
+    if model == g.FREEFLYER_SE2:
+        return P.freeflyer_batch(B), P.freeflyer_env(), None
+    bx, sp = P.iss_corner_env(True)
+    return P.astrobee_se3_batch(B), bx, sp
+
+
+@pytest.mark.parametrize("model", [g.FREEFLYER_SE2, g.ASTROBEE_SE3])
+@pytest.mark.parametrize("mu,s_tr", [(1.0, 1.0), (5.0, 0.25), (125.0, 0.03)])
+def test_subproblem_parity(model, mu, s_tr):
+    B = 24
+    (x0, glo, ghi, tf), boxes, spheres = _setup(model, B)
+    s = g.TrajOptSolver(model, 50, B, boxes=boxes, spheres=spheres)
+    s.set_problems(x0, glo, ghi, tf)
+    X0, U0 = s.traj()
+    r = s.subproblem(X0, U0, mu, s_tr)
+    o = go.OracleTrajOpt(model, 50, boxes=boxes, spheres=spheres)
+    for b in range(B):
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        ro = o.subproblem(X0[b], U0[b], mu, s_tr)
+        assert r["status"][b] == ro["status"] and ro["status"] in (1, 2), (b, r["status"][b], ro["status"])
+        tol = 5e-5 * max(1.0, mu)
+        assert np.abs(r["X"][b] - ro["X"]).max() < tol and np.abs(r["U"][b] - ro["U"]).max() < tol, b
+        assert np.abs(r["D"][b] - ro["D"]).max() < tol
+        assert abs(r["obj"][b] - ro["obj"]) <= 1e-6 * max(1.0, mu) * max(1.0, abs(ro["obj"]))
+        assert np.abs(r["dual"][b] - ro["dual"]).max() < 1e-5 * max(1.0, np.abs(ro["dual"]).max()) * max(1.0, mu)
+
+
+@pytest.mark.parametrize("model,B", [(g.FREEFLYER_SE2, 48), (g.ASTROBEE_SE3, 24)])
+def test_whole_runs_match_the_oracle(model, B):
+    """solve_trajopt_jump! end to end: identical schedules (number of solves, s_vec, mu_vec, lengths of every vector,
+    converged, stop reason), rho / xtol / ftol / ctol / J histories and the final trajectory."""
+    (x0, glo, ghi, tf), boxes, spheres = _setup(model, B)
+    s = g.TrajOptSolver(model, 50, B, boxes=boxes, spheres=spheres)
+    s.set_problems(x0, glo, ghi, tf)
+    s.solve(125)
+    X, U = s.traj()
+    st, h = s.status(), s.history()
+    o = go.OracleTrajOpt(model, 50, boxes=boxes, spheres=spheres)
+    trips = 0
+    for b in range(B):
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        R = o.solve_trajopt(125)
+        S = R["solves"]
+        trips += S
+        assert st["iterations"][b] == S and bool(st["converged"][b]) == R["converged"] and st["stop_reason"][b] == R["stop_reason"], b
+        assert h["n_mu"][b] == len(R["mu_vec"]) and h["n_xtol"][b] == len(R["xtol_vec"]) and h["n_ftol"][b] == len(R["ftol_vec"])
+        assert h["n_ctol"][b] == len(R["ctol_vec"])
+        assert np.array_equal(h["s_vec"][b, :S + 1], R["s_vec"]) and np.array_equal(h["mu_vec"][b, :h["n_mu"][b]], R["mu_vec"])
+        assert np.array_equal(h["solver_status"][b, 1:S + 1], R["solver_status"][1:S + 1])
+        assert np.allclose(h["rho_vec"][b, :S + 1], R["rho_vec"], rtol=1e-4, atol=1e-8)
+        for k, ref in (("xtol_vec", R["xtol_vec"]), ("ftol_vec", R["ftol_vec"]), ("ctol_vec", R["ctol_vec"])):
+            assert np.allclose(h[k][b, :len(ref)], ref, rtol=1e-4, atol=1e-9), (b, k)
+        assert np.allclose(h["J_true"][b, :S + 1], R["J_true"], rtol=1e-7, atol=1e-12)
+        assert np.allclose(h["J_full"][b, :S], R["J_full"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(h["convergence_measure"][b, 1:S + 1], R["conv"][1:S + 1], rtol=1e-4, atol=1e-9)
+        assert np.abs(X[b] - R["X"]).max() < 5e-5 * R["mu_vec"][-1] and np.abs(U[b] - R["U"]).max() < 5e-5 * R["mu_vec"][-1], b
+    assert trips >= 5 * B
+
+
+@pytest.mark.parametrize("model,B", [(g.FREEFLYER_SE2, 32), (g.ASTROBEE_SE3, 16)])
+def test_lockstep_every_trip(model, B):
+    """Every trip of every problem from the ORACLE's own state: its (traj, defects, mu, s) before the trip goes through
+    gusto_subproblem_trajopt and the optimum must be the oracle's optimum of that trip."""
+    (x0, glo, ghi, tf), boxes, spheres = _setup(model, B)
+    o = go.OracleTrajOpt(model, 50, boxes=boxes, spheres=spheres)
+    m0 = o.m0
+    s = g.TrajOptSolver(model, 50, B, boxes=boxes, spheres=spheres)
+    s.set_problems(x0, glo, ghi, tf)
+    runs = []
+    for b in range(B):
+        o.set_trace(64)
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        R = o.solve_trajopt(125)
+        runs.append((R, o.trace()))
+    T = max(R["solves"] for R, _ in runs)
+    trips = 0
+    for t in range(T):
+        # problems that have no trip t repeat their last one (the batch call wants B problems)
+        tt = [min(t, R["solves"] - 1) for R, _ in runs]
+        Xp = np.stack([tr[i]["Xp"] for (R, tr), i in zip(runs, tt)])
+        Up = np.stack([tr[i]["Up"][:, :m0] for (R, tr), i in zip(runs, tt)])
+        mu = np.array([R["omega"][i + 1] for (R, _), i in zip(runs, tt)])
+        s_tr = np.array([R["Delta"][i + 1] for (R, _), i in zip(runs, tt)])
+        sub = s.subproblem(Xp, Up, mu, s_tr)
+        for b, ((R, tr), i) in enumerate(zip(runs, tt)):
+            if i != t:
+                continue
+            trips += 1
+            assert sub["status"][b] == R["solver_status"][i + 1], (b, t)
+            tol = 5e-5 * max(1.0, mu[b])
+            assert np.abs(sub["X"][b] - tr[i]["Xn"]).max() < tol and np.abs(sub["U"][b] - tr[i]["Un"][:, :m0]).max() < tol, (b, t)
+            assert np.abs(sub["D"][b] - tr[i]["Un"][:, m0:]).max() < tol
+            assert abs(sub["obj"][b] - R["J_full"][i]) <= 1e-6 * max(1.0, mu[b]) * max(1.0, abs(R["J_full"][i]))
+    assert trips == sum(R["solves"] for R, _ in runs) >= 5 * B
+
+
+def test_properties_at_batch_1024():
+    """size-independent properties at a larger batch: bitwise determinism, hard boundary rows, the trust region of the last
+    step, vanishing defects once the penalty has grown, the cost histories."""
+    model, B = g.FREEFLYER_SE2, 1024
+    (x0, glo, ghi, tf), boxes, spheres = _setup(model, B)
+    s = g.TrajOptSolver(model, 50, B, boxes=boxes, spheres=spheres)
+    out = []
+    for _ in range(2):
+        s.set_problems(x0, glo, ghi, tf)
+        s.solve(125)
+        out.append(s.traj() + (s.status(), s.history()))
+    (X, U, st, h), (X2, U2, st2, h2) = out
+    assert np.array_equal(X, X2) and np.array_equal(U, U2) and np.array_equal(st["iterations"], st2["iterations"])
+    assert np.array_equal(h["rho_vec"], h2["rho_vec"])
+    # (a failed subproblem is data: 3 of these 1024 problems stop with SubproblemFailed -- on the oracle too)
+    ok = st["stop_reason"] <= 1
+    assert (st["stop_reason"] <= 2).all() and ok.sum() >= B - 8 and (st["iterations"][ok] >= 4).all()
+    assert np.abs(X[:, 0] - x0).max() < 1e-9 and np.abs(X[ok, -1] - glo[ok]).max() < 1e-7
+    tp = g.default_trajopt_params(model)
+    for b in range(0, B, 37):
+        S = st["iterations"][b]
+        sv, rv = h["s_vec"][b, :S + 1], h["rho_vec"][b, :S + 1]
+        assert sv[0] == tp.s0 and all(sv[i + 1] == (tp.tau_plus if rv[i + 1] > tp.c else tp.tau_minus) * sv[i] for i in range(S))
+        mv = h["mu_vec"][b, :h["n_mu"][b]]
+        assert mv[0] == tp.mu0 and np.allclose(mv[1:] / mv[:-1], tp.k)
+        assert np.isfinite(h["J_true"][b, :S + 1]).all() and (h["J_true"][b, 1:S + 1] > 0).all() or not ok[b]
+    # trapezoid defects of the returned trajectories: below 1e-6 for most problems whose penalty reached 25 (two increases)
+    mp = g.default_params(model)[1]
+    dt = tf[0] / 49
+    A = np.kron(np.array([[0.0, 1.0], [0.0, 0.0]]), np.eye(3))
+    Bm = np.zeros((6, 3)); Bm[3, 0] = Bm[4, 1] = 1 / mp.mass; Bm[5, 2] = 1 / mp.Jdiag[2]
+    a = X @ A.T + U @ Bm.T
+    F = X[:, 1:] - X[:, :-1] - 0.5 * dt * (a[:, :-1] + a[:, 1:])
+    grown = (h["n_mu"] >= 3) & ok
+    small = np.abs(F[grown]).reshape(grown.sum(), -1).max(axis=1) < 1e-6
+    assert grown.sum() > B // 2 and small.mean() > 0.9
+
+
+def test_through_the_seam_and_error_paths():
+    """solve_SCP!(TOS, TOP, solve_trajopt_hip!, init_traj_straightline, "hip") on the notebook problem; the models without
+    a SCPParam_TrajOpt and the calls that belong to the other algorithm fail loudly."""
+    model = H.FreeflyerSE2()
+    gs = H.GoalSet()
+    H.add_goal(gs, H.Goal(H.PointGoal(P.FREEFLYER_X_GOAL), P.FREEFLYER_TF, model))
+    PD = H.ProblemDefinition(H.Robot(), model, H.Environment(P.freeflyer_env()), P.FREEFLYER_X_INIT, gs)
+    TOP = H.TrajectoryOptimizationProblem(PD, 50, P.FREEFLYER_TF, fixed_final_time=True)
+    TOS = H.TrajectoryOptimizationSolution(TOP)
+    SCPS = H.solve_SCP(TOS, TOP, H.solve_trajopt_hip, H.init_traj_straightline, "hip", max_iter=125)
+    o = go.OracleTrajOpt(go.FREEFLYER_SE2, 50, boxes=P.freeflyer_env())
+    o.set_problem(P.FREEFLYER_X_INIT, P.FREEFLYER_X_GOAL, P.FREEFLYER_X_GOAL, P.FREEFLYER_TF)
+    R = o.solve_trajopt(125)
+    assert SCPS.iterations == R["solves"] and SCPS.converged == R["converged"] and TOS.traj is SCPS.traj
+    assert np.abs(TOS.traj.X.T - R["X"]).max() < 1e-6 and TOS.traj.U.shape == (3, 50)
+    assert len(SCPS.J_true) == R["solves"] + 1 and len(SCPS.J_full) == R["solves"] == len(SCPS.convergence_measure) - 1
+    assert SCPS.SCPP.mu_vec == list(R["mu_vec"]) and SCPS.SCPP.s_vec == list(R["s_vec"])
+    assert np.abs(SCPS.dual - R["dual"]).max() < 1e-5 * max(1.0, np.abs(R["dual"]).max()) * R["mu_vec"][-1]
+    with pytest.raises(g.GustoError):
+        g.TrajOptSolver(g.DUBINS_CAR, 30, 2)
+    s = g.TrajOptSolver(g.FREEFLYER_SE2, 50, 2, boxes=P.freeflyer_env())
+    x0, glo, ghi, tf = P.freeflyer_batch(2)
+    s.set_problems(x0, glo, ghi, tf)
+    with pytest.raises(g.GustoError):
+        g.BatchSolver.solve(s, 30)                 # gusto_solve on a TrajOpt handle
+    b = g.BatchSolver(g.FREEFLYER_SE2, 50, 2, boxes=P.freeflyer_env())
+    b.set_problems(x0, glo, ghi, tf)
+    assert b.L.gusto_solve_trajopt(b.h, 10) != 0   # and the other way round
+    small = g.TrajOptSolver(g.FREEFLYER_SE2, 50, 2, hist_cap=16, boxes=P.freeflyer_env())
+    small.set_problems(x0, glo, ghi, tf)
+    with pytest.raises(g.GustoError):
+        small.solve(125)                           # hist_cap below the schedule's needs: refused, not truncated
