@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
 
 SUB_ATOL = 1e-6
 TRAJ_ATOL = 1e-3
+# verdict mismatches the lock-step tests tolerate, as COUNTS of trips: what was measured (0 everywhere), with a margin of one
+GATE_FLAGS_SE3 = GATE_FLAGS_MANIFOLD = 1
 
 
 def _mods():
@@ -160,7 +162,7 @@ def _lockstep_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30, sub_
     # stopping test one iteration earlier, the difference is that last Newton step, which the horizon amplifies by up
     # to tf^2/2m ~ 1e3 from the residual tolerance: gated at 20 x sub_atol.
     same_it = sub["iters"] == C_("it_c")
-    assert same_it.mean() > 0.6
+    assert same_it.mean() >= 0.9, same_it.mean()          # (measured: 0.92 ... 1.0)
     assert ex[same_it].max() < sub_atol and eu[same_it].max() < u_atol, (ex[same_it].max(), eu[same_it].max())
     assert ex.max() < 20 * sub_atol and eu.max() < 20 * u_atol, (ex.max(), eu.max(), trips[int(ex.argmax())])
     assert np.quantile(ex, q_tight) < 0.01 * sub_atol and np.quantile(eu, q_tight) < 0.01 * u_atol
@@ -182,7 +184,8 @@ def _lockstep_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30, sub_
     for kd, ko in flags.items():
         same &= h[kd][:, 1] == R(ko)
     same &= (h["Delta"][:, 1] == R("Delta")) & (h["omega"][:, 1] == R("omega"))
-    assert (~same).sum() <= max(1, int(max_flag_mismatch * T)), ((~same).sum(), T, [trips[i] for i in np.nonzero(~same)[0][:8]])
+    allowed = int(max_flag_mismatch) if max_flag_mismatch >= 1 else max(1, int(max_flag_mismatch * T))
+    assert (~same).sum() <= allowed, ((~same).sum(), T, [trips[i] for i in np.nonzero(~same)[0][:8]])
     acc = same & (R("accept") == 1)
     eJ = np.abs(h["J_true"][acc, 1] - C_("J_c")[acc]) / np.maximum(1e-12, np.abs(C_("J_c")[acc]))
     assert eJ[same_it[acc]].max() < 2e-6 and eJ.max() < 1e-4, eJ.max()      # J = sum u^2: twice the relative error of u
@@ -287,21 +290,41 @@ def test_lockstep_parity_dubins():
     print("lockstep dubins", _lockstep_parity(g.DUBINS_CAR, 30, None, None, x0, glo, ghi, tf))
 
 
+def _with_raised_penalty(model, N, env, spheres, batch, want, n_raised):
+    """`want` problems of `batch`, the first up to `n_raised` of them those whose penalty weight omega the oracle raises
+    (the long, ill-conditioned runs), the rest in index order."""
+    x0, glo, ghi, tf = batch
+    runs = _oracle_runs(model, N, env, spheres, x0, glo, ghi, tf, 30, cold=False)
+    raised = [b for b, (r, _) in enumerate(runs) if r["omega"].max() > 1.5 * r["omega"][0]]
+    pick = raised[:n_raised]
+    pick += [b for b in range(len(x0)) if b not in pick][:want - len(pick)]
+    pick = np.array(sorted(pick))
+    return (x0[pick], glo[pick], ghi[pick], tf[pick]), len([b for b in pick if b in raised])
+
+
 def test_lockstep_parity_astrobee_se3():
+    """BASELINE config 4 model, every trip of 64 problems run to max_iter = 30, among them the problems whose penalty weight
+    is raised (astrobee_se3.jl:322-417): the matrix-core factor sweep, the low-rank trust-region Hessian and the recomputed
+    stage matrices are what these trips exercise."""
     g, _ = _mods()
     P = g.problems
     boxes, sph = P.iss_corner_env(True)
-    x0, glo, ghi, tf = P.astrobee_se3_batch(8)
-    print("lockstep se3", _lockstep_parity(g.ASTROBEE_SE3, 50, boxes, sph, x0, glo, ghi, tf, max_iter=10, max_flag_mismatch=0.02))
+    batch, n_raised = _with_raised_penalty(g.ASTROBEE_SE3, 50, boxes, sph, P.astrobee_se3_batch(192), 64, 24)
+    info = _lockstep_parity(g.ASTROBEE_SE3, 50, boxes, sph, *batch, max_iter=30, max_flag_mismatch=GATE_FLAGS_SE3)
+    print("lockstep se3", info, "problems with omega raised:", n_raised)
+    assert info["trips"] >= 300 and n_raised >= 4 and info["max_omega"] > 1.0
 
 
 def test_lockstep_parity_astrobee_manifold():
+    """BASELINE config 5 model (astrobee_se3_manifold.jl:533-642), 64 problems to max_iter = 30."""
     g, _ = _mods()
     P = g.problems
     boxes, sph = P.iss_corner_env(True)
-    x0, glo, ghi, tf = P.astrobee_manifold_batch(8)
-    print("lockstep manifold", _lockstep_parity(g.ASTROBEE_SE3_MANIFOLD, 50, boxes, sph, x0, glo, ghi, tf, max_iter=10, sub_atol=5e-5,
-                                                max_flag_mismatch=0.02, q_tight=0.5))
+    batch, n_raised = _with_raised_penalty(g.ASTROBEE_SE3_MANIFOLD, 50, boxes, sph, P.astrobee_manifold_batch(128), 64, 24)
+    info = _lockstep_parity(g.ASTROBEE_SE3_MANIFOLD, 50, boxes, sph, *batch, max_iter=30, sub_atol=5e-5,
+                            max_flag_mismatch=GATE_FLAGS_MANIFOLD, q_tight=0.5)
+    print("lockstep manifold", info, "problems with omega raised:", n_raised)
+    assert info["trips"] >= 300
 
 
 def test_scp_parity_freeflyer():
@@ -309,14 +332,14 @@ def test_scp_parity_freeflyer():
     P = g.problems
     x0, glo, ghi, tf = P.freeflyer_batch(64)
     x0[0] = P.FREEFLYER_X_INIT
-    _scp_parity(g.FREEFLYER_SE2, 50, P.freeflyer_env(), None, x0, glo, ghi, tf, max_diverged=1)
+    print("scp freeflyer diverged", _scp_parity(g.FREEFLYER_SE2, 50, P.freeflyer_env(), None, x0, glo, ghi, tf, max_diverged=1))
 
 
 def test_scp_parity_dubins():
     g, _ = _mods()
     x0, glo, ghi, tf = g.problems.dubins_batch(64)
     x0[0] = [2.0, 2.0, 2.0]
-    _scp_parity(g.DUBINS_CAR, 30, None, None, x0, glo, ghi, tf, max_diverged=1)
+    print("scp dubins diverged", _scp_parity(g.DUBINS_CAR, 30, None, None, x0, glo, ghi, tf, max_diverged=1))
 
 
 def test_scp_parity_astrobee_se3():

@@ -10,9 +10,13 @@ cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 300 python bench.py --overlap 2 --steps 60 --no-cpu-baseline > $OUT/bench_overlap2.json 2>> $OUT/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python bench.py --steps 20 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
-timeout 600 python tools/bench_configs.py > $OUT/configs.jsonl 2>> $OUT/bench.err
-for m in 2 3; do   # kernel stats of BASELINE configs 4 and 5 (astrobeeSE3 B=8192, manifold B=2048)
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_m$m -o stats -- python tools/bench_configs.py $m > $OUT/stats_m$m.log 2>&1
+: > $OUT/configs.jsonl
+for c in 2 3 4 5; do   # every BASELINE config through the contract harness itself
+  timeout 900 python bench.py --config $c --steps 8 --warmup 2 --no-extras >> $OUT/configs.jsonl 2>> $OUT/bench.err
+done
+for c in 4 5; do   # kernel stats of BASELINE configs 4 and 5 (astrobeeSE3 B=8192, manifold B=2048)
+  m=$((c - 2))
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_m$m -o stats -- python bench.py --config $c --steps 4 --warmup 1 --no-extras --no-cpu-baseline > $OUT/stats_m$m.log 2>&1
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc -o $c -- python tools/pmc_probe.py > $OUT/pmc_$c.log 2>&1
@@ -29,6 +33,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/sq -o "$name" -- python tools/pmc_probe.py > "$OUT/sq_$name.log" 2>&1
 done
 for m in 2 3; do   # matrix-core counters of the 12/13-state kernels (v_mfma_f64_16x16x4_f64 in the factor sweep)
-  timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/mfma_m$m -o c -- python tools/bench_configs.py $m > $OUT/mfma_m$m.log 2>&1
+  timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/mfma_m$m -o c -- python bench.py --config $((m + 2)) --steps 1 --warmup 0 --no-extras --no-cpu-baseline > $OUT/mfma_m$m.log 2>&1
 done
 ls -R $OUT | head -80
