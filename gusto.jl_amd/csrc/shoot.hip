@@ -8,8 +8,12 @@
 // with NLsolve (trust region, finite-difference Jacobian, ftol = 1e-3, <= 100 iterations).  Neither exists here; the
 // scheme is stated instead (the test suite's CPU restatement follows the same one): classical RK4 with `substeps`
 // steps per knot interval, Newton with a forward-difference Jacobian (h_j = 1e-6 max(1, |p_j|)), halving line search
-// on |F|_inf; the Newton step by Cramer's rule (n = 3) or Gaussian elimination with partial pivoting (n = 13).  The two
-// models above are the ones that have a shooting ODE in the reference.
+// on |F|_inf; the Newton step by Cramer's rule (n = 3) or rank-revealing Gaussian elimination with COMPLETE pivoting
+// (n = 13: dF/dp0 is rank deficient by one, newton_step below).  The two models above are the ones that have a shooting
+// ODE in the reference.
+// Stores: a lane owns a problem, so writing its knots straight into X[b][k][i] would touch one cache line per lane per
+// store (stride N n between lanes).  The recovered trajectory is written knot-major, Xt[k][i][b] -- consecutive lanes,
+// consecutive addresses -- and a tiled transpose (shoot_transpose_kernel) produces the [b][k][i] layout of the C ABI.
 #include <hip/hip_runtime.h>
 
 #include "handle.hpp"
@@ -22,7 +26,7 @@ struct ShootParams {
     int B, N, substeps, max_newton;
     double ftol, v, k, mass, J[3];
     const double *x_init, *goal_lo, *goal_hi, *tf, *p0;   // p0 [B][n]
-    double *X, *U, *p_out, *resid;                        // X [B][N][n], U [B][N][m]
+    double *X, *U, *p_out, *resid;                        // knot-major staging of the trajectories: X [N][n][B], U [N][m][B]
     int *status, *iters;
 };
 
@@ -74,9 +78,10 @@ template <> struct ShootModel<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     }
 };
 
-// integrates from (x_init, p0); writes the knots when X != nullptr; returns x(tf) in xT
+// integrates from (x_init, p0); writes the knots of problem b (knot-major, coalesced over the lanes) when X != nullptr;
+// returns x(tf) in xT
 template <int MODEL>
-__device__ void integrate(const ShootParams& S, const double* x0, const double* p0, double tf, double* xT, double* X, double* U) {
+__device__ void integrate(const ShootParams& S, const double* x0, const double* p0, double tf, double* xT, double* X, double* U, int b = 0) {
     using M = ShootModel<MODEL>;
     constexpr int n = M::n, m = M::m, nz = 2 * n;
     double z[nz], k1[nz], k2[nz], k3[nz], k4[nz], w[nz];
@@ -86,11 +91,11 @@ __device__ void integrate(const ShootParams& S, const double* x0, const double* 
     for (int k = 0; k < S.N; k++) {
         if (X) {
 #pragma unroll
-            for (int i = 0; i < n; i++) X[k * n + i] = z[i];
+            for (int i = 0; i < n; i++) X[(size_t)(k * n + i) * S.B + b] = z[i];
             double u[m];
             M::ctrl(S, z, u);                               // get_control
 #pragma unroll
-            for (int i = 0; i < m; i++) U[k * m + i] = u[i];
+            for (int i = 0; i < m; i++) U[(size_t)(k * m + i) * S.B + b] = u[i];
         }
         if (k == S.N - 1) break;
         for (int s = 0; s < S.substeps; s++) {
@@ -213,7 +218,23 @@ template <int MODEL> __global__ void __launch_bounds__(64) shoot_kernel(const Sh
     }
     S.status[b] = ok; S.iters[b] = it; S.resid[b] = nf;
     for (int i = 0; i < n; i++) S.p_out[(size_t)b * n + i] = pv[i];
-    if (ok) integrate<MODEL>(S, x0, pv, tf, xT, S.X + (size_t)b * S.N * n, S.U + (size_t)b * S.N * m);
+    if (ok) integrate<MODEL>(S, x0, pv, tf, xT, S.X, S.U, b);
+}
+
+// out[b][r] = in[r][b] for the problems whose shooting converged (R = N n or N m rows, B columns): 32 x 32 tiles through
+// LDS, reads and writes both coalesced; the rows of the other problems are left as they are
+__global__ void __launch_bounds__(256) shoot_transpose_kernel(const double* in, double* out, const int* status, int R, int B) {
+    __shared__ double tile[32][33];
+    const int b0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, b = b0 + tx;
+        tile[j][tx] = (r < R && b < B) ? in[(size_t)r * B + b] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int b = b0 + j, r = r0 + tx;
+        if (b < B && r < R && status[b]) out[(size_t)b * R + r] = tile[tx][j];
+    }
 }
 
 }  // namespace
@@ -243,6 +264,7 @@ int gusto_shoot(gusto_handle h, const double* p0, const gusto_shoot_opts* opts) 
     const size_t B = h->batch_cap, N = h->N;
     if (!h->d_shX) {
         HIPCHK(h, dalloc(&h->d_shX, B * N * n)); HIPCHK(h, dalloc(&h->d_shU, B * N * m)); HIPCHK(h, dalloc(&h->d_shP, B * n));
+        HIPCHK(h, dalloc(&h->d_shXt, B * N * n)); HIPCHK(h, dalloc(&h->d_shUt, B * N * m));
         HIPCHK(h, dalloc(&h->d_shP0, B * n)); HIPCHK(h, dalloc(&h->d_shRes, B)); HIPCHK(h, dalloc(&h->d_shSt, B)); HIPCHK(h, dalloc(&h->d_shIt, B));
     }
     if (p0) {
@@ -256,10 +278,16 @@ int gusto_shoot(gusto_handle h, const double* p0, const gusto_shoot_opts* opts) 
     S.v = h->mp.dubins_v; S.k = h->mp.dubins_k; S.mass = h->mp.mass;
     for (int i = 0; i < 3; i++) S.J[i] = h->mp.Jdiag[i];
     S.x_init = h->d_xinit; S.goal_lo = h->d_glo; S.goal_hi = h->d_ghi; S.tf = h->d_tf; S.p0 = h->d_shP0;
-    S.X = h->d_shX; S.U = h->d_shU; S.p_out = h->d_shP; S.resid = h->d_shRes; S.status = h->d_shSt; S.iters = h->d_shIt;
+    S.X = h->d_shXt; S.U = h->d_shUt; S.p_out = h->d_shP; S.resid = h->d_shRes; S.status = h->d_shSt; S.iters = h->d_shIt;
     if (h->model == GUSTO_DUBINS_CAR) hipLaunchKernelGGL(shoot_kernel<GUSTO_DUBINS_CAR>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, S);
     else hipLaunchKernelGGL(shoot_kernel<GUSTO_ASTROBEE_SE3_MANIFOLD>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, S);
     HIPCHK(h, hipGetLastError());
+    {   // knot-major staging -> X[b][k][i], U[b][k][i]
+        const int RX = (int)(N * n), RU = (int)(N * m);
+        hipLaunchKernelGGL(shoot_transpose_kernel, dim3((h->B + 31) / 32, (RX + 31) / 32), dim3(256), 0, h->stream, h->d_shXt, h->d_shX, h->d_shSt, RX, h->B);
+        hipLaunchKernelGGL(shoot_transpose_kernel, dim3((h->B + 31) / 32, (RU + 31) / 32), dim3(256), 0, h->stream, h->d_shUt, h->d_shU, h->d_shSt, RU, h->B);
+        HIPCHK(h, hipGetLastError());
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_shoot = true;
     return GUSTO_OK;
