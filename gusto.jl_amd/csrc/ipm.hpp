@@ -68,6 +68,25 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     GPtr<const double> x_init, goal_lo, goal_hi;
     unsigned goalmask;  // bit i: coordinate i of x_N has a point goal (goal_lo == goal_hi)
 
+    // Knot-private vectors (only lane k ever touches those of knot k): rd qrd dXs | dUs qu dv | gAx gBx gAu gBu.  The one-wave
+    // kernels whose phases are inlined keep them in REGISTERS of lane k over the whole interior point iteration (the
+    // allocator parks them in AGPRs across the sweeps) instead of the per-slot global workspace: every phase started with
+    // a round trip to L2 for them (~45 loads and as many stores per lane and iteration).  The called phases of the 12/13-state
+    // models and the multi-wave kernels keep the workspace arrays.
+#ifdef GUSTO_NO_PVT_REG
+    static constexpr bool PVT_REG = false;
+#else
+    static constexpr bool PVT_REG = ONEWAVE && !T::SWEEP_CALL && T::NDEF == 0 && T::WAVES_PER_EU == 1;   // (dubins, 2 waves per SIMD, has no registers to spare: 181 -> 201 ms)
+#endif
+    struct PvtRegs { double rd[n], qrd[n], dXs[n], dUs[m], qu[m], dv[m], gAx[n], gBx[n], gAu[m], gBu[m]; };
+    std::conditional_t<PVT_REG, PvtRegs, char> pr;
+#define GUSTO_PVT(name, dim)                                                                      \
+    GD decltype(auto) name##_(int k, int i) {                                                     \
+        if constexpr (PVT_REG) return (pr.name[i]); else return (name[k * dim + i]);              \
+    }
+    GUSTO_PVT(rd, n) GUSTO_PVT(qrd, n) GUSTO_PVT(dXs, n) GUSTO_PVT(dUs, m) GUSTO_PVT(qu, m) GUSTO_PVT(dv, m)
+    GUSTO_PVT(gAx, n) GUSTO_PVT(gBx, n) GUSTO_PVT(gAu, m) GUSTO_PVT(gBu, m)
+#undef GUSTO_PVT
     GD int nt() const { return ONEWAVE ? 64 : NTr; }
 
     // every LDS pointer from the base of the dynamic LDS.  Also called at the top of the phases that run as real calls
@@ -1894,7 +1913,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         for (int i = 0; i < n; i++) tt[i] = K.pv[k * n + i];   // pt_k = p_k + r_k
 #pragma unroll
         for (int i = 0; i < m; i++) {
-            double s = K.qu[k * m + i];
+            double s = K.qu_(k, i);
 #pragma unroll
             for (int l = 0; l < n; l++) if (T::Gnz(l, i)) s += Gamk[l * m + i] * tt[l];
             lu[i] = s;
@@ -1914,7 +1933,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
             double rdl[n];
             const double* pg = K.PGk(0);
 #pragma unroll
-            for (int i = 0; i < n; i++) rdl[i] = K.rd[k * n + i];
+            for (int i = 0; i < n; i++) rdl[i] = K.rd_(k, i);
 #pragma unroll
             for (int j = 0; j < n; j++) {
                 double g = 0.0;
@@ -1944,7 +1963,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
             if (k == N - 1 && K.is_goal(j)) {
                 const double* pg = K.PGk(k);
 #pragma unroll
-                for (int i = 0; i < n; i++) s += 0.5 * (pg[j * NZ + i] + (i == j ? 1.0 : 0.0)) * K.rd[k * n + i];
+                for (int i = 0; i < n; i++) s += 0.5 * (pg[j * NZ + i] + (i == j ? 1.0 : 0.0)) * K.rd_(k, i);
                 s -= K.goal_lo[j] - K.Xw[k * n + j];
             }
             th[j] = s;
@@ -1973,7 +1992,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
 #pragma unroll
             for (int j = 0; j < n; j++) s += K.kd(k, R::oD + i * n + j) * mugn[j];
             dk[i] = s;
-            K.dv[k * m + i] = s;
+            K.dv_(k, i) = s;
         }
         double Gamk[n * m];
         if (k >= 1) {
@@ -2034,11 +2053,11 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         for (int i = 0; i < n; i++) { dyp[i] = (k >= 1) ? K.dY[(k - 1) * n + i] : 0.0; dxs[i] = 0; }
 #pragma unroll
         for (int i = 0; i < m; i++) {
-            double s = -K.dv[k * m + i];
+            double s = -K.dv_(k, i);
 #pragma unroll
             for (int l = 0; l < n; l++) s -= K.kd(k, R::oK + i * n + l) * dyp[l];
             dus[i] = s;
-            K.dUs[k * m + i] = s;
+            K.dUs_(k, i) = s;
         }
         if (k >= 1) {
             double a[n], Bd[n * m], Mk[n * n], Gamk[n * m];
@@ -2046,7 +2065,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
             load_M_Gam(K, k, Mk, Gamk);
 #pragma unroll
             for (int i = 0; i < n; i++) {
-                double s = dyp[i] + K.rd[k * n + i];
+                double s = dyp[i] + K.rd_(k, i);
 #pragma unroll
                 for (int l = 0; l < m; l++) if (T::Bnz(i, l)) s += (hdt * Bd[i * m + l]) * dus[l];
                 a[i] = s;
@@ -2060,7 +2079,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
             }
         }
 #pragma unroll
-        for (int i = 0; i < n; i++) K.dXs[k * n + i] = dxs[i];
+        for (int i = 0; i < n; i++) K.dXs_(k, i) = dxs[i];
         if (k + 1 < N && (pass == 1 || ncomp == 0)) {  // nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g
 #pragma unroll
             for (int i = 0; i < n; i++) {
@@ -2101,9 +2120,9 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         l_amax = op.amax.value(); l_c0 = op.c0; l_c1 = op.c1; l_c2 = op.c2;
         if (pass == 0) {
 #pragma unroll
-            for (int i = 0; i < n; i++) { K.gAx[k * n + i] = gAx[i]; K.gBx[k * n + i] = gBx[i]; }
+            for (int i = 0; i < n; i++) { K.gAx_(k, i) = gAx[i]; K.gBx_(k, i) = gBx[i]; }
 #pragma unroll
-            for (int i = 0; i < m; i++) { K.gAu[k * m + i] = gAu[i]; K.gBu[k * m + i] = gBu[i]; }
+            for (int i = 0; i < m; i++) { K.gAu_(k, i) = gAu[i]; K.gBu_(k, i) = gBu[i]; }
         }
     }
     K.sync();
@@ -2178,7 +2197,7 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
             }
         }
 #pragma unroll
-        for (int i = 0; i < n; i++) K.rd[k * n + i] = rdk[i];
+        for (int i = 0; i < n; i++) K.rd_(k, i) = rdk[i];
         double gx0[n], gu0[m];
 #pragma unroll
         for (int i = 0; i < n; i++) gx0[i] = 0;
@@ -2201,9 +2220,9 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
         visit_rows<MODEL>(ctx, xs, us, op);
         // row part of the predictor right-hand side, parked in the (currently free) step arrays
 #pragma unroll
-        for (int i = 0; i < n; i++) K.dXs[k * n + i] = gx0[i];
+        for (int i = 0; i < n; i++) K.dXs_(k, i) = gx0[i];
 #pragma unroll
-        for (int i = 0; i < m; i++) K.dUs[k * m + i] = gu0[i];
+        for (int i = 0; i < m; i++) K.dUs_(k, i) = gu0[i];
         l_comp = op.comp;
         l_resp = nanmax(l_resp, op.maxrp);
 #pragma unroll
@@ -2328,7 +2347,7 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
                 double s = 0, c = 0.0 - rdk[i];
 #pragma unroll
                 for (int l = 0; l < n; l++) { s += Qt[sidx(i, l, n)] * rdk[l]; if (T::Mnz(i, l)) c += 2.0 * Mk[i * n + l] * rdk[l]; }
-                K.qrd[k * n + i] = s;
+                K.qrd_(k, i) = s;
                 K.cv[k * n + i] = c;
             }
         }
@@ -2494,14 +2513,14 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 pf.tick(PF_F1);
                 if (pass == 0) {   // the predictor's row sums were accumulated by the residual pass
 #pragma unroll
-                    for (int i = 0; i < n; i++) gx[i] = K.dXs[k * n + i];
+                    for (int i = 0; i < n; i++) gx[i] = K.dXs_(k, i);
 #pragma unroll
-                    for (int i = 0; i < m; i++) gu[i] += K.dUs[k * m + i];
+                    for (int i = 0; i < m; i++) gu[i] += K.dUs_(k, i);
                 } else {   // the corrector's row sums were accumulated by the predictor's step pass: coef = A + mu_t B per row
 #pragma unroll
-                    for (int i = 0; i < n; i++) gx[i] = K.gAx[k * n + i] + mu_t * K.gBx[k * n + i];
+                    for (int i = 0; i < n; i++) gx[i] = K.gAx_(k, i) + mu_t * K.gBx_(k, i);
 #pragma unroll
-                    for (int i = 0; i < m; i++) gu[i] += K.gAu[k * m + i] + mu_t * K.gBu[k * m + i];
+                    for (int i = 0; i < m; i++) gu[i] += K.gAu_(k, i) + mu_t * K.gBu_(k, i);
                 }
                 pf.tick(PF_F2);
                 if (k >= 1) {
@@ -2509,7 +2528,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                     load_M_Gam(K, k, Mk, Gamk);
 #pragma unroll
                     for (int i = 0; i < n; i++) {
-                        double s = K.qrd[k * n + i];
+                        double s = K.qrd_(k, i);
 #pragma unroll
                         for (int l = 0; l < n; l++) if (T::Mnz(l, i)) s += Mk[l * n + i] * gx[l];
                         gy[i] = s;
@@ -2525,7 +2544,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
 #pragma unroll
                     for (int l = 0; l < n; l++) if (T::Bnz(l, i)) s += (hdt * Bd[l * m + i]) * gy[l];
                     quk[i] = s;
-                    K.qu[k * m + i] = s;
+                    K.qu_(k, i) = s;
                 }
                 {   // qt_k = gy - K^T qu (the record of K walked in storage order, see mid_phase)
                     double qt[n];
@@ -2579,12 +2598,12 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             load_iter(xs, us);
 #pragma unroll
             for (int i = 0; i < n; i++) {
-                xs[i] += alpha * K.dXs[k * n + i];
+                xs[i] += alpha * K.dXs_(k, i);
                 K.Xw[k * n + i] = xs[i];
                 K.nu[k * n + i] += alpha * (K.nun[k * n + i] - K.nu[k * n + i]);
             }
 #pragma unroll
-            for (int i = 0; i < m; i++) { us[i] += alpha * K.dUs[k * m + i]; K.Uw[k * m + i] = us[i]; }
+            for (int i = 0; i < m; i++) { us[i] += alpha * K.dUs_(k, i); K.Uw[k * m + i] = us[i]; }
         }
         alpha_prev = alpha;   // the row state is advanced by the next residual pass
         if (k == 0) {
