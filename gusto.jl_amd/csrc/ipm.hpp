@@ -1606,11 +1606,14 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 //
 // backward: pt_{k-1} = Phicl_k^T pt_k + qq_k, k = N-1..1, pt := p + r (so qq_k = qt_k + r_{k-1}), pt_{N-1} = r_{N-1}.
 //           pv[k] holds qq_k on entry and pt_k on exit.
+#ifndef GUSTO_XL_MIN
+#define GUSTO_XL_MIN 8
+#endif
 template <class BLK> GD void backward_sweep_1w(BLK K) {
     constexpr int n = BLK::n, C = 64 / n, PS = n > 8 ? 4 : 1;
     // 12/13-state models: the n-vector goes from group to group through 64 doubles of LDS (one ds_write per lane, broadcast
     // ds_reads at compile-time addresses) instead of 2 n v_readlane per knot
-    constexpr bool XL = n > 8;
+    constexpr bool XL = n > GUSTO_XL_MIN;
     double* ex = K.sHh;
     using R = typename BLK::R;
     const int tid = K.tid, N = K.N;
@@ -1704,7 +1707,7 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
 // forward: dy_k = Phicl_k dy_{k-1} + ct_k, k = 0..N-1; dY[k] holds ct_k on entry and dy_k on exit
 template <class BLK> GD void forward_sweep_1w(BLK K) {
     constexpr int n = BLK::n, C = 64 / n, PS = n > 8 ? 4 : 1;
-    constexpr bool XL = n > 8;   // (see backward_sweep_1w)
+    constexpr bool XL = n > GUSTO_XL_MIN;   // (see backward_sweep_1w)
     double* ex = K.sHh;
     using R = typename BLK::R;
     const int tid = K.tid, N = K.N;
