@@ -117,7 +117,7 @@ def _oracle_runs(model, N, env, spheres, x0, glo, ghi, tf, max_iter, cold=True):
 
 
 def _lockstep_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30, sub_atol=SUB_ATOL, max_flag_mismatch=0.005,
-                     u_atol=SUB_ATOL, q_tight=0.9, min_same_iters=0.9):
+                     u_atol=SUB_ATOL, q_tight=0.9, min_same_iters=0.9, max_cold_fail=1):
     """EVERY trip of EVERY problem (no omega cut-off): the oracle's (traj_prev, Delta, omega) of the trip is fed to
     the device, first through gusto_subproblem (the convex solve alone), then as ONE GuSTO trip of the real state
     machine (gusto_set_trust_state + gusto_solve(1)), whose post-solve quantities -- convergence_measure, rho, the
@@ -135,7 +135,7 @@ def _lockstep_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30, sub_
     # edge of feasibility, dubins): such trips are compared by status only -- below -- and are rare
     trips = [(b, t) for b, t in all_trips if runs[b][1][t]["st_c"] in (1, 2)]
     cold_fail = [(b, t) for b, t in all_trips if runs[b][1][t]["st_c"] not in (1, 2)]
-    assert len(cold_fail) <= max(1, len(all_trips) // 100), (len(cold_fail), len(all_trips))
+    assert len(cold_fail) <= max_cold_fail, (len(cold_fail), len(all_trips))   # (measured: 0, dubins 2 of 1068)
     T = len(trips)
     assert T >= len(x0)
     bi = np.array([b for b, _ in trips])
@@ -290,7 +290,7 @@ def test_lockstep_parity_dubins():
     g, _ = _mods()
     x0, glo, ghi, tf = g.problems.dubins_batch(64)
     x0[0] = [2.0, 2.0, 2.0]
-    print("lockstep dubins", _lockstep_parity(g.DUBINS_CAR, 30, None, None, x0, glo, ghi, tf))
+    print("lockstep dubins", _lockstep_parity(g.DUBINS_CAR, 30, None, None, x0, glo, ghi, tf, max_cold_fail=3))
 
 
 def _with_raised_penalty(model, N, env, spheres, batch, want, n_raised):

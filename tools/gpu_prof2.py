@@ -8,11 +8,13 @@ B = int(sys.argv[1]); model = int(sys.argv[2])
 spheres = None
 if model == 0:
     x0, glo, ghi, tf = P.freeflyer_batch(B); boxes = P.freeflyer_env()
+elif model == 1:
+    x0, glo, ghi, tf = P.dubins_batch(B); boxes = None
 elif model == 2:
     x0, glo, ghi, tf = P.astrobee_se3_batch(B); boxes, spheres = P.iss_corner_env(True)
 else:
     x0, glo, ghi, tf = P.astrobee_manifold_batch(B); boxes, spheres = P.iss_corner_env(True)
-s = g.BatchSolver(model, 50, B, hist_cap=64, boxes=boxes, spheres=spheres)
+s = g.BatchSolver(model, 30 if model == 1 else 50, B, hist_cap=64, boxes=boxes, spheres=spheres)
 for rep in range(2):
     s.set_problems(x0, glo, ghi, tf); s.solve(30)
 st = s.status()
