@@ -215,7 +215,7 @@ template <int MODEL, bool ONE> struct LdsC {
     static constexpr int NPGB = (ONE && !T::LTI) ? 2 : 3;
     static constexpr int sP = 0, sPi = sP + n * n, sPG = sPi + n * n, sT0 = sPG + NPGB * n * NZ,
                          sHh = sT0 + ((ONE && BIG) ? 0 : n * NZ), sZ = sHh + NZ * NZ, sT = (ONE && BIG) ? sZ : sT0,
-                         sGd = sZ + NZ * n, misc = sGd + ((ONE && BIG) ? 1 : 2) * n * n, lut = misc + 64,
+                         sGd = sZ + NZ * n, misc = sGd + ((ONE && BIG) ? 1 : 2) * n * n, sgoal = misc + 64 /* goal_lo of the problem */, lut = misc + 80,
                          vecs1w = (lut + (NZ * (NZ + 1) / 2 + 1) / 2 + 1 + 1) & ~1,   // (even: 16-byte aligned rows of the n-vectors, ds_read_b128)
                          sK = vecs1w, sD = sK + m * n, sW = sD + m * n, sV = sW + m * n, vecsmw = sV + m * n,
                          vecs = ONE ? vecs1w : vecsmw;

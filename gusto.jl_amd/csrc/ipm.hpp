@@ -67,6 +67,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     GPtr<uint64_t> obs_mask;
     GPtr<const double> x_init, goal_lo, goal_hi;
     unsigned goalmask;  // bit i: coordinate i of x_N has a point goal (goal_lo == goal_hi)
+    unsigned boxmask;   // bit i: coordinate i of x_N has BoxGoal rows (goal_lo != goal_hi, at least one of them finite)
 
     // Knot-private vectors (only lane k ever touches those of knot k): rd qrd dXs | dUs qu dv | gAx gBx gAu gBu.  The one-wave
     // kernels whose phases are inlined keep them in REGISTERS of lane k over the whole interior point iteration (the
@@ -141,10 +142,16 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         }
         x_init = P.x_init + (size_t)b * n; goal_lo = P.goal_lo + (size_t)b * n; goal_hi = P.goal_hi + (size_t)b * n;
         dt = P.tf[b] / (N - 1);  // Trajectory(X,U,Tf): dt = Tf/(N-1), types.jl:235
-        goalmask = 0;
+        goalmask = 0; boxmask = 0;
 #pragma unroll
-        for (int i = 0; i < n; i++)
-            if (goal_lo[i] == goal_hi[i]) goalmask |= 1u << i;
+        for (int i = 0; i < n; i++) {
+            const double lo = goal_lo[i], hi = goal_hi[i];
+            if (lo == hi) goalmask |= 1u << i;
+            else if (isfinite(lo) || isfinite(hi)) boxmask |= 1u << i;
+        }
+        // the point-goal values next to the reduction scratch: the phases read them in every pass, and as loads from the
+        // problem's arrays in HBM/L2 each was a memory round trip of its own on the critical path of a one-wave problem
+        if (tid < n) (lds + C::sgoal)[tid] = goal_lo[tid];
         for (int e = tid; e < NZ * (NZ + 1) / 2; e += nt()) {
             int i = 0, rem = e;
             while (rem >= NZ - i) { rem -= NZ - i; i++; }
@@ -1933,16 +1940,25 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         // as a branch it is single-lane work (loads and all) that the whole wave waits for, twice per iteration
         double gterm[n], gsub[n];
         if constexpr (T::LTI) {
-            double rdl[n];
-            const double* pg = K.PGk(0);
+            double rdl[n], Mg[n * n];
+            if constexpr (T::PG2) {   // (closed form, exactly the stored block: 0.5 ((2 M - I) + I) = M entry by entry)
+                double Gg[n * m];
+                load_M_Gam(K, k, Mg, Gg);
+            } else {
+                const double* pg = K.PGk(0);
+#pragma unroll
+                for (int j = 0; j < n; j++)
+#pragma unroll
+                    for (int i = 0; i < n; i++) Mg[j * n + i] = T::Mnz(j, i) ? 0.5 * (pg[j * NZ + i] + (i == j ? 1.0 : 0.0)) : 0.0;
+            }
 #pragma unroll
             for (int i = 0; i < n; i++) rdl[i] = K.rd_(k, i);
 #pragma unroll
             for (int j = 0; j < n; j++) {
                 double g = 0.0;
 #pragma unroll
-                for (int i = 0; i < n; i++) if (T::Mnz(j, i)) g += 0.5 * (pg[j * NZ + i] + (i == j ? 1.0 : 0.0)) * rdl[i];
-                gterm[j] = g; gsub[j] = K.goal_lo[j] - K.Xw[k * n + j];
+                for (int i = 0; i < n; i++) if (T::Mnz(j, i)) g += Mg[j * n + i] * rdl[i];
+                gterm[j] = g; gsub[j] = K.misc[64 + j] - K.Xw[k * n + j];
             }
         }
         // (the record of D is walked in storage order, row by row.  Lane k reads ITS knot's record, so one load touches 50
@@ -1967,7 +1983,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
                 const double* pg = K.PGk(k);
 #pragma unroll
                 for (int i = 0; i < n; i++) s += 0.5 * (pg[j * NZ + i] + (i == j ? 1.0 : 0.0)) * K.rd_(k, i);
-                s -= K.goal_lo[j] - K.Xw[k * n + j];
+                s -= K.misc[64 + j] - K.Xw[k * n + j];
             }
             th[j] = s;
         }
@@ -2119,7 +2135,9 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
             });
         }
         OpStep<NP> op{rs, dxs, dus, pass, mu_t, tau, gAx, gAu, gBx, gBu, &pre};
+        ctx.tick(0);
         visit_rows<MODEL>(ctx, xs, us, op);
+        ctx.tick(3);
         l_amax = op.amax.value(); l_c0 = op.c0; l_c1 = op.c1; l_c2 = op.c2;
         if (pass == 0) {
 #pragma unroll
@@ -2220,7 +2238,9 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
         }
         constexpr bool LRTR = MODEL == GUSTO_ASTROBEE_SE3;   // (the manifold model has no trust region row)
         OpResidHess<n, m, NP, LRTR> op{rs, Hx, Hu, rdx, rdu, gx0, gu0, alpha_prev, &pre};
+        ctx.tick(0);   // (profile builds: PF_R0.. = prologue | fixed rows | obstacle rows | control rows | stage cost)
         visit_rows<MODEL>(ctx, xs, us, op);
+        ctx.tick(3);
         // row part of the predictor right-hand side, parked in the (currently free) step arrays
 #pragma unroll
         for (int i = 0; i < n; i++) K.dXs_(k, i) = gx0[i];
@@ -2266,7 +2286,7 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
             for (int i = 0; i < n; i++) {
                 if (K.is_goal(i)) {
                     rdx[i] += mug[i];
-                    l_resp = nanmax(l_resp, fabs(K.goal_lo[i] - xs[i]));
+                    l_resp = nanmax(l_resp, fabs(K.misc[64 + i] - xs[i]));
                 }
             }
         }
@@ -2390,7 +2410,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     RowCtx<MODEL> ctx;
     ctx.P = &K.P; ctx.N = N; ctx.k = k; ctx.nslot = K.P.wl.nslot; ctx.kappa = kappa; ctx.omega = omega; ctx.Delta = Delta;
     ctx.xp = K.Xp + (act ? k : 0) * n; ctx.mask = act ? K.obs_mask[k] : 0; ctx.obs_nh = K.obs_nh; ctx.obs_c0 = K.obs_c0;
-    ctx.goal_lo = K.goal_lo; ctx.goal_hi = K.goal_hi;
+    ctx.goal_lo = K.goal_lo; ctx.goal_hi = K.goal_hi; ctx.boxmask = K.boxmask;
     RowState rs{K.rowstate, K.P.wl.nslot, N, act ? k : 0};
     // The knot index is made opaque at every phase boundary: otherwise the compiler hoists each phase's address
     // arithmetic out of the interior point loop and its registers (hundreds) stay live across the sweeps.
@@ -2456,6 +2476,9 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         K.sync();
         // (2) residuals, condensed Hessian blocks, dual residual; (3) the LQR stage cost of this knot
         ResidOut ro;
+#ifdef GUSTO_PROFILE
+        if constexpr (T::PG2) { ctx.pf = &pf; ctx.pfb = PF_F4; }   // (slots the pipelined factor sweep leaves free)
+#endif
         if constexpr (T::SWEEP_CALL) ro = resid_phase_call<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
         else ro = resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
         const double l_resp = ro.resp, l_resd = ro.resd, l_comp = ro.comp, l_numax = ro.numax;
@@ -2576,6 +2599,9 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             // primal step of this knot, the new costates, row steps + fraction to the boundary
             const double tau = pass ? fmax(0.995, 1.0 - mu) : 1.0;
             StepOut so;
+#ifdef GUSTO_PROFILE
+            if constexpr (T::PG2) { ctx.pf = &pf; ctx.pfb = PF_FPRE; }
+#endif
             if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
             else so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
             const double l_amax = so.amax, l_c0 = so.c0, l_c1 = so.c1, l_c2 = so.c2;

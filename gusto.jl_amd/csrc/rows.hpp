@@ -34,6 +34,14 @@ template <int MODEL> struct RowCtx {
     GPtr<const double> obs_c0;  // [n_obs][N]
     GPtr<const double> goal_lo;
     GPtr<const double> goal_hi;
+    unsigned boxmask;           // coordinates of x_N with BoxGoal rows (Blk::boxmask)
+#ifdef GUSTO_PROFILE
+    Prof* pf = nullptr;   // sub-phase stamps of the row passes (PF_R*)
+    int pfb = 0;
+    GD void tick(int id) const { if (pf) pf->tick((id == 3 && pfb == PF_FPRE) ? 29 : pfb + id); }
+#else
+    GD void tick(int) const {}
+#endif
 };
 
 template <int I, int E, class F> GD void static_for(F&& f) {
@@ -148,6 +156,7 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
         // row's loads wait behind the stores of the row before it and a pass pays one memory round trip per active
         // obstacle (3-8 per knot for the freeflyer table, 15-25 in the ISS corner) -- four passes per interior point
         // iteration.  Lanes with fewer rows left aim the spare positions at their last row and skip them.
+        c.tick(1);   // fixed state rows
         uint64_t mk = c.mask;
         while (mk) {
             int oi[OBS_BATCH], oslot[OBS_BATCH];
@@ -172,6 +181,7 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
                 if (ov[q]) lin_row<false, 0, T::WS, FX_OBS + q>(op, oslot[q], ROW_PEN, xs, ob[q], oc[q], kw, 0.0);
             });
         }
+        c.tick(2);   // obstacle rows
         if (c.k < c.N - 1) {  // cci_*_accel_bound on k = 1..N-1 only (freeflyer_se2.jl:236-245,380-381)
             constexpr int nf = is2 ? 2 : 3, im = is2 ? 2 : 3, nm = is2 ? 1 : 3;
             double af[nf], am[nm];
@@ -197,7 +207,10 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
             lin_row<true, 0, 1, T::NFIX + 1>(op, slot_u + 1, ROW_HARD, us, &m1, mp.u_min, 1.0 / fabs(mp.u_min), 0.0);
         }
     }
-    if (c.k == c.N - 1) {  // csbci_goal_constraints: BoxGoal rows are hard (dynamics.jl:37-42, scp_gusto.jl:236-245)
+    // csbci_goal_constraints: BoxGoal rows are hard (dynamics.jl:37-42, scp_gusto.jl:236-245).  The wave-uniform mask comes
+    // first: without it the last knot's lane walked 2n dependent loads of the goal bounds in every row pass -- to find, for a
+    // point goal, that there is no such row -- while the other 49 lanes waited (12 k of 200 k cycles per KKT solve)
+    if (c.boxmask != 0 && c.k == c.N - 1) {
         static_for<0, n>([&](auto I) {
             constexpr int i = decltype(I)::value;
             const double lo = c.goal_lo[i], hi = c.goal_hi[i];

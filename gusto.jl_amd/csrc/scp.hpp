@@ -157,7 +157,7 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
             RowCtx<MODEL> ctx;
             ctx.P = &P; ctx.N = N; ctx.k = k; ctx.nslot = P.wl.nslot; ctx.kappa = 1.0; ctx.omega = 1.0; ctx.Delta = 1.0;
             ctx.xp = K.Xp + k * n; ctx.mask = K.obs_mask[k]; ctx.obs_nh = K.obs_nh; ctx.obs_c0 = K.obs_c0;
-            ctx.goal_lo = K.goal_lo; ctx.goal_hi = K.goal_hi;
+            ctx.goal_lo = K.goal_lo; ctx.goal_hi = K.goal_hi; ctx.boxmask = K.boxmask;
             OpCheck op{sp.eps};
             visit_rows<MODEL>(ctx, xs, us, op);
             cvx_l = op.ok;
@@ -559,7 +559,7 @@ template <int MODEL> GD void trajopt_problem(const KParams& P, double* lds, int 
                 total_ipm += io.iters;
                 const int h = n_hist;
                 if (tid == 0) { P.solver_status[hb + h] = io.status; P.ipm_it[hb + h] = io.iters; }
-                if (io.status != GUSTO_SOLVER_OPTIMAL && io.status != GUSTO_SOLVER_ALMOST) {   // (:113-116 warns and goes on)
+                if (io.status != GUSTO_SOLVER_OPTIMAL && io.status != GUSTO_SOLVER_ALMOST) {   // (:107-110 warns and goes on)
                     stop = GUSTO_STOP_SUBPROBLEM_FAILED; halt = true; break;
                 }
                 const double xt = convergence_metric_blk(K, K.Xw, Xcvx);           // evaluate_xtol :120-121

@@ -1938,7 +1938,7 @@ int go_solve_trajopt(go_problem* p, int max_iter) {
                     memcpy(p->trXp + t * n * N, p->X, nx); memcpy(p->trUp + t * m * N, p->U, nu);
                     memcpy(p->trXn + t * n * N, p->Xw, nx); memcpy(p->trUn + t * m * N, p->Uw, nu);
                 }
-                if (st != GO_SOLVER_OPTIMAL && st != GO_SOLVER_ALMOST) {                /* (:113-116 warns and goes on with the values) */
+                if (st != GO_SOLVER_OPTIMAL && st != GO_SOLVER_ALMOST) {                /* (:107-110 warns and goes on with the values) */
                     p->stop_reason = GO_STOP_SUBPROBLEM_FAILED; stop = 1; break;
                 }
                 memcpy(Xn, p->Xw, nx); memcpy(Un, p->Uw, nu);
