@@ -309,10 +309,12 @@ constexpr int SQ_HEAD_A = 0, SQ_PROBING = SQ_STRIDE /* problems that may still b
 constexpr int SD_TOGGLE = 0, SD_DUAL = 2, SD_ND = 2 + GUSTO_MAXN;
 
 // ---- optional phase timers (compile with -DGUSTO_PROFILE) ---------------------------------------------
-constexpr int PROF_N = 32;
+constexpr int PROF_N = 48;
 enum { PF_RESID = 0, PF_BUILD, PF_FACTOR, PF_POSTF, PF_RHS, PF_BACK, PF_MID, PF_FWD, PF_STEP, PF_UPDATE, PF_LIN, PF_SCP, PF_INIT,
        PF_FPRE, PF_FAB, PF_FCD, PF_F1, PF_F2, PF_F3, PF_F4, PF_F5, PF_F6, PF_F7, PF_F8,
-       PF_M_TH /* mid phase: theta */, PF_M_RED, PF_M_MU, PF_M_DK, PF_M_SYNC };
+       PF_M_TH /* mid phase: theta */, PF_M_RED, PF_M_MU, PF_M_DK, PF_M_SYNC,
+       PF_R0 = 32 /* residual pass: prologue | fixed rows | obstacle rows | control rows (the rest of the pass: PF_RESID) */,
+       PF_S0 = 36 /* step pass, likewise (the rest: PF_STEP, PF_F1) */ };
 struct Prof {
 #ifdef GUSTO_PROFILE
     long long t0, acc[PROF_N];

@@ -277,7 +277,7 @@ template <class BLK> GD void load_M_Gam(const BLK& K, int k, double* M, double* 
             for (int j = 0; j < m; j++) {
                 double s = 0;
 #pragma unroll
-                for (int l = 0; l < n; l++) s += Mx[i * n + l] * (h * Bx[l * m + j]);
+                for (int l = 0; l < n; l++) if (T::Bnz(l, j)) s += Mx[i * n + l] * (h * Bx[l * m + j]);   // (as linearize())
                 Gam[i * m + j] = T::Gnz(i, j) ? 2.0 * s : 0.0;
             }
         }
@@ -317,7 +317,7 @@ template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
                 for (int j = 0; j < m; j++) {
                     double s = 0;
 #pragma unroll
-                    for (int l = 0; l < n; l++) s += M[i * n + l] * (h * B[l * m + j]);
+                    for (int l = 0; l < n; l++) if (T::Bnz(l, j)) s += M[i * n + l] * (h * B[l * m + j]);   // (B's structural zeros add nothing: n m (n - 1) fewer FMAs for the 12/13-state models, where a column of B has one entry)
                     pg[i * NZ + n + j] = knot0 ? h * B[i * m + j] : 2.0 * s;
                 }
                 if constexpr (T::NDEF > 0) {   // a defect moves y_k directly: Gam_d = I (common.hpp)
@@ -1404,6 +1404,11 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
     (void)pf;
 }
 
+#ifdef GUSTO_NO_COSTATE_PASS
+#define GUSTO_COSTATE_PASS 0
+#else
+#define GUSTO_COSTATE_PASS 1
+#endif
 // The factor sweep of the 12/13-state models entirely on the matrix cores (MT::MFMA).  Every matrix of a stage is a
 // 16 x 16 tile in the accumulator layout of v_mfma_f64_16x16x4_f64 -- entry (row, col) in register row >> 2 of lane
 // (row & 3) << 4 | col -- and that layout IS an operand layout: register s of a tile X, used as the A operand of K step
@@ -1426,7 +1431,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
     const int mi = tid & 15, mq = tid >> 4;
     const bool c15 = mi == 15;
     // per-lane offsets, fixed for the sweep
-    int oF[KS], oG[KS], oGA[MS], oN[KS], oKr[MS], oDr[MS], oSr[MS], qyy[KS], quy[MS], quu[MS];
+    int oF[KS], oG[KS], oGA[MS], oN[KS], oNT[KS], oKr[MS], oDr[MS], oSr[MS], qyy[KS], quy[MS], quu[MS];
     bool vF[KS], vG[KS], vGA[MS];
 #pragma unroll
     for (int q = 0; q < KS; q++) {
@@ -1435,6 +1440,9 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
         oF[q] = (row < n && mi < n) ? row * NZ + mi : 0;
         oG[q] = vG[q] ? row * NZ + n + mi : 0;
         oN[q] = (row < n && mi < n) ? row * n + mi : R::SNN - 1;
+        // (P and Pi records: read by costate_pass_1w only, whose lane i takes row i -- stored TRANSPOSED, so that the n lanes of
+        // a group read n consecutive doubles per load)
+        oNT[q] = (row < n && mi < n) ? (GUSTO_COSTATE_PASS ? mi * n + row : row * n + mi) : R::SNN - 1;
         qyy[q] = (row < n && mi < n) ? sidx(row, mi, NZ) : -1;
     }
 #pragma unroll
@@ -1588,7 +1596,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
             double* pir = K.Piaft + (size_t)(k - 1) * R::SNN;
             double* kdr = K.KD + (size_t)k * R::SKD;
 #pragma unroll
-            for (int q = 0; q < KS; q++) { phr[oN[q]] = Ph[q]; par[oN[q]] = hyy[q]; pir[oN[q]] = zy[q]; }
+            for (int q = 0; q < KS; q++) { phr[oN[q]] = Ph[q]; par[oNT[q]] = hyy[q]; pir[oNT[q]] = zy[q]; }
 #pragma unroll
             for (int s = 0; s < MS; s++) { kdr[oKr[s]] = Kt[s]; kdr[oDr[s]] = Dt[s]; kdr[oSr[s]] = Si[s]; }
         }
@@ -1615,6 +1623,12 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 //           pv[k] holds qq_k on entry and pt_k on exit.
 #ifndef GUSTO_XL_MIN
 #define GUSTO_XL_MIN 8
+#endif
+#ifndef GUSTO_ROWPRE_BIG
+#define GUSTO_ROWPRE_BIG 0   // 1: the 12/13-state models fetch the state of their fixed rows in one batch too (RowPre); measured: no gain
+#endif
+#ifndef GUSTO_SWEEP_RING
+#define GUSTO_SWEEP_RING 4
 #endif
 template <class BLK> GD void backward_sweep_1w(BLK K) {
     constexpr int n = BLK::n, C = 64 / n, PS = n > 8 ? 4 : 1;
@@ -1670,6 +1684,49 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
         }
         q = K.pv[kk * n + i];
     };
+    // 12/13-state models: the operands come from the workspace in HBM (~3 k cycles away; 540 MB of slot workspaces do not
+    // fit the caches), and one chunk of work (~1.2 k cycles) in front of a fetch does not cover that: a ring of RING chunk
+    // buffers keeps RING - 1 fetches in flight.  (No buffer is ever copied: a copy waits for the newest fetch.)
+    constexpr int RING = (XL && !BLK::C::KD_LDS) ? GUSTO_SWEEP_RING : 1;
+    if constexpr (RING > 1) {
+        double cb[RING][n], qb[RING];
+#pragma unroll
+        for (int d = 0; d < RING - 1; d++) fetch(N - 1 - d * C, cb[d], qb[d]);
+        pval = K.rv[(N - 1) * n + i];
+        ex[tid] = pval;
+        K.sync();
+        if (tid < n) K.pv[(N - 1) * n + tid] = pval;
+        for (int kb = N - 1; kb >= 1; kb -= RING * C) {
+            static_for<0, RING>([&](auto DD) {
+                constexpr int d = decltype(DD)::value;
+                const int k0 = kb - d * C;
+                fetch(k0 - (RING - 1) * C, cb[(d + RING - 1) % RING], qb[(d + RING - 1) % RING]);   // (clamped: always loadable)
+                if (k0 >= 1) {
+#pragma unroll
+                    for (int gs = 0; gs < C; gs++) {
+                        if (k0 - gs >= 1) {
+                            const int sg = (gs == 0) ? C - 1 : gs - 1;
+                            double acc[PS];
+#pragma unroll
+                            for (int q = 0; q < PS; q++) acc[q] = (q == 0) ? qb[d] : 0.0;
+                            double pb[n];
+#pragma unroll
+                            for (int l = 0; l < n; l++) pb[l] = ex[sg * n + l];
+#pragma unroll
+                            for (int l = 0; l < n; l++) acc[l % PS] += cb[d][l] * pb[l];
+                            const double s = (PS == 4) ? (acc[0] + acc[1]) + (acc[2] + acc[PS - 1]) : acc[0];
+                            pval = (g == gs) ? s : pval;
+                            ex[tid] = pval;
+                        }
+                    }
+                    const int kk = k0 - g;
+                    if (tid < C * n && kk >= 1) K.pv[(kk - 1) * n + i] = pval;
+                }
+            });
+        }
+        K.sync();
+        return;
+    }
     fetch(N - 1, col, qv);
     pval = K.rv[(N - 1) * n + i];       // every group starts from pt_{N-1}; only group C-1 is read at step 0
     if constexpr (XL) ex[tid] = pval;
@@ -1757,6 +1814,44 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
         }
         c = K.dY[kk * n + i];
     };
+    constexpr int RING = (XL && !BLK::C::KD_LDS) ? GUSTO_SWEEP_RING : 1;   // (see backward_sweep_1w)
+    if constexpr (RING > 1) {
+        double rb[RING][n], qb[RING];
+#pragma unroll
+        for (int d = 0; d < RING - 1; d++) fetch(d * C, rb[d], qb[d]);
+        ex[tid] = yval;
+        K.sync();
+        for (int kb = 0; kb < N; kb += RING * C) {
+            static_for<0, RING>([&](auto DD) {
+                constexpr int d = decltype(DD)::value;
+                const int k0 = kb + d * C;
+                fetch(k0 + (RING - 1) * C, rb[(d + RING - 1) % RING], qb[(d + RING - 1) % RING]);   // (clamped: always loadable)
+                if (k0 < N) {
+#pragma unroll
+                    for (int gs = 0; gs < C; gs++) {
+                        if (k0 + gs < N) {
+                            const int sg = (gs == 0) ? C - 1 : gs - 1;
+                            double acc[PS];
+#pragma unroll
+                            for (int q = 0; q < PS; q++) acc[q] = (q == 0) ? qb[d] : 0.0;
+                            double pb[n];
+#pragma unroll
+                            for (int l = 0; l < n; l++) pb[l] = ex[sg * n + l];
+#pragma unroll
+                            for (int l = 0; l < n; l++) acc[l % PS] += rb[d][l] * pb[l];
+                            const double s = (PS == 4) ? (acc[0] + acc[1]) + (acc[2] + acc[PS - 1]) : acc[0];
+                            yval = (g == gs) ? s : yval;
+                            ex[tid] = yval;
+                        }
+                    }
+                    const int kk = k0 + g;
+                    if (tid < C * n && kk < N) K.dY[kk * n + i] = yval;
+                }
+            });
+        }
+        K.sync();
+        return;
+    }
     fetch(0, row, cv);
     if constexpr (XL) ex[tid] = yval;
     K.sync();
@@ -1793,6 +1888,55 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
         cv = cvn;
     }
     K.sync();
+}
+
+// nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g of every knot (the new costates of the corrector), for the 12/13-state models by
+// groups of n lanes: lane i of group g forms row i for knot k0 + g from ITS rows of the P_k and Pi_k records (stored transposed:
+// the lanes of a group read consecutive doubles), the next chunk's rows in flight while this one is summed.  A load
+// instruction then touches one line of each of C = 64 / n records; with a
+// lane per knot (step_phase) each of the 2 n^2 loads of the walk touched 50 records -- ~230 cycles apiece through the
+// texture addresser, 80 k of the 1.08 M cycles of a KKT solve.  Same sums in the same order as step_phase.
+template <int MODEL> GD void costate_pass_1w(SweepView<MODEL> K, const double* mugn) {
+    using T = MT<MODEL>;
+    using R = Rec<MODEL>;
+    constexpr int n = T::n, C = 64 / n;
+    const int tid = K.tid, N = K.N;
+    const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
+    double mg[n];
+#pragma unroll
+    for (int l = 0; l < n; l++) mg[l] = mugn[l];
+    constexpr int RING = GUSTO_SWEEP_RING;   // chunk buffers: RING - 1 fetches in flight (see backward_sweep_1w)
+    double pr[RING][n], pi[RING][n];
+    auto fetch = [&](int k0, double* a, double* b) {
+        const int k = (k0 + g + 1 < N) ? k0 + g : N - 2;   // (clamped: no load under a branch)
+        const double* pa = K.Paft + (size_t)k * R::SNN + i;   // (records stored transposed by factor_sweep_mfma: entry (i, l) at l n + i)
+        const double* pb = K.Piaft + (size_t)k * R::SNN + i;
+#pragma unroll
+        for (int l = 0; l < n; l++) { a[l] = pa[l * n]; b[l] = pb[l * n]; }
+    };
+#pragma unroll
+    for (int d = 0; d < RING - 1; d++) fetch(d * C, pr[d], pi[d]);
+    for (int kb = 0; kb + 1 < N; kb += RING * C) {
+        static_for<0, RING>([&](auto DD) {
+            constexpr int d = decltype(DD)::value;
+            const int k0 = kb + d * C;
+            fetch(k0 + (RING - 1) * C, pr[(d + RING - 1) % RING], pi[(d + RING - 1) % RING]);
+            if (k0 + 1 < N) {
+                const bool ok = tid < C * n && k0 + g + 1 < N;
+                const int k = (k0 + g + 1 < N) ? k0 + g : N - 2;
+                double s = K.pv[k * n + i] - K.rv[k * n + i];
+#pragma unroll
+                for (int l = 0; l < n; l++) s += pr[d][l] * K.dY[k * n + l] + pi[d][l] * mg[l];
+                if (ok) K.nun[(k + 1) * n + i] = s;
+            }
+        });
+    }
+    K.sync();
+}
+template <int MODEL> __device__ __noinline__ void costate_pass_1w_call(SweepView<MODEL> K) {
+    K.rebind_lds(gusto_dyn_lds);
+    K.rebind_global();
+    costate_pass_1w<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 48);
 }
 
 // MT::SWEEP_CALL (measured per model: astrobeeSE3 +9 %, the manifold model -10 %): the sweep as a real call.  Inlined, its 50-stage loop shares one register allocation with the whole
@@ -1899,10 +2043,24 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
     for (int i = 0; i < m; i++) d0[i] = 0;
     if (act) {
         double tt[n], lu[m], Gamk[n * m];
+        // (12/13-state models: the last knot's goal term M rd from the M this phase recomputes anyway, by EVERY lane on its own
+        // knot's data and selected below -- as a branch per goal coordinate it was n single-lane walks of the [Phi Gam]
+        // record, one memory round trip each (the workspace of these models lives in HBM: ~3 k cycles), twice per iteration)
+        constexpr bool GT_RECOMP = !T::LTI && n > 8 && T::NDEF == 0;
+        double gterm[n], gsub[n];
         if (k >= 1) {
             if constexpr (T::PG2 || (!T::LTI && n > 8 && T::NDEF == 0)) {
                 double Mk_[n * n];
                 load_M_Gam(K, k, Mk_, Gamk);
+                if constexpr (GT_RECOMP) {
+#pragma unroll
+                    for (int j = 0; j < n; j++) {
+                        double g = 0.0;
+#pragma unroll
+                        for (int i = 0; i < n; i++) if (T::Mnz(j, i)) g += Mk_[j * n + i] * K.rd_(k, i);
+                        gterm[j] = g; gsub[j] = K.misc[64 + j] - K.Xw[k * n + j];
+                    }
+                }
             } else {
                 const double* pg = K.PGk(k);
 #pragma unroll
@@ -1938,7 +2096,6 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         // theta_j = sum_k Pi_k^T c_k - D_k^T lu_k  (+ C M rd_{N-1} - rg at the last knot)
         // LTI models: the last knot's goal term is evaluated by EVERY lane on its own knot's data and selected afterwards --
         // as a branch it is single-lane work (loads and all) that the whole wave waits for, twice per iteration
-        double gterm[n], gsub[n];
         if constexpr (T::LTI) {
             double rdl[n], Mg[n * n];
             if constexpr (T::PG2) {   // (closed form, exactly the stored block: 0.5 ((2 M - I) + I) = M entry by entry)
@@ -1976,8 +2133,8 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
 #pragma unroll
         for (int j = 0; j < n; j++) {
             double s = thd[j];
-            if constexpr (T::LTI) {
-                s = (k == N - 1 && K.is_goal(j)) ? (s + gterm[j]) - gsub[j] : s;
+            if constexpr (T::LTI || GT_RECOMP) {
+                s = (k == N - 1 && K.is_goal(j)) ? (s + gterm[j]) - gsub[j] : s;   // (N >= 2: the last knot has k >= 1)
             } else
             if (k == N - 1 && K.is_goal(j)) {
                 const double* pg = K.PGk(k);
@@ -2099,7 +2256,9 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         }
 #pragma unroll
         for (int i = 0; i < n; i++) K.dXs_(k, i) = dxs[i];
-        if (k + 1 < N && (pass == 1 || ncomp == 0)) {  // nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g
+        // nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g  (one-wave 12/13-state models: costate_pass_1w has done it)
+        if constexpr (!(GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL))
+        if (k + 1 < N && (pass == 1 || ncomp == 0)) {
 #pragma unroll
             for (int i = 0; i < n; i++) {
                 double s = K.pv[k * n + i] - K.rv[k * n + i];
@@ -2126,7 +2285,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         for (int i = 0; i < m; i++) { gAu[i] = 0; gBu[i] = 0; }
         // (small models: the state of the rows every knot has, in one batch of loads -- row by row, each row's loads wait
         // behind the stores of the row before it and the pass pays one memory round trip per row)
-        constexpr int NP = (n <= 8 && T::NDEF == 0) ? T::NFIX + T::NHU : 0;
+        constexpr int NP = ((n <= 8 || GUSTO_ROWPRE_BIG) && T::NDEF == 0) ? T::NFIX + T::NHU : 0;
         RowPre<NP> pre;
         if constexpr (NP > 0) {
             const int slot_u = T::NFIX + K.P.n_obs + 2 * n;
@@ -2226,7 +2385,7 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
         for (int i = 0; i < m; i++) gu0[i] = 0;
         // (small models only: the 12/13-state kernels are far beyond the register file already -- 5 KB of scratch
         // per lane and > 1200 spilled SGPRs -- and more live values there have produced wrong code)
-        constexpr int NP = (n <= 8 && T::NDEF == 0) ? T::NFIX + T::NHU : 0;
+        constexpr int NP = ((n <= 8 || GUSTO_ROWPRE_BIG) && T::NDEF == 0) ? T::NFIX + T::NHU : 0;
         RowPre<NP> pre;
         if constexpr (NP > 0) {
             const int slot_u = T::NFIX + K.P.n_obs + 2 * n;
@@ -2477,7 +2636,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         // (2) residuals, condensed Hessian blocks, dual residual; (3) the LQR stage cost of this knot
         ResidOut ro;
 #ifdef GUSTO_PROFILE
-        if constexpr (T::PG2) { ctx.pf = &pf; ctx.pfb = PF_F4; }   // (slots the pipelined factor sweep leaves free)
+        ctx.pf = &pf; ctx.pfb = PF_R0;
 #endif
         if constexpr (T::SWEEP_CALL) ro = resid_phase_call<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
         else ro = resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
@@ -2594,13 +2753,15 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf);
             pf.tick(PF_MID);
             forward_sweep<MODEL>(K);
+            if constexpr (GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL)
+                if (pass == 1 || ncomp == 0) costate_pass_1w_call<MODEL>(SweepView<MODEL>::make(K));
             pf.tick(PF_FWD);
             GUSTO_REFRESH_K();
             // primal step of this knot, the new costates, row steps + fraction to the boundary
             const double tau = pass ? fmax(0.995, 1.0 - mu) : 1.0;
             StepOut so;
 #ifdef GUSTO_PROFILE
-            if constexpr (T::PG2) { ctx.pf = &pf; ctx.pfb = PF_FPRE; }
+            ctx.pf = &pf; ctx.pfb = PF_S0;
 #endif
             if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
             else so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);

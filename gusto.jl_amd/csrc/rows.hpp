@@ -38,7 +38,7 @@ template <int MODEL> struct RowCtx {
 #ifdef GUSTO_PROFILE
     Prof* pf = nullptr;   // sub-phase stamps of the row passes (PF_R*)
     int pfb = 0;
-    GD void tick(int id) const { if (pf) pf->tick((id == 3 && pfb == PF_FPRE) ? 29 : pfb + id); }
+    GD void tick(int id) const { if (pf) pf->tick(pfb + id); }
 #else
     GD void tick(int) const {}
 #endif

@@ -212,7 +212,7 @@ int gusto_subproblem_trajopt(gusto_handle h, int B, const double* Xp, const doub
                              double* Xn, double* Un, double* Dn, double* obj, int* status, int* iters);
 
 /* Development hook (libraries built with -DGUSTO_PROFILE only, otherwise GUSTO_ERR_STATE): per-problem cycle counters of
- * the kernel's phases, [B][32] (tools/gpu_prof.py).  Stands in for SCPS.iter_elapsed_times at a finer grain. */
+ * the kernel's phases, [B][48] (tools/gpu_prof.py).  Stands in for SCPS.iter_elapsed_times at a finer grain. */
 int gusto_dev_get_prof(gusto_handle h, long long* out);
 /* Development hook: shape of the last gusto_solve / gusto_subproblem launch -- resident (persistent) workgroups, dynamic
  * LDS bytes per workgroup, workgroups per CU.  GUSTO_ERR_STATE before the first launch.  (The freeflyerSE2 N = 50 kernel

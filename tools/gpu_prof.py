@@ -20,13 +20,12 @@ for rep in range(2):
     s.set_problems(x0, glo, ghi, tf); s.solve(30)
 st = s.status()
 print(f"B={B} kernel {s.last_solve_ms():.1f} ms conv {st['converged'].sum()} traj/s {st['converged'].sum()/(s.last_solve_ms()/1e3):.0f} ipm total {st['ipm_iters'].sum()}")
-prof = np.zeros((B, 32), dtype=np.int64)
+prof = np.zeros((B, 48), dtype=np.int64)
 s.L.gusto_dev_get_prof.argtypes = [C.c_void_p, C.c_void_p]
 rc = s.L.gusto_dev_get_prof(s.h, prof.ctypes.data)
 names = ["RESID","BUILD","FACTOR","POSTF","RHS","BACK","MID","FWD","STEP","UPDATE","LIN","SCP","INIT","F:pre","F:AB","F:CD","F1:H","F2:Z","F3:r","F4:chol","F5:ld","F6:solve","F7:store","F8","M:th","M:reduce","M:mu+sync","M:dk/ct","M:sync2","-","-","-"]
-if model == 0:   # the pipelined factor sweep leaves its slots free: sub-phases of the two row passes
-    for i, nm in {13: "S:prolog", 14: "S:fixrows", 15: "S:obsrows", 29: "S:ctlrows", 19: "R:prolog", 20: "R:fixrows", 21: "R:obsrows", 22: "R:ctlrows"}.items(): names[i] = nm
-    names[0] = "R:stagecost"; names[8] = "S:tail+red"; names[16] = "F1(+S:tail p0)"
+names += ["R:prolog", "R:fixrows", "R:obsrows", "R:ctlrows", "S:prolog", "S:fixrows", "S:obsrows", "S:ctlrows"] + ["-"] * 8
+names[0] = "R:stagecost"; names[8] = "S:tail+red"; names[16] = "F1(+S:tail p0)"
 tot = prof.sum(axis=0).astype(float)
 ipm = st["ipm_iters"].sum()
 print("phase: share, cycles per IPM iteration")

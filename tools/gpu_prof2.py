@@ -18,7 +18,7 @@ s = g.BatchSolver(model, 30 if model == 1 else 50, B, hist_cap=64, boxes=boxes, 
 for rep in range(2):
     s.set_problems(x0, glo, ghi, tf); s.solve(30)
 st = s.status()
-prof = np.zeros((B, 32), dtype=np.int64)
+prof = np.zeros((B, 48), dtype=np.int64)
 s.L.gusto_dev_get_prof.argtypes = [C.c_void_p, C.c_void_p]
 s.L.gusto_dev_get_prof(s.h, prof.ctypes.data)
 cyc = prof.sum(axis=1); it = st["ipm_iters"]
