@@ -1429,6 +1429,11 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
     static_assert(!T::LTI && n <= 15 && m <= 8 && R::SNN > NN && R::SKD > 2 * m * n + m * m, "tile / record shape");
     const int tid = K.tid, N = K.N;
     const int mi = tid & 15, mq = tid >> 4;
+#ifdef GUSTO_PROFILE   // finer stamps of a stage (slots 40..47): the value is made a VGPR operand first, so the stamp waits for it
+#define FX_(id, val) do { asm volatile("" :: "v"(val)); pf.tick(40 + (id)); } while (0)
+#else
+#define FX_(id, val) do { } while (0)
+#endif
     const bool c15 = mi == 15;
     // per-lane offsets, fixed for the sweep
     int oF[KS], oG[KS], oGA[MS], oN[KS], oNT[KS], oKr[MS], oDr[MS], oSr[MS], qyy[KS], quy[MS], quu[MS];
@@ -1501,12 +1506,17 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
         }
 #pragma unroll
         for (int s = 0; s < MS; s++) { const double a = PGs[oGA[s]]; GA[s] = vGA[s] ? -a : 0.0; }
+        // (every LDS operand of the stage requested before the first product: left alone hipcc pairs each ds_read with the
+        // MFMA that consumes it and pays the LDS latency once per pair)
+        __builtin_amdgcn_sched_barrier(0);
+        FX_(0, F[0] + G[0] + GA[0]);   // operand gathers from LDS landed
         v4d tph = {0, 0, 0, 0}, tga = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < KS; q++) {               // T_Phi = P Phi (column 15: P c), T_Gam = P Gam
             tph = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[q], F[q], tph, 0, 0, 0);
             tga = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[q], G[q], tga, 0, 0, 0);
         }
+        FX_(1, tph[0] + tga[0]);       // T = P [Phi Gam] done
         v4d hyy = {0, 0, 0, 0}, huy = {0, 0, 0, 0}, huu = {0, 0, 0, 0}, zy = {0, 0, 0, 0}, zu = {0, 0, 0, 0};
 #pragma unroll
         for (int r = 0; r < KS; r++) hyy[r] = qyy[r] < 0 ? 0.0 : qc[r];
@@ -1520,6 +1530,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
             hyy = __builtin_amdgcn_mfma_f64_16x16x4f64(F[q], tph[q], hyy, 0, 0, 0);     // Phi^T T_Phi
             zy = __builtin_amdgcn_mfma_f64_16x16x4f64(F[q], Pit[q], zy, 0, 0, 0);       // Phi^T Pi (row 15: c^T Pi)
         }
+        FX_(2, hyy[0] + huy[0] + huu[0] + zy[0] + zu[0]);   // H, Z done
         // the two matrix-vector products of the stage, for the stage-parallel blocks: r_k = P_k c_k, Pi_k^T c_k
 #pragma unroll
         for (int q = 0; q < KS; q++) { const int row = mq + 4 * q; if (c15 && row < n) K.rv[k * n + row] = tph[q]; }
@@ -1561,6 +1572,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
             LiA[s] = v ? a : 0.0;   // A[i = mi][k = kk] = Li[mi][kk]:   L^-1 X
             LiT[s] = v ? b : 0.0;   // A[i = mi][k = kk] = Li[kk][mi]:   L^-T X  (and, as a B operand, L^-1 itself)
         }
+        FX_(3, LiA[0] + LiT[0]);       // L^-1 through LDS
         // take the prefetched QQ_{k-1} before this stage's stores are issued (see factor_sweep_1w)
 #pragma unroll
         for (int e = 0; e < KS + 2 * MS; e++) qc[e] = qn[e];
@@ -1571,6 +1583,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
             W = __builtin_amdgcn_mfma_f64_16x16x4f64(LiA[s], huy[s], W, 0, 0, 0);      // W = L^-1 H_uy
             V = __builtin_amdgcn_mfma_f64_16x16x4f64(LiA[s], zu[s], V, 0, 0, 0);       // V = L^-1 Z_u
         }
+        FX_(4, W[0] + V[0] + qc[0]);   // W, V done (and the QQ prefetch taken)
         v4d Kt = {0, 0, 0, 0}, Dt = {0, 0, 0, 0}, Si = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < MS; s++) {
@@ -1582,11 +1595,13 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
             Dt = __builtin_amdgcn_mfma_f64_16x16x4f64(LiT[s], V[s], Dt, 0, 0, 0);      // D = L^-T V
             Si = __builtin_amdgcn_mfma_f64_16x16x4f64(LiT[s], LiT[s], Si, 0, 0, 0);    // S^-1 = L^-T L^-1
         }
+        FX_(5, hyy[0] + zy[0] + Gdt[0] + Kt[0] + Dt[0] + Si[0]);   // P', Pi', Gd, K, D, S^-1 done
         v4d Ph = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < KS; q++) Ph[q] = F[q];
 #pragma unroll
         for (int s = 0; s < MS; s++) Ph = __builtin_amdgcn_mfma_f64_16x16x4f64(GA[s], Kt[s], Ph, 0, 0, 0);   // Phi - Gam K
+        FX_(6, Ph[0]);                 // Phicl done
         pf.tick(PF_F6);
         Pt = hyy; Pit = zy;
         // records (unconditional stores: lanes outside a matrix aim at the padding slot of the record)
