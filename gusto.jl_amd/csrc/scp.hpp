@@ -132,6 +132,10 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
             }
             return -1;
         }
+        // (profile builds, slots 40..44: objective after the loop | row check | reductions | rho | accept copy; the matrix-core
+        // models use those slots for their factor stage and lump the trip into slot 47)
+        auto tk = [&](int i_) { pf.tick(MT<MODEL>::MFMA ? 47 : 40 + i_); };
+        tk(0);
         warm = io.status == GUSTO_SOLVER_OPTIMAL;
         total_ipm += io.iters;
         const int h = n_hist;
@@ -162,16 +166,19 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
             visit_rows<MODEL>(ctx, xs, us, op);
             cvx_l = op.ok;
         }
+        tk(1);
         const double max_d2 = block_reduce(dn, OpMax(), K.misc);
         const double max_x2 = block_reduce(xn, OpMax(), K.misc);
         const double conv = sqrt(max_d2) / sqrt(max_x2);
         const int cvx_sat = block_reduce(cvx_l ? 0.0 : 1.0, OpMax(), K.misc) == 0.0;
+        tk(2);
         // the literal `max_val - Delta <= 0` evaluated with the solver's accuracy as slack
         const int tr_sat = (max_d2 - Delta <= P.io.tr_tol * fmax(1.0, Delta));
         int accept, status;
         double Delta_n, omega_n;
         if (tr_sat) {                                       // :123-141
             const double rho = trust_region_ratio<MODEL>(K, K.Xw, K.Uw, K.Xp, K.Up);
+            tk(3);
             if (tid == 0) P.rho[hb + n_rho] = rho;
             n_rho++;
             if (rho > sp.rho1) {
@@ -191,6 +198,7 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
             for (int e = tid; e < N * n; e += K.nt()) K.Xp[e] = K.Xw[e];
             for (int e = tid; e < N * m; e += K.nt()) K.Up[e] = K.Uw[e];
             K.sync();
+            tk(4);
         }
         if (tid == 0)
             for (int i = 0; i < n; i++) std_[SD_DUAL + i] = K.nu[i] * fmax(1.0, omega);  // :117 get_dual_jump

@@ -29,6 +29,8 @@ names += ["R:prolog", "R:fixrows", "R:obsrows", "R:ctlrows", "S:prolog", "S:fixr
 names[0] = "R:stagecost"; names[8] = "S:tail+red"; names[16] = "F1(+S:tail p0)"
 tot = prof.sum(axis=0).astype(float)
 ipm = st["ipm_iters"].sum()
+if model in (0, 1):   # (no matrix-core factor sweep: slots 40..44 are the per-trip stamps of scp.hpp)
+    names[40:45] = ["T:obj", "T:rowcheck", "T:reduce", "T:rho", "T:accept"]
 print("phase: share, cycles per IPM iteration")
 for i, nm in enumerate(names):
     print(f"  {nm:7s} {100*tot[i]/tot.sum():5.1f}%  {tot[i]/ipm:9.0f}")
