@@ -365,8 +365,12 @@ template <class Op> GD double wave_reduce(double v, Op op) {
 GD double nanmax(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
 struct OpNanMax { GD double operator()(double a, double b) const { return nanmax(a, b); } };
 
-template <class Op> GD double block_reduce(double v, Op op, double* sred) {
+// ONE: the caller's kernel is a one-wave kernel (Blk::ONE).  Without it the test below reads blockDim from the dispatch
+// packet -- inside the phases that are real calls (MT::SWEEP_CALL) on every call: an s_load, a global_load_ushort and an
+// s_waitcnt vmcnt(0) that drains every load in flight, ~830 cycles per reduction, two dozen reductions per KKT solve.
+template <bool ONE = false, class Op> GD double block_reduce(double v, Op op, double* sred) {
     v = wave_reduce(v, op);
+    if constexpr (ONE) return v;
     if (blockDim.x <= 64) return v;
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();

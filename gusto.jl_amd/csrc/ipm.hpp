@@ -2162,7 +2162,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
     }
     MT_(PF_M_TH);
 #pragma unroll
-    for (int j = 0; j < n; j++) th[j] = (K.goalmask != 0) ? block_reduce(th[j], OpSum(), red) : 0.0;
+    for (int j = 0; j < n; j++) th[j] = (K.goalmask != 0) ? block_reduce<BLK::ONE>(th[j], OpSum(), red) : 0.0;
     MT_(PF_M_RED);
     if (k == 0) {
 #pragma unroll
@@ -2618,7 +2618,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         *fail = 0.0;
         for (int i = 0; i < n; i++) { mug[i] = 0; mugn[i] = 0; }
     }
-    const double ncomp = block_reduce(ncomp_l, OpSum(), red);
+    const double ncomp = block_reduce<BLK::ONE>(ncomp_l, OpSum(), red);
     K.sync();
     pf.tick(PF_INIT);
 
@@ -2656,10 +2656,10 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         if constexpr (T::SWEEP_CALL) ro = resid_phase_call<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
         else ro = resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
         const double l_resp = ro.resp, l_resd = ro.resd, l_comp = ro.comp, l_numax = ro.numax;
-        res_p = block_reduce(l_resp, OpNanMax(), red);
-        res_d = block_reduce(l_resd, OpNanMax(), red);
-        const double comp = block_reduce(l_comp, OpSum(), red);
-        const double numax = block_reduce(l_numax, OpMax(), red);
+        res_p = block_reduce<BLK::ONE>(l_resp, OpNanMax(), red);
+        res_d = block_reduce<BLK::ONE>(l_resd, OpNanMax(), red);
+        const double comp = block_reduce<BLK::ONE>(l_comp, OpSum(), red);
+        const double numax = block_reduce<BLK::ONE>(l_numax, OpMax(), red);
         mu = ncomp > 0 ? comp / ncomp : 0.0;
         K.sync();
         pf.tick(PF_RESID);
@@ -2781,11 +2781,11 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
             else so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
             const double l_amax = so.amax, l_c0 = so.c0, l_c1 = so.c1, l_c2 = so.c2;
-            const double a_max = block_reduce(l_amax, OpMin(), red);
+            const double a_max = block_reduce<BLK::ONE>(l_amax, OpMin(), red);
             alpha = a_max;
             if (pass == 0) {
-                const double q0 = block_reduce(l_c0, OpSum(), red), q1 = block_reduce(l_c1, OpSum(), red),
-                             q2 = block_reduce(l_c2, OpSum(), red);
+                const double q0 = block_reduce<BLK::ONE>(l_c0, OpSum(), red), q1 = block_reduce<BLK::ONE>(l_c1, OpSum(), red),
+                             q2 = block_reduce<BLK::ONE>(l_c2, OpSum(), red);
                 const double ca = q0 + a_max * (q1 + a_max * q2);   // complementarity after the affine step
                 const double mu_aff = ncomp > 0 ? ca / ncomp : 0.0;
                 const double rr = (mu > 0) ? mu_aff / mu : 0.0;
@@ -2828,7 +2828,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         visit_rows<MODEL>(ctx, xs, us, op);
         l_obj += op.sum;
     }
-    const double obj = block_reduce(l_obj, OpSum(), red);
+    const double obj = block_reduce<BLK::ONE>(l_obj, OpSum(), red);
     K.sync();
 #undef GUSTO_REFRESH_K
     out.status = status; out.iters = it; out.obj = obj / kappa; out.res_p = res_p; out.res_d = res_d; out.mu = mu;

@@ -19,7 +19,7 @@ template <class BLK> GD double cost_true(BLK& K, const double* U) {
 #pragma unroll
         for (int j = 0; j < mc; j++) l += 0.5 * K.dt * (U[(k - 1) * m + j] * U[(k - 1) * m + j] + U[k * m + j] * U[k * m + j]);
     }
-    return block_reduce(l, OpSum(), K.misc);
+    return block_reduce<BLK::ONE>(l, OpSum(), K.misc);
 }
 
 // trust_region_ratio_gusto (freeflyer_se2.jl:392-427 etc.); the "linearised" dynamics deliberately lack B*du
@@ -64,8 +64,8 @@ template <int MODEL, class BLK> GD double trust_region_ratio(BLK& K, const doubl
                 }
         }
     }
-    num = block_reduce(num, OpSum(), K.misc);
-    den = block_reduce(den, OpSum(), K.misc);
+    num = block_reduce<BLK::ONE>(num, OpSum(), K.misc);
+    den = block_reduce<BLK::ONE>(den, OpSum(), K.misc);
     return num / den;
 }
 
@@ -167,10 +167,10 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
             cvx_l = op.ok;
         }
         tk(1);
-        const double max_d2 = block_reduce(dn, OpMax(), K.misc);
-        const double max_x2 = block_reduce(xn, OpMax(), K.misc);
+        const double max_d2 = block_reduce<ONEWAVE>(dn, OpMax(), K.misc);
+        const double max_x2 = block_reduce<ONEWAVE>(xn, OpMax(), K.misc);
         const double conv = sqrt(max_d2) / sqrt(max_x2);
-        const int cvx_sat = block_reduce(cvx_l ? 0.0 : 1.0, OpMax(), K.misc) == 0.0;
+        const int cvx_sat = block_reduce<ONEWAVE>(cvx_l ? 0.0 : 1.0, OpMax(), K.misc) == 0.0;
         tk(2);
         // the literal `max_val - Delta <= 0` evaluated with the solver's accuracy as slack
         const int tr_sat = (max_d2 - Delta <= P.io.tr_tol * fmax(1.0, Delta));
@@ -381,7 +381,7 @@ template <class BLK> GD double convergence_metric_blk(BLK& K, const double* X, c
 #pragma unroll
         for (int i = 0; i < n; i++) { const double e = X[k * n + i] - Xq[k * n + i]; dn += e * e; xn += X[k * n + i] * X[k * n + i]; }
     }
-    const double a = block_reduce(dn, OpMax(), K.misc), b = block_reduce(xn, OpMax(), K.misc);
+    const double a = block_reduce<BLK::ONE>(dn, OpMax(), K.misc), b = block_reduce<BLK::ONE>(xn, OpMax(), K.misc);
     return sqrt(a) / sqrt(b);
 }
 // trust_region_ratio_trajopt (freeflyer_se2.jl:429-467, astrobee_se3.jl:419-460) with the index typos of its dynamics terms
@@ -430,8 +430,8 @@ template <int MODEL, class BLK> GD double trajopt_ratio(BLK& K, const double* X,
                 num += (cl - d0) - (cl - d1); den += (cl - d0) - (cl - lin);
             }
     }
-    num = block_reduce(num, OpSum(), K.misc);
-    den = block_reduce(den, OpSum(), K.misc);
+    num = block_reduce<BLK::ONE>(num, OpSum(), K.misc);
+    den = block_reduce<BLK::ONE>(den, OpSum(), K.misc);
     return num / den;
 }
 // evaluate_ctol (scp_trajopt.jl:289-312): per class of constraints the largest change and the largest value over its members,
@@ -445,7 +445,7 @@ template <int MODEL, class BLK> GD double trajopt_ctol(BLK& K, const double* X, 
     const gusto_model_params& mp = K.P.mp;
     double JN = 0, JD = 0;
     auto cls = [&](double a, double b) {
-        JN += block_reduce(a, OpMax(), K.misc); JD += block_reduce(b, OpMax(), K.misc);
+        JN += block_reduce<BLK::ONE>(a, OpMax(), K.misc); JD += block_reduce<BLK::ONE>(b, OpMax(), K.misc);
     };
     double x[n], q[n];
 #pragma unroll
