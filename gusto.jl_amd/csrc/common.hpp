@@ -23,6 +23,9 @@ GD bool row_is_hard(int kind) { return kind == ROW_HARD || kind == ROW_HARD_EQ; 
 constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5, RS_DS = 6, RS_KA = 7, RS_KB = 8,
               RS_NVAR = 9;
 
+#ifndef GUSTO_KD_LDS_SMALL
+#define GUSTO_KD_LDS_SMALL 1
+#endif
 #ifndef GUSTO_WAVES_PER_EU
 #define GUSTO_WAVES_PER_EU 1
 #endif
@@ -233,8 +236,11 @@ template <int MODEL, bool ONE> struct LdsC {
 #ifdef GUSTO_NO_KD_LDS
     static constexpr bool KD_LDS = false;
 #else
-    static constexpr bool KD_LDS = ONE && T::PG2 && n <= 8;
+    // (the 3-state model too: it keeps BOTH K | D | S^-1 -- 10 doubles per knot, for the stage-parallel phases -- and Phicl,
+    // for the vector sweeps, in LDS; no select chains for the K | D | S^-1 record, no QQ record in global memory)
+    static constexpr bool KD_LDS = ONE && n <= 8 && (T::PG2 || GUSTO_KD_LDS_SMALL);
 #endif
+    static constexpr bool PHI_FROM_K = KD_LDS && T::PG2;   // the vector sweeps rebuild Phicl from K (double integrator)
     static constexpr int KDW = 2 * m * n + m * (m + 1) / 2;
     // ... and the slot of knot k first holds the stage cost QQ_k (NZ (NZ + 1) / 2 doubles): the residual phase writes it
     // there, factor stage k reads it and then overwrites the slot with K_k | D_k | S_k^-1 -- the factors of the previous
@@ -243,12 +249,13 @@ template <int MODEL, bool ONE> struct LdsC {
 #ifdef GUSTO_NO_PHICL_LDS
     static constexpr bool PHICL_LDS = false;
 #else
-    static constexpr bool PHICL_LDS = n <= 8 && !(T::PG2 && n <= 8);
+    static constexpr bool PHICL_LDS = n <= 8 && !PHI_FROM_K;
 #endif
 };
 struct LdsLayout {
     int total;
-    int phicl;  // offset of the LDS copy of Phicl -- or of K | D | S^-1, LdsC::KD_LDS -- (doubles), -1 if in the global workspace
+    int phicl;  // offset of the LDS copy of Phicl (doubles), -1 if in the global workspace or rebuilt from K
+    int kd;     // offset of K | D | S^-1 per knot in LDS (LdsC::KD_LDS), -1 if in the global workspace
 };
 template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     using C1 = LdsC<MODEL, true>;
@@ -257,9 +264,9 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     // (the TrajOpt variants run the multi-wave phases whatever N: their layout is the multi-wave one)
     const bool one = N <= 64 && MT<MODEL>::NDEF == 0;
     L.total = (one ? C1::vecs : CM::vecs) + N * (C1::NVN * C1::n + C1::NVM * C1::m);
-    L.phicl = -1;
-    if (C1::KD_LDS && one) { L.phicl = L.total; L.total += N * C1::KDS; }
-    else if (C1::PHICL_LDS && one) { L.phicl = L.total; L.total += N * C1::n * C1::n; }
+    L.phicl = -1; L.kd = -1;
+    if (C1::KD_LDS && one) { L.kd = L.total; L.total += N * C1::KDS; }
+    if (C1::PHICL_LDS && one) { L.phicl = L.total; L.total += N * C1::n * C1::n; }
     return L;
 }
 

@@ -102,7 +102,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         Xw = v; dY = v + N * n; pv = v + 2 * N * n; cv = v + 3 * N * n; rv = v + 4 * N * n; nu = v + 5 * N * n;
         nun = v + 6 * N * n;
         Uw = v + C::NVN * N * n;
-        if constexpr (C::KD_LDS) kdl = lds + P.ll.phicl;
+        if constexpr (C::KD_LDS) kdl = lds + P.ll.kd;
     }
     // entry e of the K | D block of knot k (e = i n + j of K, m n + i n + j of D) and S_k^-1[i][l]
     GD double kd(int k, int e) const {
@@ -652,7 +652,7 @@ template <int MODEL> struct SweepView {
     GD void sync() const { blk_sync<true>(); }
     GD const double* PGk(int k) const { return PG + (size_t)(T::LTI ? 0 : k) * n * NZ; }
     GD bool is_goal(int i) const { return (goalmask >> i) & 1u; }
-    int phicl_off;   // LdsLayout::phicl
+    int phicl_off, kd_off;   // LdsLayout::phicl, ::kd
     GD void rebind_lds(double* l) {   // see Blk::rebind_lds
         lds = l;
         sP = lds + C::sP; sPi = lds + C::sPi; sPG = lds + C::sPG; sT = lds + C::sT; sHh = lds + C::sHh;
@@ -662,14 +662,14 @@ template <int MODEL> struct SweepView {
         dY = v + N * n; pv = v + 2 * N * n; cv = v + 3 * N * n; rv = v + 4 * N * n; nun = v + 6 * N * n;
         // (one-wave problems of the small models: Phicl lives in LDS, stride n*n; otherwise padded global records)
         if constexpr (C::PHICL_LDS) Phicl = lds + phicl_off;
-        if constexpr (C::KD_LDS) kdl = lds + phicl_off;
+        if constexpr (C::KD_LDS) kdl = lds + kd_off;
     }
     GD void rebind_global() {
         PG = al16((double*)PG); QQ = al16((double*)QQ); Paft = al16((double*)Paft); Piaft = al16((double*)Piaft); KD = al16((double*)KD);
     }
     template <class BLK> GD static SweepView make(const BLK& K) {
         SweepView v;
-        v.N = K.N; v.phicl_off = K.P.ll.phicl;
+        v.N = K.N; v.phicl_off = K.P.ll.phicl; v.kd_off = K.P.ll.kd;
         if constexpr (!C::PHICL_LDS) v.Phicl = K.Phicl;   // (LDS copy of the small models: set by rebind_lds)
         v.rebind_lds(K.lds);
         v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.KD = K.KD;
@@ -1202,7 +1202,7 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
     const int wP = on ? C::sP + i * n + pcol(j) : dmy, wPi = on ? C::sPi + j * n + i : dmy, wGd = on ? C::sGd + tid : dmy;
     const int vecs = C::vecs, oCv = vecs + 3 * N * n, oRv = vecs + 4 * N * n, oNun = vecs + 6 * N * n;   // (Blk::rebind_lds)
     const int wRv = tid < n ? oRv + tid : dmy, wNun = tid < n ? oNun + tid : dmy, sRv = tid < n ? n : 0;
-    const int kdo = K.phicl_off;
+    const int kdo = K.kd_off;
     const int wKD = tid < n ? kdo + tid : dmy, sKD = tid < n ? C::KDS : 0;             // K[a][tid] at + a n, D[a][tid] at + (m + a) n
     const int wSi = tid == 0 ? kdo + 2 * m * n : dmy, sSi = tid == 0 ? C::KDS : 0;     // S^-1, upper triangle
     const int ep = (on && i <= j) ? sidx(i, j, n) : R::SNN - 1, eq = on ? NH + tid : R::SNN - 1;   // packed P | Pi record
@@ -1657,7 +1657,7 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
     // (KD_LDS) the entries of Gam and Phi of the double integrator, formed as linearize() forms them
     double gl[n];
     auto phi_e = [&](int r_, int c_) { return (r_ == c_) ? 1.0 : ((c_ == r_ + n / 2) ? K.dt : 0.0); };
-    if constexpr (BLK::C::KD_LDS) {
+    if constexpr (BLK::C::PHI_FROM_K) {
         constexpr int m = BLK::m;
         double Bd[n * m];
         Dyn<BLK::MODEL_ID>::B(*K.mpp, Bd);
@@ -1678,7 +1678,7 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
         // guarded wave-uniformly below -- so its operands only need to be loadable.  As `ok ? load : 0` every load sat
         // in a branch of its own.)
         const int kk = (k0 - g >= 1) ? k0 - g : 1;
-        if constexpr (BLK::C::KD_LDS) {
+        if constexpr (BLK::C::PHI_FROM_K) {
             // column i of Phicl = Phi - Gam K from the LDS copy of K: Gam has ONE entry per row (row l: column l mod m),
             // Phi = I + dt [0 I; 0 0]; the fma of the factor sweep (which formed Phi - Gam K with the zero terms too)
             constexpr int m = BLK::m;
@@ -1793,7 +1793,7 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
     const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
     double gi = 0.0;
     auto phi_e = [&](int r_, int c_) { return (r_ == c_) ? 1.0 : ((c_ == r_ + n / 2) ? K.dt : 0.0); };
-    if constexpr (BLK::C::KD_LDS) {
+    if constexpr (BLK::C::PHI_FROM_K) {
         constexpr int m = BLK::m;
         double Bd[n * m];
         Dyn<BLK::MODEL_ID>::B(*K.mpp, Bd);
@@ -1812,7 +1812,7 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
     double row[n], rown[n], cv, cvn = 0, yval = 0.0;
     auto fetch = [&](int k0, double* r, double& c) {
         const int kk = (k0 + g < N) ? k0 + g : N - 1;   // (clamped, see backward_sweep_1w)
-        if constexpr (BLK::C::KD_LDS) {   // row i of Phicl = Phi - Gam K (see backward_sweep_1w)
+        if constexpr (BLK::C::PHI_FROM_K) {   // row i of Phicl = Phi - Gam K (see backward_sweep_1w)
             constexpr int m = BLK::m;
             const int ic = (i < m) ? i : i - m;
 #pragma unroll
