@@ -23,6 +23,9 @@ GD bool row_is_hard(int kind) { return kind == ROW_HARD || kind == ROW_HARD_EQ; 
 constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5, RS_DS = 6, RS_KA = 7, RS_KB = 8,
               RS_NVAR = 9;
 
+#ifndef GUSTO_PG_LDS
+#define GUSTO_PG_LDS 1
+#endif
 #ifndef GUSTO_KD_LDS_SMALL
 #define GUSTO_KD_LDS_SMALL 1
 #endif
@@ -241,6 +244,10 @@ template <int MODEL, bool ONE> struct LdsC {
     static constexpr bool KD_LDS = ONE && n <= 8 && (T::PG2 || GUSTO_KD_LDS_SMALL);
 #endif
     static constexpr bool PHI_FROM_K = KD_LDS && T::PG2;   // the vector sweeps rebuild Phicl from K (double integrator)
+    // the 3-state time-varying model keeps [Phi Gam] of every knot in LDS as well (12 doubles per knot): linearize() writes
+    // it there, the factor sweep reads its stage operands in place (no prefetch, no staging buffer) and the stage-parallel
+    // phases read M and Gam of their knot from LDS instead of walking a global record
+    static constexpr bool PG_LDS = ONE && !T::LTI && n <= 4 && GUSTO_PG_LDS;
     static constexpr int KDW = 2 * m * n + m * (m + 1) / 2;
     // ... and the slot of knot k first holds the stage cost QQ_k (NZ (NZ + 1) / 2 doubles): the residual phase writes it
     // there, factor stage k reads it and then overwrites the slot with K_k | D_k | S_k^-1 -- the factors of the previous
@@ -256,6 +263,7 @@ struct LdsLayout {
     int total;
     int phicl;  // offset of the LDS copy of Phicl (doubles), -1 if in the global workspace or rebuilt from K
     int kd;     // offset of K | D | S^-1 per knot in LDS (LdsC::KD_LDS), -1 if in the global workspace
+    int pg;     // offset of [Phi Gam] per knot in LDS (LdsC::PG_LDS), -1 if in the global workspace
 };
 template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     using C1 = LdsC<MODEL, true>;
@@ -267,6 +275,8 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     L.phicl = -1; L.kd = -1;
     if (C1::KD_LDS && one) { L.kd = L.total; L.total += N * C1::KDS; }
     if (C1::PHICL_LDS && one) { L.phicl = L.total; L.total += N * C1::n * C1::n; }
+    L.pg = -1;
+    if (C1::PG_LDS && one) { L.pg = L.total; L.total += N * C1::n * C1::NZ; }
     return L;
 }
 

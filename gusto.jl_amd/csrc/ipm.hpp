@@ -64,6 +64,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     // global workspace of this problem
     GPtr<double> rowstate, obs_nh, obs_c0, PG, QQ, Paft, Piaft, KD, Phicl;
     LPtr<double> kdl;   // K | D | S^-1 (upper triangle) per knot in LDS, stride C::KDS (LdsC::KD_LDS); before factor stage k the slot of knot k holds QQ_k
+    LPtr<double> pgl;   // [Phi Gam] per knot in LDS (LdsC::PG_LDS)
     GPtr<uint64_t> obs_mask;
     GPtr<const double> x_init, goal_lo, goal_hi;
     unsigned goalmask;  // bit i: coordinate i of x_N has a point goal (goal_lo == goal_hi)
@@ -103,6 +104,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         nun = v + 6 * N * n;
         Uw = v + C::NVN * N * n;
         if constexpr (C::KD_LDS) kdl = lds + P.ll.kd;
+        if constexpr (C::PG_LDS) pgl = lds + P.ll.pg;
     }
     // entry e of the K | D block of knot k (e = i n + j of K, m n + i n + j of D) and S_k^-1[i][l]
     GD double kd(int k, int e) const {
@@ -159,7 +161,10 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         }
     }
     GD void sync() const { blk_sync<ONEWAVE>(); }
-    GD const double* PGk(int k) const { return PG + (size_t)(T::LTI ? 0 : k) * n * NZ; }
+    GD auto PGk(int k) const {
+        if constexpr (C::PG_LDS) return pgl + k * n * NZ;
+        else return PG + (size_t)(T::LTI ? 0 : k) * n * NZ;
+    }
     GD bool is_goal(int i) const { return (goalmask >> i) & 1u; }
 };
 
@@ -283,7 +288,7 @@ template <class BLK> GD void load_M_Gam(const BLK& K, int k, double* M, double* 
         }
         return;
     }
-    const double* pg = K.PGk(k);
+    const auto pg = K.PGk(k);
 #pragma unroll
     for (int i = 0; i < n; i++) {
 #pragma unroll
@@ -307,7 +312,7 @@ template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
             double M[n * n], B[n * m];
             const double h = 0.5 * K.dt;
             stage_M<MODEL>(K.P.mp, xp, up, h, M, B);
-            double* pg = K.PG + (size_t)(T::LTI ? 0 : k) * n * NZ;
+            auto pg = K.PGk(T::LTI ? 0 : k);
             const bool knot0 = !T::LTI && k == 0;   // x_1 is pinned: the sweep's operand of knot 0 is [0 | b_0], b_0 = dt/2 B
 #pragma unroll
             for (int i = 0; i < n; i++) {
@@ -368,7 +373,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
 #pragma unroll
     for (int r = 0; r < PPT; r++) pgn[r] = 0.0;
     {
-        const double* pg = K.PGk(N - 1);
+        const auto pg = K.PGk(N - 1);
         for (int e = tid; e < NPG; e += NT) K.sPG[((N - 1) & 1) * NPG + e] = pg[e];
     }
     K.sync();
@@ -382,7 +387,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
             qqn[r] = (k > 0 && e < NQ) ? K.QQ[(size_t)(k - 1) * R::SQQ + e] : 0.0;
         }
         if (!T::LTI && k > 1) {
-            const double* pg = K.PGk(k - 1);
+            const auto pg = K.PGk(k - 1);
 #pragma unroll
             for (int r = 0; r < PPT; r++) { const int e = tid + r * NT; pgn[r] = (e < NPG) ? pg[e] : 0.0; }
         }
@@ -643,14 +648,19 @@ template <int MODEL> struct SweepView {
     LPtr<double> cv, rv, nun, pv, dY;
     GPtr<double> PG, QQ, Paft, Piaft, KD;
     std::conditional_t<C::PHICL_LDS, LPtr<double>, GPtr<double>> Phicl;
-    LPtr<double> kdl;   // K | D | S^-1 per knot in LDS (LdsC::KD_LDS; Phicl is then rebuilt from K by the sweeps)
+    LPtr<double> kdl;   // K | D | S^-1 per knot in LDS (LdsC::KD_LDS; the double integrator's sweeps rebuild Phicl from it)
+    LPtr<double> pgl;   // [Phi Gam] per knot in LDS (LdsC::PG_LDS)
+    int pg_off;
     const gusto_model_params* mpp;
     struct PW { const gusto_model_params& mp; } ;
     int tid, N;
     double dt;
     unsigned goalmask;
     GD void sync() const { blk_sync<true>(); }
-    GD const double* PGk(int k) const { return PG + (size_t)(T::LTI ? 0 : k) * n * NZ; }
+    GD auto PGk(int k) const {
+        if constexpr (C::PG_LDS) return pgl + k * n * NZ;
+        else return PG + (size_t)(T::LTI ? 0 : k) * n * NZ;
+    }
     GD bool is_goal(int i) const { return (goalmask >> i) & 1u; }
     int phicl_off, kd_off;   // LdsLayout::phicl, ::kd
     GD void rebind_lds(double* l) {   // see Blk::rebind_lds
@@ -663,13 +673,14 @@ template <int MODEL> struct SweepView {
         // (one-wave problems of the small models: Phicl lives in LDS, stride n*n; otherwise padded global records)
         if constexpr (C::PHICL_LDS) Phicl = lds + phicl_off;
         if constexpr (C::KD_LDS) kdl = lds + kd_off;
+        if constexpr (C::PG_LDS) pgl = lds + pg_off;
     }
     GD void rebind_global() {
         PG = al16((double*)PG); QQ = al16((double*)QQ); Paft = al16((double*)Paft); Piaft = al16((double*)Piaft); KD = al16((double*)KD);
     }
     template <class BLK> GD static SweepView make(const BLK& K) {
         SweepView v;
-        v.N = K.N; v.phicl_off = K.P.ll.phicl; v.kd_off = K.P.ll.kd;
+        v.N = K.N; v.phicl_off = K.P.ll.phicl; v.kd_off = K.P.ll.kd; v.pg_off = K.P.ll.pg;
         if constexpr (!C::PHICL_LDS) v.Phicl = K.Phicl;   // (LDS copy of the small models: set by rebind_lds)
         v.rebind_lds(K.lds);
         v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.KD = K.KD;
@@ -686,7 +697,8 @@ template <int MODEL, class BLK> GD double* pg_buf(const BLK& K, int k) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int NPG = T::n * (T::n + T::m);
-    if constexpr (T::LTI) return K.sPG + (k == 0 ? 2 * NPG : 0);
+    if constexpr (LdsC<MODEL, true>::PG_LDS) return K.pgl + k * NPG;   // (every knot's block lives in LDS: read in place)
+    else if constexpr (T::LTI) return K.sPG + (k == 0 ? 2 * NPG : 0);
     else return K.sPG + (k & 1) * NPG;
 }
 
@@ -727,7 +739,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 K.sPG[e] = K.PGk(N - 1)[e];
             }
         }
-    } else {   // time-varying: block N-1 now, the others one knot ahead; block 0 of the global array IS [0 | b_0]
+    } else if constexpr (!C::PG_LDS) {   // time-varying: block N-1 now, the others one knot ahead; block 0 of the global array IS [0 | b_0]
 #pragma unroll
         for (int r = 0; r < RT; r++) {
             const int e = tid + 64 * r;
@@ -764,8 +776,8 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             if constexpr (C::KD_LDS) qqn[r] = K.kdl[((k > 0) ? k - 1 : 0) * C::KDS + (e < NQ ? e : 0)];   // (slot k-1 still holds QQ_{k-1})
             else qqn[r] = K.QQ[(size_t)((k > 0) ? k - 1 : 0) * R::SQQ + e];   // (padded record: every lane has an entry)
         }
-        if (!T::LTI) {
-            const double* pg = K.PGk((k > 0) ? k - 1 : 0);
+        if (!T::LTI && !C::PG_LDS) {
+            const auto pg = K.PGk((k > 0) ? k - 1 : 0);
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
         }
@@ -1141,7 +1153,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                 }
             }
         }
-        if (!T::LTI && k > 0) {
+        if (!T::LTI && !C::PG_LDS && k > 0) {
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; if (e < NPG) K.sPG[((k - 1) & 1) * NPG + e] = pgn[r]; }
         }
@@ -1491,7 +1503,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
         const double* PGs = pg_buf<MODEL>(K, k);
         gather((k > 0) ? k - 1 : 0, qn);
         {
-            const double* pg = K.PGk((k > 0) ? k - 1 : 0);
+            const auto pg = K.PGk((k > 0) ? k - 1 : 0);
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
         }
@@ -2077,7 +2089,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
                     }
                 }
             } else {
-                const double* pg = K.PGk(k);
+                const auto pg = K.PGk(k);
 #pragma unroll
                 for (int i = 0; i < n; i++)
 #pragma unroll
@@ -2117,7 +2129,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
                 double Gg[n * m];
                 load_M_Gam(K, k, Mg, Gg);
             } else {
-                const double* pg = K.PGk(0);
+                const auto pg = K.PGk(0);
 #pragma unroll
                 for (int j = 0; j < n; j++)
 #pragma unroll
@@ -2152,7 +2164,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
                 s = (k == N - 1 && K.is_goal(j)) ? (s + gterm[j]) - gsub[j] : s;   // (N >= 2: the last knot has k >= 1)
             } else
             if (k == N - 1 && K.is_goal(j)) {
-                const double* pg = K.PGk(k);
+                const auto pg = K.PGk(k);
 #pragma unroll
                 for (int i = 0; i < n; i++) s += 0.5 * (pg[j * NZ + i] + (i == j ? 1.0 : 0.0)) * K.rd_(k, i);
                 s -= K.misc[64 + j] - K.Xw[k * n + j];
@@ -2191,7 +2203,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
                 double Mk_[n * n];
                 load_M_Gam(K, k, Mk_, Gamk);
             } else {
-                const double* pg = K.PGk(k);
+                const auto pg = K.PGk(k);
 #pragma unroll
                 for (int i = 0; i < n; i++)
 #pragma unroll
