@@ -23,6 +23,9 @@ GD bool row_is_hard(int kind) { return kind == ROW_HARD || kind == ROW_HARD_EQ; 
 constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5, RS_DS = 6, RS_KA = 7, RS_KB = 8,
               RS_NVAR = 9;
 
+#ifndef GUSTO_LC_LDS
+#define GUSTO_LC_LDS 1
+#endif
 #ifndef GUSTO_PG_LDS
 #define GUSTO_PG_LDS 1
 #endif
@@ -248,6 +251,9 @@ template <int MODEL, bool ONE> struct LdsC {
     // it there, the factor sweep reads its stage operands in place (no prefetch, no staging buffer) and the stage-parallel
     // phases read M and Gam of their knot from LDS instead of walking a global record
     static constexpr bool PG_LDS = ONE && !T::LTI && n <= 4 && GUSTO_PG_LDS;
+    // ... and two numbers per knot from which f and A of the linearisation point follow without a sin / cos (Dyn::lin_cache):
+    // the phases of an interior point iteration asked for them six times, ~140 instructions apiece in double precision
+    static constexpr bool LC_LDS = ONE && MODEL == GUSTO_DUBINS_CAR && GUSTO_LC_LDS;
     static constexpr int KDW = 2 * m * n + m * (m + 1) / 2;
     // ... and the slot of knot k first holds the stage cost QQ_k (NZ (NZ + 1) / 2 doubles): the residual phase writes it
     // there, factor stage k reads it and then overwrites the slot with K_k | D_k | S_k^-1 -- the factors of the previous
@@ -264,6 +270,7 @@ struct LdsLayout {
     int phicl;  // offset of the LDS copy of Phicl (doubles), -1 if in the global workspace or rebuilt from K
     int kd;     // offset of K | D | S^-1 per knot in LDS (LdsC::KD_LDS), -1 if in the global workspace
     int pg;     // offset of [Phi Gam] per knot in LDS (LdsC::PG_LDS), -1 if in the global workspace
+    int lc;     // offset of the linearisation cache (LdsC::LC_LDS: 2 doubles per knot), -1 if none
 };
 template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     using C1 = LdsC<MODEL, true>;
@@ -277,6 +284,8 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     if (C1::PHICL_LDS && one) { L.phicl = L.total; L.total += N * C1::n * C1::n; }
     L.pg = -1;
     if (C1::PG_LDS && one) { L.pg = L.total; L.total += N * C1::n * C1::NZ; }
+    L.lc = -1;
+    if (C1::LC_LDS && one) { L.lc = L.total; L.total += 2 * N; }
     return L;
 }
 

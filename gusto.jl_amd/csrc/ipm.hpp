@@ -65,6 +65,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     GPtr<double> rowstate, obs_nh, obs_c0, PG, QQ, Paft, Piaft, KD, Phicl;
     LPtr<double> kdl;   // K | D | S^-1 (upper triangle) per knot in LDS, stride C::KDS (LdsC::KD_LDS); before factor stage k the slot of knot k holds QQ_k
     LPtr<double> pgl;   // [Phi Gam] per knot in LDS (LdsC::PG_LDS)
+    LPtr<double> lcl;   // linearisation cache per knot in LDS (LdsC::LC_LDS)
     GPtr<uint64_t> obs_mask;
     GPtr<const double> x_init, goal_lo, goal_hi;
     unsigned goalmask;  // bit i: coordinate i of x_N has a point goal (goal_lo == goal_hi)
@@ -105,6 +106,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         Uw = v + C::NVN * N * n;
         if constexpr (C::KD_LDS) kdl = lds + P.ll.kd;
         if constexpr (C::PG_LDS) pgl = lds + P.ll.pg;
+        if constexpr (C::LC_LDS) lcl = lds + P.ll.lc;
     }
     // entry e of the K | D block of knot k (e = i n + j of K, m n + i n + j of D) and S_k^-1[i][l]
     GD double kd(int k, int e) const {
@@ -2339,7 +2341,10 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         for (int i = 0; i < n; i++) x0[i] = K.Xp[i];
 #pragma unroll
         for (int i = 0; i < m; i++) u0[i] = K.Up[i];
-        Dyn<MODEL>::A(K.P.mp, x0, u0, Ad);
+        if constexpr (BLK::C::LC_LDS) {
+            const double c2[2] = {K.lcl[0], K.lcl[1]};
+            Dyn<MODEL>::A_cached(c2, Ad);
+        } else Dyn<MODEL>::A(K.P.mp, x0, u0, Ad);
 #pragma unroll
         for (int i = 0; i < n; i++) {
             double s = gxs[i] + K.nun[n + i];
@@ -2392,7 +2397,10 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
             for (int i = 0; i < n; i++) xpk[i] = K.Xp[k * n + i];
 #pragma unroll
             for (int i = 0; i < m; i++) upk[i] = K.Up[k * m + i];
-            Dyn<MODEL>::A(K.P.mp, xpk, upk, Ad);
+            if constexpr (BLK::C::LC_LDS) {
+                const double c2[2] = {K.lcl[2 * k], K.lcl[2 * k + 1]};
+                Dyn<MODEL>::A_cached(c2, Ad);
+            } else Dyn<MODEL>::A(K.P.mp, xpk, upk, Ad);
             Dyn<MODEL>::B(K.P.mp, Bd);
         }
         if (k >= 1) {
@@ -2634,6 +2642,17 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     K.sync();
     pf.tick(PF_INIT);
 
+    constexpr bool LINC = BLK::C::LC_LDS;
+    if constexpr (LINC) {   // (the linearisation point is fixed for the solve: its sin / cos once, two numbers per knot in LDS)
+        if (act) {
+            double xpk[n], c2[2];
+#pragma unroll
+            for (int i = 0; i < n; i++) xpk[i] = K.Xp[k * n + i];
+            Dyn<MODEL>::lin_cache(K.P.mp, xpk, c2);
+            K.lcl[2 * k] = c2[0]; K.lcl[2 * k + 1] = c2[1];
+        }
+        K.sync();
+    }
     int status = GUSTO_SOLVER_FAILED, it = 0;
     double res_p = 0, res_d = 0, mu = 0, alpha_prev = 0.0;
     for (it = 0;; it++) {
@@ -2646,8 +2665,14 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             for (int i = 0; i < n; i++) xpk[i] = K.Xp[k * n + i];
 #pragma unroll
             for (int i = 0; i < m; i++) upk[i] = K.Up[k * m + i];
+            if constexpr (LINC) {
+                const double c2[2] = {K.lcl[2 * k], K.lcl[2 * k + 1]};
+                Dyn<MODEL>::f_cached(K.P.mp, c2, upk, fp);
+                Dyn<MODEL>::A_cached(c2, Ad);
+            } else {
             Dyn<MODEL>::f(K.P.mp, xpk, upk, fp);
             Dyn<MODEL>::A(K.P.mp, xpk, upk, Ad);
+            }
             Dyn<MODEL>::B(K.P.mp, Bd);
 #pragma unroll
             for (int i = 0; i < n; i++) {
