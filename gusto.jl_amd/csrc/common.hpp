@@ -23,6 +23,9 @@ GD bool row_is_hard(int kind) { return kind == ROW_HARD || kind == ROW_HARD_EQ; 
 constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5, RS_DS = 6, RS_KA = 7, RS_KB = 8,
               RS_NVAR = 9;
 
+#ifndef GUSTO_PP_LDS
+#define GUSTO_PP_LDS 0   // (measured: 146 vs 141.5 ms per dubins batch with the records in LDS)
+#endif
 #ifndef GUSTO_LC_LDS
 #define GUSTO_LC_LDS 1
 #endif
@@ -251,6 +254,10 @@ template <int MODEL, bool ONE> struct LdsC {
     // it there, the factor sweep reads its stage operands in place (no prefetch, no staging buffer) and the stage-parallel
     // phases read M and Gam of their knot from LDS instead of walking a global record
     static constexpr bool PG_LDS = ONE && !T::LTI && n <= 4 && GUSTO_PG_LDS;
+    // ... and the packed P | Pi record of every knot (upper triangle of P, then Pi: 15 doubles, one more as the dummy slot
+    // of the unconditional stores; record -1 exists), which the factor sweep writes and the corrector's costates read
+    static constexpr bool PP_LDS = KD_LDS && !T::PG2 && GUSTO_PP_LDS;
+    static constexpr int PPS = (n * (n + 1) / 2 + n * n + 2) & ~1;
     // ... and two numbers per knot from which f and A of the linearisation point follow without a sin / cos (Dyn::lin_cache):
     // the phases of an interior point iteration asked for them six times, ~140 instructions apiece in double precision
     static constexpr bool LC_LDS = ONE && MODEL == GUSTO_DUBINS_CAR && GUSTO_LC_LDS;
@@ -271,6 +278,7 @@ struct LdsLayout {
     int kd;     // offset of K | D | S^-1 per knot in LDS (LdsC::KD_LDS), -1 if in the global workspace
     int pg;     // offset of [Phi Gam] per knot in LDS (LdsC::PG_LDS), -1 if in the global workspace
     int lc;     // offset of the linearisation cache (LdsC::LC_LDS: 2 doubles per knot), -1 if none
+    int pp;     // offset of the packed P | Pi records (LdsC::PP_LDS: N + 1 records of PPS doubles), -1 if in the global workspace
 };
 template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     using C1 = LdsC<MODEL, true>;
@@ -286,6 +294,8 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
     if (C1::PG_LDS && one) { L.pg = L.total; L.total += N * C1::n * C1::NZ; }
     L.lc = -1;
     if (C1::LC_LDS && one) { L.lc = L.total; L.total += 2 * N; }
+    L.pp = -1;
+    if (C1::PP_LDS && one) { L.pp = L.total; L.total += (N + 1) * C1::PPS; }
     return L;
 }
 

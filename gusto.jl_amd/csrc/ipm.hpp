@@ -66,6 +66,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     LPtr<double> kdl;   // K | D | S^-1 (upper triangle) per knot in LDS, stride C::KDS (LdsC::KD_LDS); before factor stage k the slot of knot k holds QQ_k
     LPtr<double> pgl;   // [Phi Gam] per knot in LDS (LdsC::PG_LDS)
     LPtr<double> lcl;   // linearisation cache per knot in LDS (LdsC::LC_LDS)
+    LPtr<double> ppl;   // packed P | Pi records in LDS (LdsC::PP_LDS)
     GPtr<uint64_t> obs_mask;
     GPtr<const double> x_init, goal_lo, goal_hi;
     unsigned goalmask;  // bit i: coordinate i of x_N has a point goal (goal_lo == goal_hi)
@@ -107,6 +108,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         if constexpr (C::KD_LDS) kdl = lds + P.ll.kd;
         if constexpr (C::PG_LDS) pgl = lds + P.ll.pg;
         if constexpr (C::LC_LDS) lcl = lds + P.ll.lc;
+        if constexpr (C::PP_LDS) ppl = lds + P.ll.pp;
     }
     // entry e of the K | D block of knot k (e = i n + j of K, m n + i n + j of D) and S_k^-1[i][l]
     GD double kd(int k, int e) const {
@@ -167,6 +169,12 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         if constexpr (C::PG_LDS) return pgl + k * n * NZ;
         else return PG + (size_t)(T::LTI ? 0 : k) * n * NZ;
     }
+    // the P | Pi record after knot k (k >= -1) and its dummy slot
+    GD auto pprec(int k) const {
+        if constexpr (C::PP_LDS) return ppl + (k + 1) * C::PPS;
+        else return Paft + (size_t)k * R::SNN;
+    }
+    static constexpr int PP_DUMMY = C::PP_LDS ? C::PPS - 1 : R::SNN - 1;
     GD bool is_goal(int i) const { return (goalmask >> i) & 1u; }
 };
 
@@ -652,7 +660,8 @@ template <int MODEL> struct SweepView {
     std::conditional_t<C::PHICL_LDS, LPtr<double>, GPtr<double>> Phicl;
     LPtr<double> kdl;   // K | D | S^-1 per knot in LDS (LdsC::KD_LDS; the double integrator's sweeps rebuild Phicl from it)
     LPtr<double> pgl;   // [Phi Gam] per knot in LDS (LdsC::PG_LDS)
-    int pg_off;
+    LPtr<double> ppl;   // packed P | Pi records in LDS (LdsC::PP_LDS)
+    int pg_off, pp_off;
     const gusto_model_params* mpp;
     struct PW { const gusto_model_params& mp; } ;
     int tid, N;
@@ -663,6 +672,12 @@ template <int MODEL> struct SweepView {
         if constexpr (C::PG_LDS) return pgl + k * n * NZ;
         else return PG + (size_t)(T::LTI ? 0 : k) * n * NZ;
     }
+    // the P | Pi record after knot k (k >= -1) and its dummy slot
+    GD auto pprec(int k) const {
+        if constexpr (C::PP_LDS) return ppl + (k + 1) * C::PPS;
+        else return Paft + (size_t)k * R::SNN;
+    }
+    static constexpr int PP_DUMMY = C::PP_LDS ? C::PPS - 1 : R::SNN - 1;
     GD bool is_goal(int i) const { return (goalmask >> i) & 1u; }
     int phicl_off, kd_off;   // LdsLayout::phicl, ::kd
     GD void rebind_lds(double* l) {   // see Blk::rebind_lds
@@ -676,13 +691,14 @@ template <int MODEL> struct SweepView {
         if constexpr (C::PHICL_LDS) Phicl = lds + phicl_off;
         if constexpr (C::KD_LDS) kdl = lds + kd_off;
         if constexpr (C::PG_LDS) pgl = lds + pg_off;
+        if constexpr (C::PP_LDS) ppl = lds + pp_off;
     }
     GD void rebind_global() {
         PG = al16((double*)PG); QQ = al16((double*)QQ); Paft = al16((double*)Paft); Piaft = al16((double*)Piaft); KD = al16((double*)KD);
     }
     template <class BLK> GD static SweepView make(const BLK& K) {
         SweepView v;
-        v.N = K.N; v.phicl_off = K.P.ll.phicl; v.kd_off = K.P.ll.kd; v.pg_off = K.P.ll.pg;
+        v.N = K.N; v.phicl_off = K.P.ll.phicl; v.kd_off = K.P.ll.kd; v.pg_off = K.P.ll.pg; v.pp_off = K.P.ll.pp;
         if constexpr (!C::PHICL_LDS) v.Phicl = K.Phicl;   // (LDS copy of the small models: set by rebind_lds)
         v.rebind_lds(K.lds);
         v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.KD = K.KD;
@@ -766,7 +782,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
             K.Paft[(size_t)(N - 1) * R::SNN + e] = 0.0;   // value function after the last knot
             K.Piaft[(size_t)(N - 1) * R::SNN + e] = 0.0;
         }
-        if constexpr (C::KD_LDS) { if (e < R::SNN) K.Paft[(size_t)(N - 1) * R::SNN + e] = 0.0; }   // (packed P | Pi record)
+        if constexpr (C::KD_LDS) { if (e < (C::PP_LDS ? C::PPS : R::SNN)) K.pprec(N - 1)[e] = 0.0; }   // (packed P | Pi record)
     }
     K.sync();
     for (int k = N - 1; k >= 0; k--) {
@@ -1076,10 +1092,10 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
                     // fit the 64 doubles; the step phase walks one record instead of two
                     constexpr int NH = n * (n + 1) / 2;
                     static_assert(NH + NN < R::SNN, "P | Pi record");
-                    const int ep = (on && i <= j) ? sidx(i, j, n) : R::SNN - 1;
-                    const int eq = on ? NH + e2 : R::SNN - 1;
-                    K.Paft[(size_t)(k - 1) * R::SNN + ep] = pn;
-                    K.Paft[(size_t)(k - 1) * R::SNN + eq] = pin;
+                    const int ep = (on && i <= j) ? sidx(i, j, n) : K.PP_DUMMY;
+                    const int eq = on ? NH + e2 : K.PP_DUMMY;
+                    K.pprec(k - 1)[ep] = pn;
+                    K.pprec(k - 1)[eq] = pin;
                 } else {
                     const int eo = on ? e2 : NN;
                     K.Paft[(size_t)(k - 1) * R::SNN + eo] = pn;
@@ -2294,8 +2310,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
 #pragma unroll
                 for (int l = 0; l < n; l++)
                     if constexpr (BLK::C::KD_LDS)   // (packed record: upper triangle of P, then Pi; factor_sweep_1w)
-                        s += K.Paft[(size_t)k * R::SNN + sidx(i, l, n)] * K.dY[k * n + l] +
-                             K.Paft[(size_t)k * R::SNN + n * (n + 1) / 2 + i * n + l] * mugn[l];
+                        s += K.pprec(k)[sidx(i, l, n)] * K.dY[k * n + l] + K.pprec(k)[n * (n + 1) / 2 + i * n + l] * mugn[l];
                     else
                     s += K.Paft[(size_t)k * R::SNN + i * n + l] * K.dY[k * n + l] +
                          K.Piaft[(size_t)k * R::SNN + i * n + l] * mugn[l];
