@@ -23,6 +23,9 @@ GD bool row_is_hard(int kind) { return kind == ROW_HARD || kind == ROW_HARD_EQ; 
 constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5, RS_DS = 6, RS_KA = 7, RS_KB = 8,
               RS_NVAR = 9;
 
+#ifndef GUSTO_DUBINS_WAVES
+#define GUSTO_DUBINS_WAVES 2
+#endif
 #ifndef GUSTO_PP_LDS
 #define GUSTO_PP_LDS 0   // (measured: 146 vs 141.5 ms per dubins batch with the records in LDS)
 #endif
@@ -76,7 +79,7 @@ template <> struct MT<GUSTO_FREEFLYER_SE2> {
 template <> struct MT<GUSTO_DUBINS_CAR> {
     static constexpr int NDEF = 0;   // (no defect controls: the dynamics are hard rows)
     static constexpr int n = 3, m = 1, WS = 2, NFIX = 6, NHU = 2;
-    static constexpr int WAVES_PER_EU = 2;   // register budget of the one-wave kernel: 512 / this
+    static constexpr int WAVES_PER_EU = GUSTO_DUBINS_WAVES;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool MFMA = false;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
     static constexpr int SCHED_PROBE = 1;   // (short problems: 2 slices cost more than they order -- 316 vs 211 ms at B = 65 536)
