@@ -1954,10 +1954,12 @@ template <int MODEL> GD void costate_pass_1w(SweepView<MODEL> K, const double* m
     double pr[RING][n], pi[RING][n];
     auto fetch = [&](int k0, double* a, double* b) {
         const int k = (k0 + g + 1 < N) ? k0 + g : N - 2;   // (clamped: no load under a branch)
-        const double* pa = K.Paft + (size_t)k * R::SNN + i;   // (records stored transposed by factor_sweep_mfma: entry (i, l) at l n + i)
-        const double* pb = K.Piaft + (size_t)k * R::SNN + i;
+        // (records stored transposed by factor_sweep_mfma: entry (i, l) at l n + i; row-major by the VALU sweep of a
+        // -DGUSTO_USE_MFMA=false build)
+        const double* pa = K.Paft + (size_t)k * R::SNN + (T::MFMA ? i : i * n);
+        const double* pb = K.Piaft + (size_t)k * R::SNN + (T::MFMA ? i : i * n);
 #pragma unroll
-        for (int l = 0; l < n; l++) { a[l] = pa[l * n]; b[l] = pb[l * n]; }
+        for (int l = 0; l < n; l++) { a[l] = pa[T::MFMA ? l * n : l]; b[l] = pb[T::MFMA ? l * n : l]; }
     };
 #pragma unroll
     for (int d = 0; d < RING - 1; d++) fetch(d * C, pr[d], pi[d]);
