@@ -297,7 +297,8 @@ def main():
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["name"] + (" per GPU" if args.scaling == "weak" else " split over the ranks"),
+            "config": {"workload": (cfg["name"] if not args.batch else cfg["name"].replace(f"batch={cfg['B']}", f"batch={args.batch} (--batch)")) +
+                                   (" per GPU" if args.scaling == "weak" else " split over the ranks"),
                        "baseline_config": args.config, "batch_total": problems, "batch_rank0": B, "N": N_KNOTS,
                        "max_iter": MAX_ITER, "sharding": "independent problems per rank; final gather of X,U to rank 0 "
                                                          "over RCCL inside every step (N > 1)",
