@@ -158,7 +158,7 @@ int gusto_destroy(gusto_handle h) {
                     h->d_prof, h->d_subD, h->d_subW, h->d_subT, h->d_subX, h->d_subU, h->d_subObj, h->d_subSt, h->d_subIt, h->d_box, h->d_sph,
                     h->d_to_mu, h->d_to_xtol, h->d_to_ftol, h->d_to_ctol};
     for (void* p : ptrs) if (p) hipFree(p);
-    for (void* p : {(void*)h->d_shX, (void*)h->d_shU, (void*)h->d_shP, (void*)h->d_shP0, (void*)h->d_shRes, (void*)h->d_shSt, (void*)h->d_shIt, (void*)h->d_shXt, (void*)h->d_shUt}) if (p) hipFree(p);
+    for (void* p : {(void*)h->d_shX, (void*)h->d_shU, (void*)h->d_shP, (void*)h->d_shP0, (void*)h->d_shRes, (void*)h->d_shSt, (void*)h->d_shIt, (void*)h->d_shList, (void*)h->d_shXt, (void*)h->d_shUt}) if (p) hipFree(p);
     if (h->d_order) hipFree(h->d_order);
     if (h->d_queue) hipFree(h->d_queue);
     if (h->d_sched_ord) hipFree(h->d_sched_ord);

@@ -47,7 +47,7 @@ struct gusto_handle_s {
     // indirect shooting (shoot.hip): trajectories, converged costates, seeds, residuals, status, Newton iterations
     double *d_shX = nullptr, *d_shU = nullptr, *d_shP = nullptr, *d_shP0 = nullptr, *d_shRes = nullptr;
     double *d_shXt = nullptr, *d_shUt = nullptr;   // knot-major staging of the shooting trajectories ([N][n][B])
-    int *d_shSt = nullptr, *d_shIt = nullptr;
+    int *d_shSt = nullptr, *d_shIt = nullptr, *d_shList = nullptr;
     std::string err;
 };
 

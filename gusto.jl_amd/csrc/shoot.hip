@@ -11,6 +11,9 @@
 // on |F|_inf; the Newton step by Cramer's rule (n = 3) or rank-revealing Gaussian elimination with COMPLETE pivoting
 // (n = 13: dF/dp0 is rank deficient by one, newton_step below).  The two models above are the ones that have a shooting
 // ODE in the reference.
+// Two passes (gusto_shoot): a lane per problem for the first Newton iterations, then the problems still running -- the ones
+// that do not converge and would hold their wave for a hundred iterations -- with a group of lanes each, one lane per
+// Jacobian column / line-search candidate (shoot_group_kernel).
 // Stores: a lane owns a problem, so writing its knots straight into X[b][k][i] would touch one cache line per lane per
 // store (stride N n between lanes).  The recovered trajectory is written knot-major, Xt[k][i][b] -- consecutive lanes,
 // consecutive addresses -- and a tiled transpose (shoot_transpose_kernel) produces the [b][k][i] layout of the C ABI.
@@ -28,6 +31,8 @@ struct ShootParams {
     const double *x_init, *goal_lo, *goal_hi, *tf, *p0;   // p0 [B][n]
     double *X, *U, *p_out, *resid;                        // knot-major staging of the trajectories: X [N][n][B], U [N][m][B]
     int *status, *iters;
+    int cap;            // Newton iterations of the lane-per-problem pass; a problem still running then goes to `list`
+    int *list, *count;  // problems handed to the group pass (shoot_group_kernel), their number
 };
 
 template <int MODEL> struct ShootModel;
@@ -189,10 +194,12 @@ template <int MODEL> __global__ void __launch_bounds__(64) shoot_kernel(const Sh
 #pragma unroll
     for (int i = 0; i < n; i++) { F[i] = xg[i] - xT[i]; nf = (F[i] != F[i] || nf != nf) ? NAN : fmax(nf, fabs(F[i])); }   // (fmax drops a NaN)
     int it = 0, ok = 0;
+    bool later = false;
     for (;; it++) {
         if (!(nf == nf) || !isfinite(nf)) break;
         if (nf <= S.ftol) { ok = 1; break; }
         if (it >= S.max_newton) break;
+        if (it >= S.cap) { later = true; break; }
         double J[n * n], pj[n];
         for (int j = 0; j < n; j++) {
             const double h = 1e-6 * fmax(1.0, fabs(pv[j]));
@@ -218,7 +225,103 @@ template <int MODEL> __global__ void __launch_bounds__(64) shoot_kernel(const Sh
     }
     S.status[b] = ok; S.iters[b] = it; S.resid[b] = nf;
     for (int i = 0; i < n; i++) S.p_out[(size_t)b * n + i] = pv[i];
+    if (later) S.list[atomicAdd(S.count, 1)] = b;   // (its state: p_out, iters)
     if (ok) integrate<MODEL>(S, x0, pv, tf, xT, S.X, S.U, b);
+}
+
+// The problems the lane-per-problem pass did not finish within S.cap Newton iterations -- for dubins_car the ones that do
+// not converge at all and run their 100 iterations, each a Jacobian of n integrations and a halving line search of up to
+// 14 -- continue here with G lanes each: a lane of the group integrates ONE perturbed start (a column of the Jacobian) or
+// ONE candidate of the line search, so an iteration is two to three integrations long instead of up to n + 14.  In the
+// first pass such a problem held its whole wave for ~1 700 integrations (measured: 370 ms for B = 65 536, 10 % of the lanes
+// active); here the few thousand of them fill the GPU by themselves.  The same arithmetic per integration, the same
+// acceptance rule (the first candidate of the halving sequence that decreases |F|): the same results.
+template <int MODEL, int G> __global__ void __launch_bounds__(64) shoot_group_kernel(const ShootParams S, int count) {
+    using M = ShootModel<MODEL>;
+    constexpr int n = M::n, PG = 64 / G, NC = 14;   // candidates a = 2^-c > 1e-4: c = 0 .. 13
+    static_assert(G >= n + 1 && 64 % G == 0, "a lane per Jacobian column");
+    __shared__ double ex[64 * (2 * n + 1)];
+    const int lane = threadIdx.x, g = lane / G, r = lane % G;
+    const int idx = blockIdx.x * PG + g;
+    const bool have = idx < count;
+    const int b = S.list[have ? idx : 0];
+    double x0[n], pv[n], xg[n], F[n], xT[n], nf = 0.0;
+    const double tf = S.tf[b];
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        x0[i] = S.x_init[(size_t)b * n + i];
+        pv[i] = S.p_out[(size_t)b * n + i];
+        const double lo = S.goal_lo[(size_t)b * n + i], hi = S.goal_hi[(size_t)b * n + i];
+        xg[i] = (isfinite(lo) && isfinite(hi)) ? 0.5 * (lo + hi) : 0.0;
+    }
+    integrate<MODEL>(S, x0, pv, tf, xT, nullptr, nullptr);   // (F at the saved iterate: the values the first pass had)
+#pragma unroll
+    for (int i = 0; i < n; i++) { F[i] = xg[i] - xT[i]; nf = (F[i] != F[i] || nf != nf) ? NAN : fmax(nf, fabs(F[i])); }
+    int it = S.iters[b], ok = 0;
+    bool done = !have;
+    for (;;) {   // (every lane of the wave runs every trip: the barriers below are wave-wide; a finished group idles)
+        if (!done) {
+            if (!(nf == nf) || !isfinite(nf)) done = true;
+            else if (nf <= S.ftol) { ok = 1; done = true; }
+            else if (it >= S.max_newton) done = true;
+        }
+        if (!__any(!done)) break;
+        // Jacobian: lane r = 1 .. n integrates the start perturbed in component r - 1
+        {
+            const int j = (r >= 1 && r <= n) ? r - 1 : 0;
+            double pj[n];
+            double h = 0;
+#pragma unroll
+            for (int i = 0; i < n; i++) { const double hh = 1e-6 * fmax(1.0, fabs(pv[i])); pj[i] = (i == j) ? pv[i] + hh : pv[i]; h = (i == j) ? hh : h; }
+            if (!done && r >= 1 && r <= n) integrate<MODEL>(S, x0, pj, tf, xT, nullptr, nullptr);
+#pragma unroll
+            for (int i = 0; i < n; i++) ex[lane * (2 * n + 1) + i] = ((xg[i] - xT[i]) - F[i]) / h;
+        }
+        __syncthreads();
+        double J[n * n], dp[n];
+#pragma unroll
+        for (int j = 0; j < n; j++)
+#pragma unroll
+            for (int i = 0; i < n; i++) J[i * n + j] = ex[(g * G + 1 + j) * (2 * n + 1) + i];
+        __syncthreads();
+        bool stepok = newton_step<n>(J, F, dp);
+        if (!done && !stepok) done = true;
+        // line search: lane r of round q takes candidate c = q G + r of a = 1, 1/2, 1/4, ...; the first that decreases |F| wins
+        bool dec = false;
+        for (int q = 0; q * G < NC; q++) {
+            const int c = q * G + r;
+            double a = 1.0;
+            for (int e = 0; e < c; e++) a *= 0.5;
+            double pn[n], Fn[n], nn = 0.0;
+#pragma unroll
+            for (int i = 0; i < n; i++) pn[i] = pv[i] + a * dp[i];
+            const bool mine = !done && !dec && c < NC;
+            if (mine) integrate<MODEL>(S, x0, pn, tf, xT, nullptr, nullptr);
+#pragma unroll
+            for (int i = 0; i < n; i++) { Fn[i] = xg[i] - xT[i]; nn = (Fn[i] != Fn[i] || nn != nn) ? NAN : fmax(nn, fabs(Fn[i])); }
+            const unsigned long long good = __ballot(mine && nn < nf);
+            const unsigned grp = (unsigned)((good >> (g * G)) & ((1ull << G) - 1ull));
+#pragma unroll
+            for (int i = 0; i < n; i++) { ex[lane * (2 * n + 1) + i] = pn[i]; ex[lane * (2 * n + 1) + n + i] = Fn[i]; }
+            ex[lane * (2 * n + 1) + 2 * n] = nn;
+            __syncthreads();
+            if (!done && !dec && grp != 0) {
+                const int w = g * G + (__ffs(grp) - 1);
+#pragma unroll
+                for (int i = 0; i < n; i++) { pv[i] = ex[w * (2 * n + 1) + i]; F[i] = ex[w * (2 * n + 1) + n + i]; }
+                nf = ex[w * (2 * n + 1) + 2 * n];
+                dec = true;
+            }
+            __syncthreads();
+        }
+        if (!done && !dec) done = true;
+        else if (!done) it++;
+    }
+    if (have && r == 0) {
+        S.status[b] = ok; S.iters[b] = it; S.resid[b] = nf;
+        for (int i = 0; i < n; i++) S.p_out[(size_t)b * n + i] = pv[i];
+        if (ok) integrate<MODEL>(S, x0, pv, tf, xT, S.X, S.U, b);
+    }
 }
 
 // out[b][r] = in[r][b] for the problems whose shooting converged (R = N n or N m rows, B columns): 32 x 32 tiles through
@@ -266,6 +369,7 @@ int gusto_shoot(gusto_handle h, const double* p0, const gusto_shoot_opts* opts) 
         HIPCHK(h, dalloc(&h->d_shX, B * N * n)); HIPCHK(h, dalloc(&h->d_shU, B * N * m)); HIPCHK(h, dalloc(&h->d_shP, B * n));
         HIPCHK(h, dalloc(&h->d_shXt, B * N * n)); HIPCHK(h, dalloc(&h->d_shUt, B * N * m));
         HIPCHK(h, dalloc(&h->d_shP0, B * n)); HIPCHK(h, dalloc(&h->d_shRes, B)); HIPCHK(h, dalloc(&h->d_shSt, B)); HIPCHK(h, dalloc(&h->d_shIt, B));
+        HIPCHK(h, dalloc(&h->d_shList, B + 1));   // [B] problems for the group pass, [1] their number
     }
     if (p0) {
         HIPCHK(h, hipMemcpyAsync(h->d_shP0, p0, sizeof(double) * h->B * n, hipMemcpyHostToDevice, h->stream));
@@ -279,9 +383,26 @@ int gusto_shoot(gusto_handle h, const double* p0, const gusto_shoot_opts* opts) 
     for (int i = 0; i < 3; i++) S.J[i] = h->mp.Jdiag[i];
     S.x_init = h->d_xinit; S.goal_lo = h->d_glo; S.goal_hi = h->d_ghi; S.tf = h->d_tf; S.p0 = h->d_shP0;
     S.X = h->d_shXt; S.U = h->d_shUt; S.p_out = h->d_shP; S.resid = h->d_shRes; S.status = h->d_shSt; S.iters = h->d_shIt;
+    // two passes: a lane per problem for the first SHOOT_CAP Newton iterations (the problems that converge need 0-4), then
+    // the stragglers with a group of lanes each (shoot_group_kernel)
+    constexpr int SHOOT_CAP = 8;
+    const int cap_env = getenv("GUSTO_SHOOT_CAP") ? atoi(getenv("GUSTO_SHOOT_CAP")) : SHOOT_CAP;   // (development knob)
+    S.cap = (getenv("GUSTO_SHOOT_ONE_PASS") || o.max_newton <= cap_env) ? o.max_newton : cap_env;
+    S.list = h->d_shList; S.count = h->d_shList + h->batch_cap;
+    HIPCHK(h, hipMemsetAsync(S.count, 0, sizeof(int), h->stream));
     if (h->model == GUSTO_DUBINS_CAR) hipLaunchKernelGGL(shoot_kernel<GUSTO_DUBINS_CAR>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, S);
     else hipLaunchKernelGGL(shoot_kernel<GUSTO_ASTROBEE_SE3_MANIFOLD>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, S);
     HIPCHK(h, hipGetLastError());
+    int n_later = 0;
+    HIPCHK(h, hipMemcpyAsync(&n_later, S.count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n_later > 0) {
+        // (16 lanes per problem: the 14 candidates of a line search in one round; measured 83 ms against 104 with 8 lanes and
+        // 112 with 4 for dubins_car B = 65 536, 368 ms with the lane-per-problem pass alone)
+        if (h->model == GUSTO_DUBINS_CAR) hipLaunchKernelGGL((shoot_group_kernel<GUSTO_DUBINS_CAR, 16>), dim3((n_later + 3) / 4), dim3(64), 0, h->stream, S, n_later);
+        else hipLaunchKernelGGL((shoot_group_kernel<GUSTO_ASTROBEE_SE3_MANIFOLD, 16>), dim3((n_later + 3) / 4), dim3(64), 0, h->stream, S, n_later);
+        HIPCHK(h, hipGetLastError());
+    }
     {   // knot-major staging -> X[b][k][i], U[b][k][i]
         const int RX = (int)(N * n), RU = (int)(N * m);
         hipLaunchKernelGGL(shoot_transpose_kernel, dim3((h->B + 31) / 32, (RX + 31) / 32), dim3(256), 0, h->stream, h->d_shXt, h->d_shX, h->d_shSt, RX, h->B);

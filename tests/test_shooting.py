@@ -142,6 +142,26 @@ def test_gpu_shooting_matches_the_oracle():
 
 
 @pytest.mark.gpu
+def test_group_pass_of_the_stragglers_changes_nothing(monkeypatch):
+    """gusto_shoot runs the problems that are still iterating after 8 Newton steps with 16 lanes each (a lane per Jacobian
+    column / line-search candidate).  Same integrations, same acceptance rule: every output equals, bit for bit, what the
+    lane-per-problem pass alone produces -- for the problems that converge late and for the ones that never do."""
+    B = 4096
+    s = g.BatchSolver(g.DUBINS_CAR, 30, B, hist_cap=40)
+    s.set_problems(*P.dubins_batch(B))
+    s.solve(3)                                       # a few SCP iterations: a mediocre seed, many long Newton runs
+    two = s.shoot()
+    monkeypatch.setenv("GUSTO_SHOOT_ONE_PASS", "1")
+    one = s.shoot()
+    late = two["newton_iters"] > 8
+    assert late.sum() > B // 50 and (two["status"][late] == 1).any() and (two["status"][late] == 0).any()
+    for key in ("status", "newton_iters", "resid", "p0"):
+        assert np.array_equal(two[key], one[key], equal_nan=(key in ("resid", "p0"))), key
+    ok = two["status"] == 1
+    assert np.array_equal(two["X"][ok], one["X"][ok]) and np.array_equal(two["U"][ok], one["U"][ok])
+
+
+@pytest.mark.gpu
 def test_gpu_manifold_shooting_matches_the_oracle():
     B, N = 48, 50
     x0, glo, ghi, tf = P.astrobee_manifold_batch(B)
