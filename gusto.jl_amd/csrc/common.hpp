@@ -344,7 +344,8 @@ constexpr int ST_ITER = 0, ST_CONV = 1, ST_SUCC = 2, ST_STOP = 3, ST_IPM = 4, ST
 constexpr int SCHED_LEVELS = 16, SQ_STRIDE = 32;
 constexpr int SQ_HEAD_A = 0, SQ_PROBING = SQ_STRIDE /* problems that may still be pushed */, SQ_TAIL = 2 * SQ_STRIDE /* [level] */,
               SQ_HEAD = (2 + SCHED_LEVELS) * SQ_STRIDE /* [level] */, SQ_ERR = (2 + 2 * SCHED_LEVELS) * SQ_STRIDE /* scheduler gave up */,
-              SQ_WORDS = (3 + 2 * SCHED_LEVELS) * SQ_STRIDE;
+              SQ_HI = (3 + 2 * SCHED_LEVELS) * SQ_STRIDE /* entries waiting in the lists of level >= 1 (a hint) */,
+              SQ_WORDS = (4 + 2 * SCHED_LEVELS) * SQ_STRIDE;
 constexpr int SD_TOGGLE = 0, SD_DUAL = 2, SD_ND = 2 + GUSTO_MAXN;
 
 // ---- optional phase timers (compile with -DGUSTO_PROFILE) ---------------------------------------------

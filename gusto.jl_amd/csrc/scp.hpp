@@ -252,6 +252,9 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
 // (trajectory, histories, st_i), so results are bit-identical to an unsliced run.
 //   hand-off of a problem between workgroups (possibly on different XCDs): the producer writes the state, releases at
 //   agent scope, then publishes the list entry; the consumer claims an index, spins until the entry is there, acquires.
+#ifndef GUSTO_SCHED_PREEMPT
+#define GUSTO_SCHED_PREEMPT 1
+#endif
 constexpr int SCHED_SPIN_LIMIT = 1 << 20;   // (seconds of sleeping polls: a scheduler bug must not hang the GPU)
 // wave-uniform primitives: every lane of the wave executes them, the result is the same scalar in every lane
 GD int uload(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
@@ -273,14 +276,9 @@ GD int ucas(int* p, int expected, int desired) {   // returns the value found (=
 // structurizer when the other lanes stay in the outer loop (the wave never reconverges; found the hard way).
 GD int sched_pop(const KParams& P, bool& cont) {
     int* Q = P.queue;
-    for (int spin = 0;; spin++) {
-        // BEFORE the scan, with acquire: a push is published (tail increment, release) before SQ_PROBING drops
-        const int probing_seen = uload_acq(Q + SQ_PROBING);
-        if (uload(Q + SQ_HEAD_A) < P.B) {
-            const int q = uadd(Q + SQ_HEAD_A, 1);
-            if (q < P.B) { cont = false; return P.order ? uload(P.order + q) : q; }
-        }
-        for (int L = SCHED_LEVELS - 1; L >= 0; L--) {
+    // claims the head of the highest non-empty list of levels hi .. lo: its entry, -2 if they are empty, -1 if an entry is lost
+    auto take = [&](int hi, int lo) -> int {
+        for (int L = hi; L >= lo; L--) {
             int h = uload(Q + SQ_HEAD + L * SQ_STRIDE);
             while (h < uload(Q + SQ_TAIL + L * SQ_STRIDE)) {
                 const int found = ucas(Q + SQ_HEAD + L * SQ_STRIDE, h, h + 1);
@@ -292,11 +290,31 @@ GD int sched_pop(const KParams& P, bool& cont) {
                         if ((threadIdx.x & 63) == 0) atomicExch(Q + SQ_ERR, 1);
                         return -1;
                     }
-                    cont = true;
+                    if (L >= 1) uadd(Q + SQ_HI, -1);
                     return e;
                 }
                 h = found;
             }
+        }
+        return -2;
+    };
+    for (int spin = 0;; spin++) {
+        // BEFORE the scan, with acquire: a push is published (tail increment, release) before SQ_PROBING drops
+        const int probing_seen = uload_acq(Q + SQ_PROBING);
+        // A problem whose penalty weight has been raised (level >= 1: the long ones) goes ahead of the fresh problems.
+        // SQ_HI is only a hint that such an entry may be waiting (one load instead of a scan of every list per fresh
+        // problem); whatever it misses is found by the full scan below -- at the latest by the workgroup that pushed it.
+        if (GUSTO_SCHED_PREEMPT && uload(Q + SQ_HI) > 0) {
+            const int e = take(SCHED_LEVELS - 1, 1);
+            if (e != -2) { cont = true; return e; }
+        }
+        if (uload(Q + SQ_HEAD_A) < P.B) {
+            const int q = uadd(Q + SQ_HEAD_A, 1);
+            if (q < P.B) { cont = false; return P.order ? uload(P.order + q) : q; }
+        }
+        {
+            const int e = take(SCHED_LEVELS - 1, 0);
+            if (e != -2) { cont = true; return e; }
         }
         // Nothing to take.  More can only come from problems still in their probing slices; once there are none, this
         // workgroup retires and frees its slot -- the tail of a batch then overlaps the head of the next one enqueued on
@@ -358,6 +376,7 @@ scp_kernel(const KParams P) {
             if (lvl >= 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // state first ...
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lvl >= 1) atomicAdd(P.queue + SQ_HI, 1);
                 const int idx = atomicAdd(P.queue + SQ_TAIL + lvl * SQ_STRIDE, 1);
                 __hip_atomic_store(P.lists + (size_t)lvl * P.list_cap + idx, ((visits + 1) << 24) | b, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);                                                        // ... then the entry
