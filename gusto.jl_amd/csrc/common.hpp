@@ -99,7 +99,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3> {
     static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool MFMA = GUSTO_USE_MFMA;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
-    static constexpr int SCHED_PROBE = 2;   // default number of one-trip probing slices of the longest-first scheduler
+    static constexpr int SCHED_PROBE = 1;   // (measured with raised-penalty problems ahead of fresh ones: 123.0 / 127.1 / 132.7 ms for 1 / 2 / 3 slices)
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
@@ -121,7 +121,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true ;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool MFMA = GUSTO_USE_MFMA;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
-    static constexpr int SCHED_PROBE = 2;   // default number of one-trip probing slices of the longest-first scheduler
+    static constexpr int SCHED_PROBE = 1;   // (130.1 / 133.7 / 130.9 ms for 1 / 2 / 3 slices)
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
