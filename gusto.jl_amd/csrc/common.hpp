@@ -60,6 +60,7 @@ template <> struct MT<GUSTO_FREEFLYER_SE2> {
     static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool MFMA = false;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
     static constexpr int SCHED_PROBE = 2;   // default number of one-trip probing slices of the longest-first scheduler
+    static constexpr int SCHED_SLICE = 4;   // then slices of 4 trips for problems of penalty level 0 (34.1 vs 34.65 ms; the 12/13-state models lose with any)
     static constexpr bool LTI = true, HAS_OBS = true;
     // Double integrator (freeflyer_se2.jl:121,178-179: A = [0 I; 0 0], B = [0; diag]): Phi = I + dt A and
     // Gam = 2 (I + dt/2 A) b have at most TWO nonzeros per column of [Phi Gam], at rows pg_r0(c), pg_r1(c)
@@ -82,7 +83,7 @@ template <> struct MT<GUSTO_DUBINS_CAR> {
     static constexpr int WAVES_PER_EU = GUSTO_DUBINS_WAVES;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = false;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool MFMA = false;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
-    static constexpr int SCHED_PROBE = 1;   // (short problems: 2 slices cost more than they order -- 316 vs 211 ms at B = 65 536)
+    static constexpr int SCHED_PROBE = 1; static constexpr int SCHED_SLICE = 0;   // (short problems: 2 slices cost more than they order -- 316 vs 211 ms at B = 65 536)
     static constexpr bool LTI = false, HAS_OBS = false;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
@@ -99,7 +100,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3> {
     static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool MFMA = GUSTO_USE_MFMA;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
-    static constexpr int SCHED_PROBE = 1;   // (measured with raised-penalty problems ahead of fresh ones: 123.0 / 127.1 / 132.7 ms for 1 / 2 / 3 slices)
+    static constexpr int SCHED_PROBE = 1; static constexpr int SCHED_SLICE = 0;   // (measured with raised-penalty problems ahead of fresh ones: 123.0 / 127.1 / 132.7 ms for 1 / 2 / 3 slices)
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
@@ -121,7 +122,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr int WAVES_PER_EU = 1;   // register budget of the one-wave kernel: 512 / this
     static constexpr bool SWEEP_CALL = true ;   // factor sweep as a function call (ipm.hpp:factor_sweep)
     static constexpr bool MFMA = GUSTO_USE_MFMA;   // dense per-knot products of the factor sweep on v_mfma_f64_16x16x4_f64
-    static constexpr int SCHED_PROBE = 1;   // (130.1 / 133.7 / 130.9 ms for 1 / 2 / 3 slices)
+    static constexpr int SCHED_PROBE = 1; static constexpr int SCHED_SLICE = 0;   // (130.1 / 133.7 / 130.9 ms for 1 / 2 / 3 slices)
     static constexpr bool LTI = false, HAS_OBS = true;
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
@@ -146,7 +147,7 @@ template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
 template <> struct MT<GUSTO_TO_FREEFLYER_SE2> {
     using G = MT<GUSTO_FREEFLYER_SE2>;
     static constexpr int NDEF = 6, n = 6, m = 3 + NDEF, WS = 2, NFIX = 3, NHU = 2 + 2 * NDEF;
-    static constexpr int WAVES_PER_EU = 1, SCHED_PROBE = 0;
+    static constexpr int WAVES_PER_EU = 1, SCHED_PROBE = 0, SCHED_SLICE = 0;
     static constexpr bool SWEEP_CALL = false, MFMA = false, LTI = false, HAS_OBS = true, PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
     static constexpr int pg_r1(int) { return 0; }
@@ -159,7 +160,7 @@ template <> struct MT<GUSTO_TO_FREEFLYER_SE2> {
 template <> struct MT<GUSTO_TO_ASTROBEE_SE3> {
     using G = MT<GUSTO_ASTROBEE_SE3>;
     static constexpr int NDEF = 12, n = 12, m = 6 + NDEF, WS = 3, NFIX = 3, NHU = 2 + 2 * NDEF;
-    static constexpr int WAVES_PER_EU = 1, SCHED_PROBE = 0;
+    static constexpr int WAVES_PER_EU = 1, SCHED_PROBE = 0, SCHED_SLICE = 0;
     static constexpr bool SWEEP_CALL = false, MFMA = false, LTI = false, HAS_OBS = true, PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
     static constexpr int pg_r1(int) { return 0; }
@@ -306,10 +307,11 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N) {
 struct KParams {
     int N, B, n_obs, n_box, n_sph, hist_cap, max_iter, force, mode;  // mode 0: SCP solve, 1: one subproblem
     int probe_visits;   // longest-first schedule: a problem's first `probe_visits` time slices are ONE trip each (0: off)
+    int slice_q;        // ... after which a problem of penalty level 0 goes on in slices of `slice_q` trips (0: runs to its end)
     int* queue;         // scheduler state of this launch (Sched below): persistent workgroups pull work with atomics
     int* lists;         // [SCHED_LEVELS][list_cap] problems waiting for their next slice, by penalty level; entries start
                         // at -1; an entry is (slices so far << 24) | problem
-    int list_cap;       // probe_visits * B: a problem is pushed at most once per probing slice
+    int list_cap;       // entries per list: a problem is pushed at most once per finite slice
     const int* order;   // fresh problems are handed out in this order (hardest first, scp.hpp: sched_key_kernel); null = 0, 1, 2, ...
     gusto_scp_params sp;
     gusto_model_params mp;

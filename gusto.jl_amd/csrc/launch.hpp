@@ -75,18 +75,20 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     memset(h->sched_init, 0, sizeof(h->sched_init));
     h->sched_init[SQ_PROBING] = dyn ? h->B : 0;     // every problem starts with its probing slices still ahead
     HIPCHK(h, hipMemcpyAsync(h->d_queue, h->sched_init, SQ_WORDS * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    const int slice_q = dyn ? (getenv("GUSTO_SLICE_Q") ? atoi(getenv("GUSTO_SLICE_Q")) : MT<MODEL>::SCHED_SLICE) : 0;
+    const int pushes = probe + (slice_q > 0 ? (max_iter + slice_q - 1) / slice_q + 1 : 0);   // finite slices of a problem at most
     if (dyn) {
-        const size_t need = (size_t)SCHED_LEVELS * probe * h->batch_cap;
+        const size_t need = (size_t)SCHED_LEVELS * pushes * h->batch_cap;
         if (need > h->order_ints) {
             if (h->d_order) hipFree(h->d_order);
             h->d_order = nullptr; h->order_ints = 0;
             HIPCHK(h, dalloc(&h->d_order, need));
             h->order_ints = need;
         }
-        P.list_cap = probe * h->B;
+        P.list_cap = pushes * h->B;
         HIPCHK(h, hipMemsetAsync(h->d_order, 0xFF, (size_t)SCHED_LEVELS * P.list_cap * sizeof(int), h->stream));
     }
-    P.queue = h->d_queue; P.lists = h->d_order; P.probe_visits = dyn ? probe : 0;
+    P.queue = h->d_queue; P.lists = h->d_order; P.probe_visits = dyn ? probe : 0; P.slice_q = slice_q;
     P.order = nullptr;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));   // (the solve's time includes the ordering kernels below)
     if (dyn && T::HAS_OBS && P.n_obs > 0 && !getenv("GUSTO_DEV_NO_ORDER")) {   // hardest first (scp.hpp: sched_key_kernel)

@@ -274,7 +274,7 @@ GD int ucas(int* p, int expected, int desired) {   // returns the value found (=
 // at the head of the highest non-empty level list, else -1 when nothing can come any more.  Executed by a WHOLE wave
 // with uniform control flow: a polling loop with exits under `if (lane == 0)` does not survive the compiler's
 // structurizer when the other lanes stay in the outer loop (the wave never reconverges; found the hard way).
-GD int sched_pop(const KParams& P, bool& cont) {
+GD int sched_pop(const KParams& P, bool& cont, int& from) {   // from: the level of the list the entry came from
     int* Q = P.queue;
     // claims the head of the highest non-empty list of levels hi .. lo: its entry, -2 if they are empty, -1 if an entry is lost
     auto take = [&](int hi, int lo) -> int {
@@ -291,6 +291,7 @@ GD int sched_pop(const KParams& P, bool& cont) {
                         return -1;
                     }
                     if (L >= 1) uadd(Q + SQ_HI, -1);
+                    from = L;
                     return e;
                 }
                 h = found;
@@ -334,20 +335,20 @@ scp_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int slot = blockIdx.x;
     for (;;) {
-        int b = 0, ci = 0;
+        int b = 0, ci = 0, from = 0;
         if constexpr (ONEWAVE) {
             bool c = false;
-            b = sched_pop(P, c); ci = c;
+            b = sched_pop(P, c, from); ci = c;
         } else {
-            __shared__ int sh_b, sh_cont;
+            __shared__ int sh_b, sh_cont, sh_from;
             __syncthreads();               // (everyone is done with the previous problem's LDS)
             if (threadIdx.x < 64) {        // wave 0 asks the scheduler, the others get the answer through LDS
                 bool c = false;
-                b = sched_pop(P, c);
-                if (threadIdx.x == 0) { sh_b = b; sh_cont = c; }
+                b = sched_pop(P, c, from);
+                if (threadIdx.x == 0) { sh_b = b; sh_cont = c; sh_from = from; }
             }
             __syncthreads();
-            b = sh_b; ci = sh_cont;
+            b = sh_b; ci = sh_cont; from = sh_from;
         }
         if (b < 0) return;
         const bool cont = ci != 0;
@@ -365,7 +366,14 @@ scp_kernel(const KParams P) {
 #ifdef GUSTO_SCHED_DEBUG
         if (b >= P.B) { if (threadIdx.x == 0) printf("sched: bad b %d (ci %d visits %d) slot %d\n", b, ci, visits, slot); return; }
 #endif
-        const int trips = (P.mode == 0 && visits < P.probe_visits) ? 1 : (1 << 30);
+        // slices: one trip each while probing; then a problem of penalty level 0 goes on in slices of slice_q trips (it is
+        // requeued behind the others of its level, and ahead of them all once its penalty weight is raised), a problem of a
+        // higher level runs to its end
+        const bool sliced = P.mode == 0 && P.probe_visits > 0;
+        const int trips = !sliced ? (1 << 30) : (visits < P.probe_visits) ? 1 : (P.slice_q > 0 && cont && from == 0) ? P.slice_q : (1 << 30);
+        // a problem that starts its last slice will not be pushed again (SQ_PROBING: the problems that still may be)
+        if (sliced && trips == (1 << 30) && threadIdx.x == 0)
+            __hip_atomic_fetch_sub(P.queue + SQ_PROBING, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const int lvl = scp_problem<MODEL, ONEWAVE>(P, lds, b, slot, cont, trips);
         blk_sync<ONEWAVE>();               // the next problem reuses this workgroup's LDS and workspace slot
         if constexpr (!ONEWAVE) __syncthreads();
@@ -381,9 +389,9 @@ scp_kernel(const KParams P) {
                 __hip_atomic_store(P.lists + (size_t)lvl * P.list_cap + idx, ((visits + 1) << 24) | b, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);                                                        // ... then the entry
             }
-            // this was the problem's last probing slice (or it stopped inside one): it will not be pushed again
+            // the problem stopped inside a finite slice: it will not be pushed again
             // (release: the tail increment and the entry above are visible to whoever sees the counter drop)
-            if (trips == 1 && (lvl < 0 || visits + 1 >= P.probe_visits))
+            if (sliced && trips != (1 << 30) && lvl < 0)
                 __hip_atomic_fetch_sub(P.queue + SQ_PROBING, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
