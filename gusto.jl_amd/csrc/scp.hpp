@@ -246,10 +246,12 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
 // batch has stopped.  Problem lengths vary 5...30 trips and are not known in advance; with first-come-first-served a long
 // problem that starts late leaves the GPU empty at the end (makespan 674 "KKT units" against 374 balanced and 415 for the
 // longest problem, freeflyer B = 4096).  So a problem's first `probe_visits` slices are ONE trip each, after which it goes
-// into the list of its penalty level (omega raises so far: the long problems are those raised early); workgroups take
-// fresh problems while there are any, then always the highest level waiting, and from slice probe_visits on a problem
-// runs to its end (simulated makespan 473).  Slicing is free: between trips a problem's whole state lives in HBM
-// (trajectory, histories, st_i), so results are bit-identical to an unsliced run.
+// into the list of its penalty level (omega raises so far: the long problems are those raised early); a workgroup takes
+// the highest level >= 1 waiting, else a fresh problem (handed out hardest first, sched_key_kernel), else level 0; from slice
+// probe_visits on a problem of level >= 1 runs to its end and one of level 0 goes on in slices of `slice_q` trips (0: to its
+// end).  Slicing is free: between trips a problem's whole state lives in HBM (trajectory, histories, st_i), so results
+// are bit-identical to an unsliced run.  SQ_PROBING counts the problems that may still be pushed: it drops when a problem
+// starts its last slice or stops inside a finite one, and a workgroup that finds nothing to take retires once it is zero.
 //   hand-off of a problem between workgroups (possibly on different XCDs): the producer writes the state, releases at
 //   agent scope, then publishes the list entry; the consumer claims an index, spins until the entry is there, acquires.
 #ifndef GUSTO_SCHED_PREEMPT

@@ -93,9 +93,10 @@ int gusto_set_env(gusto_handle h, int n_box, const double* box_min_max, int n_sp
  * launch of persistent workgroups that pull work from a device-side scheduler.  In batches of at least `min_batch`
  * problems the first `probe_iters` time slices of a problem are one SCP iteration each; between slices the problem
  * waits in the list of its penalty level (number of omega raises so far -- the problems whose omega was raised early are
- * the long ones) and workgroups always take the highest level waiting; from slice `probe_iters` on a problem runs to
- * its end.  probe_iters = 0: first come, first served.  Without this call: batches of >= 2048 problems, 2 probing slices
- * (1 for dubins_car, whose problems are short). */
+ * the long ones); workgroups take the highest raised level waiting, then fresh problems (the ones that start deepest
+ * inside an obstacle first), then level 0; from slice `probe_iters` on a problem runs to its end (freeflyerSE2 problems of
+ * level 0: in slices of four iterations).  probe_iters = 0: first come, first served.  Without this call: batches of
+ * >= 2048 problems, 2 probing slices for freeflyerSE2, 1 for the other models.  Results do not depend on the schedule. */
 int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch);
 /* run on a caller-owned hipStream_t (NULL = a new stream owned by the handle).  Like every setter it first completes
  * a pending gusto_solve_async on the stream that solve was enqueued on. */
