@@ -19,6 +19,10 @@
 #pragma once
 #include "rows.hpp"
 
+#ifndef GUSTO_COOP_CHOL_MIN
+#define GUSTO_COOP_CHOL_MIN 7   // control blocks from this size on are factored once per workgroup in LDS (factor_sweep_mw)
+#endif
+
 namespace gusto {
 
 // the dynamic LDS of the workgroup (the same memory as the `extern __shared__` array of scp_kernel)
@@ -164,7 +168,13 @@ template <int MODEL, bool ONEWAVE> struct Blk {
             lut[e] = (i << 8) | (i + rem);
         }
     }
-    GD void sync() const { blk_sync<ONEWAVE>(); }
+    // (the multi-wave kernels also run with ONE wave -- the TrajOpt variants for N <= 64 --: no s_barrier then, and none of the
+    // s_waitcnt vmcnt(0) a __syncthreads() implies)
+    GD void sync() const {
+        if constexpr (ONEWAVE) blk_sync<true>();
+        else if (NTr <= 64) blk_sync<true>();
+        else blk_sync<false>();
+    }
     GD auto PGk(int k) const {
         if constexpr (C::PG_LDS) return pgl + k * n * NZ;
         else return PG + (size_t)(T::LTI ? 0 : k) * n * NZ;
@@ -369,7 +379,7 @@ template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
 // ---- Riccati factorisation of the condensed KKT system (cooperative, sequential in k) ---------------
 // All goal-multiplier blocks (Pi, Z, V, D, Gd) have n columns in state-index space; column i is identically
 // zero when coordinate i has no point goal.
-template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
+template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail, Prof& pf) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ;
@@ -401,6 +411,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
 #pragma unroll
             for (int r = 0; r < PPT; r++) { const int e = tid + r * NT; pgn[r] = (e < NPG) ? pg[e] : 0.0; }
         }
+        pf.tick(PF_FPRE);
         // value function after knot k
         for (int e = tid; e < n * n; e += NT) {
             K.Paft[(size_t)k * R::SNN + e] = K.sP[e];
@@ -442,6 +453,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
             (isr ? K.rv : K.nun)[k * n + i] = s;
         }
         K.sync();
+        pf.tick(PF_FAB);
         // phase 2: Hh = QQ + [Phi Gam]^T T (one triangle, mirrored)
 #pragma unroll
         for (int r = 0; r < QPT; r++) {
@@ -460,8 +472,75 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
             }
         }
         K.sync();
+        pf.tick(PF_F1);
         // phase 3: block Cholesky of [S Hyu^T; Hyu Hyy]: L = chol(S), W = L^-1 Hyu^T, V = L^-1 Zu,
         // K = L^-T W, D = L^-T V.  One thread per column; the m x m factor is recomputed by each of them.
+        if constexpr (m >= GUSTO_COOP_CHOL_MIN) {
+            // Large control blocks (the TrajOpt variants: m = 9, 18 with the defect variables): one Cholesky for the workgroup,
+            // in place in the uu block of Hh (left-looking, a lane per row, one synchronisation per column), then a lane per
+            // right-hand side -- the n columns of Hyu^T, the n of Zu and the m unit vectors for S^-1 -- runs the two
+            // triangular solves with L read from LDS.  With every lane factoring the block in registers (below: fine for
+            // m <= 6) the 9 x 9 case held 243 doubles per lane, spilled, and was 45 % of a KKT solve.
+            static_assert(2 * n + m <= 64 && m * m <= n * NZ, "a lane per right-hand side; r in the T buffer");
+            auto Lu = [&](int i, int j) -> decltype(auto) { return (K.sHh[(n + i) * NZ + n + j]); };
+            auto rinv = K.sT;      // 1 / L(i, i)   (the T buffer is free after phase 2)
+            // lane i < m keeps row i of L in registers; column by column it reads row j (final, written by lane j) as a
+            // broadcast from LDS, forms its entry and the pivot (every lane the pivot itself: j more FMAs, one
+            // synchronisation per column less), scales and publishes its entry
+            {
+                const int i = tid < m ? tid : m - 1;
+                double row[m];
+#pragma unroll
+                for (int l = 0; l < m; l++) row[l] = Lu(i, l);
+                static_for<0, m>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    double rj[j > 0 ? j : 1];
+#pragma unroll
+                    for (int l = 0; l < j; l++) rj[l] = Lu(j, l);
+                    double d = Lu(j, j), sacc = row[j];   // (the diagonal keeps S(j, j): nothing reads L(j, j) itself)
+#pragma unroll
+                    for (int l = 0; l < j; l++) { d -= rj[l] * rj[l]; sacc -= row[l] * rj[l]; }
+                    const double r = rsqrt_nr(d);
+                    if (!(d > 0.0)) *fail = 1.0;
+                    row[j] = sacc * r;
+                    if (tid > j && tid < m) Lu(tid, j) = row[j];
+                    if (tid == j) rinv[j] = r;
+                    K.sync();
+                });
+            }
+            if (tid < 2 * n + m) {
+                const int c = tid;
+                const bool isK = c < n, isD = c >= n && c < 2 * n;
+                const int g = isK ? c : (isD ? c - n : c - 2 * n);
+                double w[m], kk[m];
+#pragma unroll
+                for (int l = 0; l < m; l++) w[l] = isK ? K.sHh[g * NZ + n + l] : (isD ? K.sZ[(n + l) * n + g] : ((l == g) ? 1.0 : 0.0));
+#pragma unroll
+                for (int i = 0; i < m; i++) {      // L w = col
+                    double sacc = w[i];
+#pragma unroll
+                    for (int l = 0; l < i; l++) sacc -= Lu(i, l) * w[l];
+                    w[i] = sacc * rinv[i];
+                }
+#pragma unroll
+                for (int i = m - 1; i >= 0; i--) {  // L^T kk = w
+                    double sacc = w[i];
+#pragma unroll
+                    for (int l = i + 1; l < m; l++) sacc -= Lu(l, i) * kk[l];
+                    kk[i] = sacc * rinv[i];
+                }
+                if (isK || isD) {
+                    double* sw = isK ? K.sW : K.sV;
+                    double* sk = isK ? K.sK : K.sD;
+                    double* gk = K.KD + (size_t)k * R::SKD + (isK ? R::oK : R::oD);
+#pragma unroll
+                    for (int i = 0; i < m; i++) { sw[i * n + g] = w[i]; sk[i * n + g] = kk[i]; gk[i * n + g] = kk[i]; }
+                } else {   // column g of S^-1 = L^-T L^-1 (feed-forward only)
+#pragma unroll
+                    for (int i = 0; i < m; i++) K.KD[(size_t)k * R::SKD + R::oS + i * m + g] = kk[i];
+                }
+            }
+        } else
         if (tid < 2 * n || tid < m * m) {
             double S[m * m], Li[m * m];
 #pragma unroll
@@ -504,6 +583,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
             }
         }
         K.sync();
+        pf.tick(PF_F4);
         // phase 4: P' = Hyy - W^T W, Pi' = Zy - W^T V, Phicl = Phi - Gam K, Gd += V^T V.  The Schur complements are
         // never formed through an explicit S^-1: with barrier weights ~1/mu in Hyy that loses every digit.
         for (int e = tid; e < 4 * n * n; e += NT) {
@@ -557,7 +637,9 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail) {
         }
 #pragma unroll
         for (int r = 0; r < QPT; r++) qq[r] = qqn[r];
+        pf.tick(PF_F7);
         K.sync();
+        pf.tick(PF_FCD);
     }
 }
 
@@ -1996,7 +2078,7 @@ template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(SweepView
     else factor_sweep_1w<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
 }
 template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof& pf) {
-    if constexpr (!BLK::ONE) factor_sweep_mw<MODEL>(K, fail);
+    if constexpr (!BLK::ONE) factor_sweep_mw<MODEL>(K, fail, pf);
 #ifndef GUSTO_SWEEP_INLINE
     else if constexpr (MT<MODEL>::SWEEP_CALL) factor_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K), &pf);
 #endif
