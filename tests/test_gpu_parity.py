@@ -502,17 +502,26 @@ def test_async_solves_on_two_handles_match_the_blocking_solve():
             assert np.array_equal(np.asarray(hist[k])[valid], np.asarray(h2[k])[valid]), k
 
 
-def test_longest_first_schedule_is_bit_identical():
-    """gusto_set_schedule: probing every problem for a few trips and then launching the rest in order of decreasing
-    penalty weight changes the time of a solve, not one bit of its results (trajectories, statuses, histories)."""
+@pytest.mark.parametrize("model", ["freeflyer", "dubins", "astrobee_se3"])
+def test_longest_first_schedule_is_bit_identical(model):
+    """gusto_set_schedule: probing every problem for a few trips, taking raised-penalty problems ahead of fresh ones and
+    slicing the rest changes the time of a solve, not one bit of its results (trajectories, statuses, histories)."""
     g, _ = _mods()
     P = g.problems
-    env = P.freeflyer_env()
-    B = 768
-    x0, glo, ghi, tf = P.freeflyer_batch(B, first=100)
+    spheres = None
+    if model == "freeflyer":
+        mid, N, B, env = g.FREEFLYER_SE2, 50, 768, P.freeflyer_env()
+        x0, glo, ghi, tf = P.freeflyer_batch(B, first=100)
+    elif model == "dubins":
+        mid, N, B, env = g.DUBINS_CAR, 30, 1024, None
+        x0, glo, ghi, tf = P.dubins_batch(B, first=100)
+    else:
+        mid, N, B = g.ASTROBEE_SE3, 50, 192
+        env, spheres = P.iss_corner_env(True)
+        x0, glo, ghi, tf = P.astrobee_se3_batch(B, first=100)
     out = []
-    for probe in (0, 2, 5):
-        s = g.BatchSolver(g.FREEFLYER_SE2, 50, B, hist_cap=40, boxes=env)
+    for probe in (0, 2, 5) if model == "freeflyer" else (0, 1, 3):
+        s = g.BatchSolver(mid, N, B, hist_cap=40, boxes=env, spheres=spheres)
         s.set_schedule(probe, 1)
         s.set_problems(x0, glo, ghi, tf)
         s.solve(30)
