@@ -87,18 +87,43 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(P, g, cfg, n_sample, threads):
-    """The oracle (a C port, NOT the Julia reference) on a bounded sample of the same workload."""
+def cpu_baseline(P, g, cfg, n_sample, threads, B_gpu, algo="gusto"):
+    """The oracle (a C port, NOT the Julia reference) on a bounded sample of the same workload: all usable host cores
+    (OpenMP over problems) and, as SURVEY.md 8(d) asks, ONE core beside it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gusto_oracle as go
-    model, boxes, spheres, (x0, glo, ghi, tf) = workload(P, g, cfg, n_sample, 0)
     go.lib()
+    N = CONFIGS[cfg]["N"]
+
+    def what(k):   # the sample in words: problems 0..k-1 of the config's seeded generator; the GPU batch is problems 0..B-1 of it
+        rel = "the first %d problems of the GPU batch" % k if k <= B_gpu else \
+              "problems 0..%d of the config's generator (the GPU batch is its first %d)" % (k - 1, B_gpu)
+        return rel
+
+    if algo == "trajopt":      # no OpenMP entry point for TrajOpt in the oracle: one core, problem by problem
+        model, boxes, spheres, (x0, glo, ghi, tf) = workload(P, g, cfg, n_sample, 0)
+        o = go.OracleTrajOpt(model, N, boxes=boxes, spheres=spheres)
+        t0 = time.perf_counter()
+        conv = 0
+        for b in range(n_sample):
+            o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+            conv += int(o.solve_trajopt(125)["converged"])
+        dt = time.perf_counter() - t0
+        return {"value": n_sample / dt, "unit": "problems/s", "converged": conv, "cores": 1, "kind": "port",
+                "sample": f"{what(n_sample)}, oracle/libgusto_oracle.so go_solve_trajopt, {dt:.1f} s wall"}
+    model, boxes, spheres, (x0, glo, ghi, tf) = workload(P, g, cfg, n_sample, 0)
     t0 = time.perf_counter()
-    r = go.solve_batch(model, CONFIGS[cfg]["N"], boxes, spheres, x0, glo, ghi, tf, MAX_ITER, threads)
+    r = go.solve_batch(model, N, boxes, spheres, x0, glo, ghi, tf, MAX_ITER, threads)
     dt = time.perf_counter() - t0
-    return {"value": float(r["converged"].sum() / dt), "unit": "converged trajectories/s", "cores": threads,
-            "kind": "port", "sample": f"first {n_sample} problems of the batch, oracle/libgusto_oracle.so "
-            f"(OpenMP over problems), {dt:.1f} s wall"}
+    out = {"value": float(r["converged"].sum() / dt), "unit": "converged trajectories/s", "cores": threads,
+           "kind": "port", "sample": f"{what(n_sample)}, oracle/libgusto_oracle.so (OpenMP over problems), {dt:.1f} s wall"}
+    n1 = max(8, n_sample // (4 * max(1, threads)))      # about a quarter of the all-core wall time on one core
+    t0 = time.perf_counter()
+    r1 = go.solve_batch(model, N, boxes, spheres, x0[:n1], glo[:n1], ghi[:n1], tf[:n1], MAX_ITER, 1)
+    dt1 = time.perf_counter() - t0
+    out["one_core"] = {"value": float(r1["converged"].sum() / dt1), "unit": "converged trajectories/s", "cores": 1,
+                       "sample": f"{what(n1)}, {dt1:.1f} s wall"}
+    return out
 
 
 def main():
@@ -117,12 +142,21 @@ def main():
     ap.add_argument("--overlap", type=int, default=1,
                     help="batches in flight: consecutive steps alternate between this many handles/streams, so the "
                          "slowest problems of one batch overlap the start of the next (1 = strictly serial steps)")
+    ap.add_argument("--algo", default="gusto", choices=("gusto", "trajopt"),
+                    help="gusto: solve_gusto_hip! (the metric of BASELINE.json); trajopt: gusto_solve_trajopt, the second SCP "
+                         "algorithm behind the same seam (configs 2 and 4: FreeflyerSE2 / AstrobeeSE3; default batch 1024 / 256)")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend of a multi-rank run (nccl = RCCL; gloo: ranks sharing one GPU in tests)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    trajopt = args.algo == "trajopt"
+    if trajopt:
+        if args.config not in (2, 4):
+            raise SystemExit("--algo trajopt: FreeflyerSE2 (--config 2) and AstrobeeSE3 (--config 4) have a TrajOpt variant")
+        args.overlap = 1
+        args.batch = args.batch or {2: 1024, 4: 256}[args.config]
     if not args.steps:
-        args.steps = {2: 160, 3: 40, 4: 50, 5: 50}[args.config]
+        args.steps = ({2: 40, 4: 6} if trajopt else {2: 160, 3: 40, 4: 50, 5: 50})[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -156,7 +190,12 @@ def main():
     model, boxes, spheres, (x0, glo, ghi, tf) = workload(P, g, args.config, B, first)
     n, m = g.MODEL_DIMS[model]
     D = max(1, args.overlap)
-    mk = lambda: g.BatchSolver(model, N_KNOTS, B, hist_cap=MAX_ITER + 34, device=dev_ord, boxes=boxes, spheres=spheres)
+    if trajopt:
+        tp = g.default_trajopt_params(model)
+        TO_MAX = tp.max_penalty_iteration * tp.max_convex_iteration * tp.max_trust_iteration
+        mk = lambda: g.TrajOptSolver(model, N_KNOTS, B, hist_cap=2 * TO_MAX + 16, device=dev_ord, boxes=boxes, spheres=spheres)
+    else:
+        mk = lambda: g.BatchSolver(model, N_KNOTS, B, hist_cap=MAX_ITER + 34, device=dev_ord, boxes=boxes, spheres=spheres)
     solvers = [mk() for _ in range(D)]
     solver = solvers[0]
     # inputs resident in HBM before the timed region
@@ -202,7 +241,10 @@ def main():
         j = i % D
         collect(j, in_flight[j])
         solvers[j].set_problems_dev(B, d_x0.data_ptr(), d_glo.data_ptr(), d_ghi.data_ptr(), d_tf.data_ptr())
-        solvers[j].solve_async(MAX_ITER)
+        if trajopt:
+            solvers[j].solve(TO_MAX)        # (gusto_solve_trajopt is synchronous)
+        else:
+            solvers[j].solve_async(MAX_ITER)
         timed_in_flight[j] = timed
         in_flight[j] = True
 
@@ -248,13 +290,13 @@ def main():
     for _ in range(0 if args.no_extras else 5):
         t1 = time.perf_counter()
         solver.set_problems(x0, glo, ghi, tf)
-        solver.solve(MAX_ITER)
+        solver.solve(TO_MAX if trajopt else MAX_ITER)
         solver.traj()
         pcie.append(time.perf_counter() - t1)
     pcie_s = float(np.median(pcie)) if pcie else float("nan")
     # (b) two batches in flight on two handles/streams (the tail of one batch overlaps the head of the next)
     overlapped = None
-    if D == 1 and dist is None and not args.no_extras:
+    if D == 1 and dist is None and not args.no_extras and not trajopt:
         s2 = [solver, mk()]
         K2 = 12
         for i in range(2):
@@ -275,10 +317,13 @@ def main():
         overlapped = n_conv * K2 / (time.perf_counter() - t1)
 
     if rank == 0:
-        value = tot[0] * args.steps / elapsed
+        # TrajOpt marks a problem `converged` only when evaluate_ctol < ctol (scp_trajopt.jl:150-154), which the default
+        # SCPParam_TrajOpt rarely reaches before its loops end: the rate of that line is problems run through the whole
+        # three-loop schedule per second, the converged count is reported beside it
+        value = (tot[4] if trajopt else tot[0]) * args.steps / elapsed
         problems = int(tot[4])
         avg_ms = float(np.mean(kernel_ms))
-        b_kkt, b_lin = algorithmic_bytes(n, m, N_KNOTS)
+        b_kkt, b_lin = algorithmic_bytes(n, m + (n if trajopt else 0), N_KNOTS)   # (TrajOpt: the n defect variables of a knot are controls)
         alg_bytes = b_kkt * ipm_iters + b_lin * scp_iters      # this rank, one launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM traffic of one solve: NOT measured in this run -- PMC counters need their own rocprofv3 --pmc passes
@@ -286,28 +331,33 @@ def main():
         traffic, traffic_src = None, None
         try:
             import glob
-            pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-            if pmc and args.config == 2 and B == CONFIGS[2]["B"]:
+            pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json" if args.config == 2 else f"r*_pmc_config{args.config}.json")))
+            if pmc and not trajopt and B == CONFIGS[args.config]["B"]:
                 traffic = json.load(open(pmc[-1]))["traffic_bytes_per_launch"]
                 traffic_src = "profiles/" + os.path.basename(pmc[-1]) + " (separate rocprofv3 --pmc passes, not this run)"
         except Exception:
             traffic = None
         out = {
-            "metric": f"converged trajectories/sec (batched SCP), {cfg['model'].lower()} N={N_KNOTS}, inputs resident in HBM",
-            "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": (f"problems/sec through the whole TrajOpt schedule (batched SCP, solve_trajopt_hip!), {cfg['model'].lower()} N={N_KNOTS}, inputs resident in HBM"
+                       if trajopt else f"converged trajectories/sec (batched SCP), {cfg['model'].lower()} N={N_KNOTS}, inputs resident in HBM"),
+            # the run contract: `value` = whole-job rate with the inputs resident in HBM when the timed region starts; the
+            # PCIe-inclusive median-of-5 rate of SURVEY.md 8(d) is `pcie_inclusive_traj_per_s` below
+            "value_definition": ("problems" if trajopt else "converged problems") + " x steps / wall time of the timed steps, inputs resident in HBM (serial steps)",
+            "value": value, "unit": "problems/s" if trajopt else "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (cfg["name"] if not args.batch else cfg["name"].replace(f"batch={cfg['B']}", f"batch={args.batch} (--batch)")) +
                                    (" per GPU" if args.scaling == "weak" else " split over the ranks"),
                        "baseline_config": args.config, "batch_total": problems, "batch_rank0": B, "N": N_KNOTS,
-                       "max_iter": MAX_ITER, "sharding": "independent problems per rank; final gather of X,U to rank 0 "
+                       "algorithm": "TrajOpt (gusto_solve_trajopt)" if trajopt else "GuSTO (gusto_solve)",
+                       "max_iter": TO_MAX if trajopt else MAX_ITER, "sharding": "independent problems per rank; final gather of X,U to rank 0 "
                                                          "over RCCL inside every step (N > 1)",
                        "batches_in_flight": D},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          # one gusto_solve = ONE launch of the persistent kernel (device-side longest-first scheduler,
                          # gusto_set_schedule); avg_launch_ms from HIP events on the handle's stream
-                         "kernel": f"gusto::scp_kernel<{model}>", "launches_per_solve": 1, "avg_launch_ms": avg_ms,
+                         "kernel": f"gusto::trajopt_kernel<{4 if args.config == 2 else 5}>" if trajopt else f"gusto::scp_kernel<{model}>", "launches_per_solve": 1, "avg_launch_ms": avg_ms,
                          "kkt_solves_per_launch": ipm_iters, "scp_iters_per_launch": scp_iters,
                          "bytes_per_kkt_solve": b_kkt, "bytes_per_linearisation": b_lin,
                          # with D > 1 launches overlap, so a launch's duration spans the batches it shares the GPU
@@ -324,8 +374,8 @@ def main():
         }
         if not args.no_cpu_baseline:
             threads = usable_cores()
-            n_sample = args.cpu_sample or cfg["cpu_per_core"] * max(2, threads)
-            out["cpu_baseline"] = cpu_baseline(P, g, args.config, n_sample, threads)
+            n_sample = args.cpu_sample or (({2: 768, 4: 16}[args.config]) if trajopt else cfg["cpu_per_core"] * max(2, threads))
+            out["cpu_baseline"] = cpu_baseline(P, g, args.config, n_sample, threads, B, args.algo)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

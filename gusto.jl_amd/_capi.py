@@ -19,11 +19,11 @@ STOP_REASON = {0: "MaxIter", 1: "Converged", 2: "SubproblemFailed", 3: "OmegaMax
 
 # every symbol include/gusto_hip.h declares
 SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims", "gusto_create", "gusto_destroy",
-           "gusto_last_error", "gusto_set_params", "gusto_set_ipm_opts", "gusto_set_env", "gusto_set_schedule",
+           "gusto_last_error", "gusto_set_params", "gusto_set_ipm_opts", "gusto_set_env", "gusto_set_env_batch", "gusto_set_schedule",
            "gusto_set_stream",
            "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_solve_async", "gusto_wait",
            "gusto_last_solve_ms", "gusto_get_traj",
-           "gusto_get_traj_dev", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_get_hist_cap",
+           "gusto_get_traj_dev", "gusto_gather_peer", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_get_hist_cap",
            "gusto_set_trust_state", "gusto_subproblem", "gusto_default_shoot_opts", "gusto_shoot", "gusto_get_shoot",
            "gusto_default_trajopt_params", "gusto_create_trajopt", "gusto_set_trajopt_params", "gusto_solve_trajopt",
            "gusto_get_trajopt_history", "gusto_subproblem_trajopt",
@@ -128,6 +128,7 @@ def lib():
         L.gusto_set_params.argtypes = [vp, C.POINTER(ScpParams), C.POINTER(ModelParams)]
         L.gusto_set_ipm_opts.argtypes = [vp, C.POINTER(IpmOpts)]
         L.gusto_set_env.argtypes = [vp, ci, vp, ci, vp]
+        L.gusto_set_env_batch.argtypes = [vp, ci, vp, vp, vp, vp]
         L.gusto_set_stream.argtypes = [vp, vp]
         L.gusto_set_problems.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
         L.gusto_set_problems_dev.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
@@ -139,6 +140,7 @@ def lib():
         L.gusto_get_traj.argtypes = [vp, vp, vp]
         L.gusto_get_traj_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
         L.gusto_get_status.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.gusto_gather_peer.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, C.POINTER(ci)]
         L.gusto_get_dual.argtypes = [vp, vp]
         L.gusto_get_history.argtypes = [vp, C.POINTER(History)]
         L.gusto_get_hist_cap.argtypes = [vp, C.POINTER(ci)]
@@ -234,6 +236,21 @@ class BatchSolver:
         self._chk(self.L.gusto_set_env(self.h, len(self.boxes), self.boxes.ctypes.data, len(self.spheres),
                                        self.spheres.ctypes.data), "set_env")
 
+    def set_env_batch(self, boxes_list, spheres_list=None):
+        """gusto_set_env_batch: one keep-out set per problem -- boxes_list[b] is [n_box_b, 6], spheres_list[b] [n_sph_b, 4]
+        (None = no spheres anywhere).  In the reference every ProblemDefinition owns its env (types.jl:32-39)."""
+        B = len(boxes_list)
+        bl = [_arr(b if b is not None else np.zeros((0, 6))).reshape(-1, 6) for b in boxes_list]
+        sl = [_arr(s if s is not None else np.zeros((0, 4))).reshape(-1, 4) for s in (spheres_list or [None] * B)]
+        if len(sl) != B:
+            raise ValueError("set_env_batch: as many sphere tables as box tables")
+        nb, ns = _arr([len(b) for b in bl], np.int32), _arr([len(s) for s in sl], np.int32)
+        box = _arr(np.concatenate(bl, axis=0)) if bl else np.zeros((0, 6))
+        sph = _arr(np.concatenate(sl, axis=0)) if sl else np.zeros((0, 4))
+        self.boxes, self.spheres = bl, sl
+        self._chk(self.L.gusto_set_env_batch(self.h, B, nb.ctypes.data, box.ctypes.data, ns.ctypes.data, sph.ctypes.data),
+                  "set_env_batch")
+
     def set_problems(self, x_init, goal_lo, goal_hi, tf, X0=None, U0=None):
         x_init, goal_lo, goal_hi = _arr(x_init).reshape(-1, self.n), _arr(goal_lo).reshape(-1, self.n), \
             _arr(goal_hi).reshape(-1, self.n)
@@ -295,6 +312,31 @@ class BatchSolver:
         dev = torch.device("cuda", self.device)
         return (torch.as_tensor(_View(px.value, (self.B, self.N, self.n)), device=dev),
                 torch.as_tensor(_View(pu.value, (self.B, self.N, self.m)), device=dev))
+
+    def gather_peer(self, sources, host=True):
+        """gusto_gather_peer: the shards of `sources` (BatchSolvers, one per GPU, solves possibly still in flight) onto this
+        handle's GPU by direct peer copies; returns (X, U) of all problems in the order of `sources` -- numpy arrays, or
+        with host=False zero-copy torch views of the gathered device buffers."""
+        hs = (C.c_void_p * len(sources))(*[q.h for q in sources])
+        px, pu, bt = C.c_void_p(), C.c_void_p(), C.c_int()
+        Bt = sum(q.B for q in sources)
+        X = np.zeros((Bt, self.N, self.n)) if host else None
+        U = np.zeros((Bt, self.N, self.m)) if host else None
+        self._chk(self.L.gusto_gather_peer(self.h, len(sources), hs, C.byref(px), C.byref(pu),
+                                           X.ctypes.data if host else None, U.ctypes.data if host else None, C.byref(bt)),
+                  "gather_peer")
+        assert bt.value == Bt
+        if host:
+            return X, U
+        import torch
+
+        class _View:
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = dict(shape=shape, typestr="<f8", data=(int(ptr), False), version=2)
+
+        dev = torch.device("cuda", self.device)
+        return (torch.as_tensor(_View(px.value, (Bt, self.N, self.n)), device=dev),
+                torch.as_tensor(_View(pu.value, (Bt, self.N, self.m)), device=dev))
 
     def status(self):
         a = [np.zeros(self.B, dtype=np.int32) for _ in range(5)]

@@ -316,8 +316,10 @@ struct KParams {
     gusto_scp_params sp;
     gusto_model_params mp;
     gusto_ipm_opts io;
-    const double* box;  // [n_box][6]
+    const double* box;  // [n_box][6]   (gusto_set_env_batch: the tables of all problems, concatenated)
     const double* sph;  // [n_sph][4]
+    const int* env;     // null: one keep-out set for the batch; else [B][4] = box offset, n_box, sphere offset, n_sph of problem b
+                        // (n_obs is then the LARGEST count of the batch: it sizes the row slots and the obstacle arrays)
     double* X;          // [B][N][n]  SCPS.traj.X
     double* U;          // [B][N][m]
     const double *x_init, *goal_lo, *goal_hi, *tf;

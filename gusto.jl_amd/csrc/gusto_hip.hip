@@ -2,6 +2,8 @@
 // There is no CPU fallback: every entry point needs a gfx950 device and fails loudly without one.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -156,12 +158,13 @@ int gusto_destroy(gusto_handle h) {
     void* ptrs[] = {h->d_X, h->d_U, h->d_xinit, h->d_glo, h->d_ghi, h->d_tf, h->d_sti, h->d_std, h->d_Jt, h->d_Jf, h->d_conv,
                     h->d_Delta, h->d_omega, h->d_rho, h->d_acc, h->d_scp, h->d_sol, h->d_tr, h->d_cvx, h->d_ipm, h->d_ws,
                     h->d_prof, h->d_subD, h->d_subW, h->d_subT, h->d_subX, h->d_subU, h->d_subObj, h->d_subSt, h->d_subIt, h->d_box, h->d_sph,
-                    h->d_to_mu, h->d_to_xtol, h->d_to_ftol, h->d_to_ctol};
+                    h->d_to_mu, h->d_to_xtol, h->d_to_ftol, h->d_to_ctol, h->d_Upub, h->d_env, h->d_gX, h->d_gU};
     for (void* p : ptrs) if (p) hipFree(p);
     for (void* p : {(void*)h->d_shX, (void*)h->d_shU, (void*)h->d_shP, (void*)h->d_shP0, (void*)h->d_shRes, (void*)h->d_shSt, (void*)h->d_shIt, (void*)h->d_shList, (void*)h->d_shXt, (void*)h->d_shUt}) if (p) hipFree(p);
     if (h->d_order) hipFree(h->d_order);
     if (h->d_queue) hipFree(h->d_queue);
     if (h->d_sched_ord) hipFree(h->d_sched_ord);
+    if (h->h_sched_err) hipHostFree(h->h_sched_err);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -213,10 +216,47 @@ int gusto_set_env(gusto_handle h, int n_box, const double* box, int n_sph, const
     { int rc = setter_enter(h); if (rc) return rc; }
     hipFree(h->d_box); hipFree(h->d_sph);
     h->d_box = h->d_sph = nullptr;
+    if (h->d_env) { hipFree(h->d_env); h->d_env = nullptr; }   // back to one keep-out set for the whole batch
+    h->env_B = 0; h->n_obs_max = 0;
     HIPCHK(h, dalloc(&h->d_box, (size_t)6 * n_box)); HIPCHK(h, dalloc(&h->d_sph, (size_t)4 * n_sph));
     if (n_box) HIPCHK(h, hipMemcpy(h->d_box, box, sizeof(double) * 6 * n_box, hipMemcpyHostToDevice));
     if (n_sph) HIPCHK(h, hipMemcpy(h->d_sph, sph, sizeof(double) * 4 * n_sph, hipMemcpyHostToDevice));
     h->n_box = n_box; h->n_sph = n_sph;
+    return GUSTO_OK;
+}
+
+// One Workspace per problem: in the reference every ProblemDefinition owns its env (types.jl:32-39) and Workspace(robot, env)
+// is built per problem (types.jl:12-24).  The tables of all problems are concatenated in problem order.
+int gusto_set_env_batch(gusto_handle h, int B, const int* n_box, const double* box, const int* n_sph, const double* sph) {
+    if (!h || B < 1 || !n_box || !n_sph) return GUSTO_ERR_ARG;
+    if (B > h->batch_cap) { h->err = "gusto_set_env_batch: more problems than the handle's batch_cap"; return GUSTO_ERR_ARG; }
+    std::vector<int> rec((size_t)4 * B);
+    size_t tb = 0, ts = 0;
+    int mx = 0;
+    for (int b = 0; b < B; b++) {
+        if (n_box[b] < 0 || n_sph[b] < 0 || n_box[b] + n_sph[b] > 64) {
+            h->err = "gusto_set_env_batch: between 0 and 64 keep-out components per problem";
+            return GUSTO_ERR_ARG;
+        }
+        if (tb + n_box[b] > (size_t)INT_MAX / 8 || ts + n_sph[b] > (size_t)INT_MAX / 8) {
+            h->err = "gusto_set_env_batch: tables too large";
+            return GUSTO_ERR_ARG;
+        }
+        rec[4 * b] = (int)tb; rec[4 * b + 1] = n_box[b]; rec[4 * b + 2] = (int)ts; rec[4 * b + 3] = n_sph[b];
+        tb += n_box[b]; ts += n_sph[b];
+        mx = std::max(mx, n_box[b] + n_sph[b]);
+    }
+    if ((tb && !box) || (ts && !sph)) return GUSTO_ERR_ARG;
+    { int rc = setter_enter(h); if (rc) return rc; }
+    hipFree(h->d_box); hipFree(h->d_sph);
+    h->d_box = h->d_sph = nullptr;
+    if (h->d_env) { hipFree(h->d_env); h->d_env = nullptr; }
+    h->env_B = 0; h->n_obs_max = 0; h->n_box = 0; h->n_sph = 0;
+    HIPCHK(h, dalloc(&h->d_box, 6 * tb)); HIPCHK(h, dalloc(&h->d_sph, 4 * ts)); HIPCHK(h, dalloc(&h->d_env, (size_t)4 * B));
+    if (tb) HIPCHK(h, hipMemcpy(h->d_box, box, sizeof(double) * 6 * tb, hipMemcpyHostToDevice));
+    if (ts) HIPCHK(h, hipMemcpy(h->d_sph, sph, sizeof(double) * 4 * ts, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_env, rec.data(), sizeof(int) * rec.size(), hipMemcpyHostToDevice));
+    h->env_B = B; h->n_obs_max = mx;
     return GUSTO_OK;
 }
 
@@ -272,7 +312,8 @@ static int set_problems_impl(gusto_handle h, int B, const double* x_init, const 
         return GUSTO_ERR_ARG;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcw = gusto_finish(h); if (rcw) return rcw; }
+    { int rcw = gusto_finish(h); if (rcw && !h->sched_err) return rcw; }
+    h->sched_err = 0;   // (a latched scheduler error ends here: every problem is set again)
     const size_t n = h->n, m = h->m, N = h->N;
     h->B = B;
     HIPCHK(h, hipMemcpyAsync(h->d_xinit, x_init, sizeof(double) * B * n, kind, h->stream));
@@ -303,7 +344,8 @@ int gusto_solve(gusto_handle h, int max_iter, int force) {
     if (!h->have_problems) { h->err = "gusto_solve: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc = gusto_finish(h);
-    if (rc) return rc;
+    if (rc && !h->sched_err) return rc;
+    h->sched_err = 0;
     rc = do_scp(h, 0, max_iter, force ? 1 : 0);
     return rc ? rc : gusto_finish(h);
 }
@@ -313,7 +355,8 @@ int gusto_solve_async(gusto_handle h, int max_iter, int force) {
     if (!h->have_problems) { h->err = "gusto_solve_async: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc = gusto_finish(h);
-    if (rc) return rc;
+    if (rc && !h->sched_err) return rc;
+    h->sched_err = 0;
     return do_scp(h, 0, max_iter, force ? 1 : 0);
 }
 
@@ -361,8 +404,76 @@ int gusto_get_traj(gusto_handle h, double* X, double* U) {
 int gusto_get_traj_dev(gusto_handle h, const double** X, const double** U) {
     if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
     if (!h) return GUSTO_ERR_ARG;
+    if (!h->have_problems) { h->err = "gusto_get_traj_dev: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
     if (X) *X = h->d_X;
-    if (U) *U = h->d_U;
+    if (U) {
+        if (h->trajopt) {   // device rows are (u | defect), pitch u_dim + x_dim: hand out a compact [B][N][u_dim] copy
+            HIPCHK(h, hipSetDevice(h->device));
+            if (!h->d_Upub) HIPCHK(h, dalloc(&h->d_Upub, (size_t)h->batch_cap * h->N * h->m_pub));
+            HIPCHK(h, copy_U(h, h->d_Upub, h->d_U, false, hipMemcpyDeviceToDevice));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            *U = h->d_Upub;
+        } else *U = h->d_U;
+    }
+    return GUSTO_OK;
+}
+
+// The final gather of a multi-GPU run below the host language (SURVEY.md 8(b) threading row, 8(e); north_star: "RCCL only
+// for the batch split and final gather").  One process, one handle per GPU: every shard goes to the GPU of `dst` with ONE
+// direct peer copy over xGMI (hipMemcpyPeerAsync: one hop per source, all links busy -- the fan-in 8(e) asks for, not a
+// ring), enqueued on dst's stream behind the completion of each source's solve.
+int gusto_gather_peer(gusto_handle dst, int n_src, const gusto_handle* src, const double** X_dev, const double** U_dev,
+                      double* X_host, double* U_host, int* B_total) {
+    if (!dst || n_src < 1 || !src) return GUSTO_ERR_ARG;
+    size_t tot = 0;
+    for (int i = 0; i < n_src; i++) {
+        gusto_handle q = src[i];
+        if (!q || !q->have_problems) { dst->err = "gusto_gather_peer: a source handle holds no problems"; return GUSTO_ERR_STATE; }
+        if (q->model_pub != dst->model_pub || q->N != dst->N || q->trajopt != dst->trajopt) {
+            dst->err = "gusto_gather_peer: every handle must hold the same model, algorithm and N";
+            return GUSTO_ERR_ARG;
+        }
+        HIPCHK(q, hipSetDevice(q->device));
+        { int rc = gusto_finish(q); if (rc) { dst->err = "gusto_gather_peer: source: " + q->err; return rc; } }
+        if (q->trajopt) {     // (device rows are (u | defect): compact them on the source GPU first)
+            if (!q->d_Upub) HIPCHK(q, dalloc(&q->d_Upub, (size_t)q->batch_cap * q->N * q->m_pub));
+            HIPCHK(q, copy_U(q, q->d_Upub, q->d_U, false, hipMemcpyDeviceToDevice));
+            HIPCHK(q, hipStreamSynchronize(q->stream));
+        }
+        tot += q->B;
+    }
+    HIPCHK(dst, hipSetDevice(dst->device));
+    { int rc = gusto_finish(dst); if (rc) return rc; }
+    const size_t N = dst->N, n = dst->n, mp = dst->m_pub;
+    if (tot > dst->gather_cap) {
+        if (dst->d_gX) hipFree(dst->d_gX);
+        if (dst->d_gU) hipFree(dst->d_gU);
+        dst->d_gX = dst->d_gU = nullptr; dst->gather_cap = 0;
+        HIPCHK(dst, dalloc(&dst->d_gX, tot * N * n)); HIPCHK(dst, dalloc(&dst->d_gU, tot * N * mp));
+        dst->gather_cap = tot;
+    }
+    size_t at = 0;
+    for (int i = 0; i < n_src; i++) {
+        gusto_handle q = src[i];
+        if (q->device != dst->device) {   // (best effort: without peer access the runtime stages the copy)
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, dst->device, q->device) == hipSuccess && can) {
+                hipError_t e = hipDeviceEnablePeerAccess(q->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+        }
+        const double* su = q->trajopt ? q->d_Upub : q->d_U;
+        HIPCHK(dst, hipMemcpyPeerAsync(dst->d_gX + at * N * n, dst->device, q->d_X, q->device, sizeof(double) * q->B * N * n, dst->stream));
+        HIPCHK(dst, hipMemcpyPeerAsync(dst->d_gU + at * N * mp, dst->device, su, q->device, sizeof(double) * q->B * N * mp, dst->stream));
+        at += q->B;
+    }
+    if (X_host) HIPCHK(dst, hipMemcpyAsync(X_host, dst->d_gX, sizeof(double) * tot * N * n, hipMemcpyDeviceToHost, dst->stream));
+    if (U_host) HIPCHK(dst, hipMemcpyAsync(U_host, dst->d_gU, sizeof(double) * tot * N * mp, hipMemcpyDeviceToHost, dst->stream));
+    HIPCHK(dst, hipStreamSynchronize(dst->stream));
+    if (X_dev) *X_dev = dst->d_gX;
+    if (U_dev) *U_dev = dst->d_gU;
+    if (B_total) *B_total = (int)tot;
     return GUSTO_OK;
 }
 
@@ -400,6 +511,7 @@ int gusto_get_hist_cap(gusto_handle h, int* hist_cap) {
 }
 
 int gusto_get_history(gusto_handle h, gusto_history* o) {
+    if (h && h->trajopt) { h->err = "gusto_get_history: TrajOpt handle, use gusto_get_trajopt_history"; return GUSTO_ERR_STATE; }
     if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
     if (!h || !o || !h->have_problems) return GUSTO_ERR_STATE;
     // o->hist_cap is the row capacity of the CALLER's arrays; rows are written with that pitch
@@ -429,6 +541,7 @@ int gusto_get_history(gusto_handle h, gusto_history* o) {
 // LAST entries of Delta_vec / omega_vec of every problem, i.e. the trust region and penalty the next trip uses
 int gusto_set_trust_state(gusto_handle h, const double* Delta, const double* omega) {
     if (!h || (!Delta && !omega)) return GUSTO_ERR_ARG;
+    if (h->trajopt) { h->err = "gusto_set_trust_state: TrajOpt handle (its trust region s and penalty mu follow SCPParam_TrajOpt)"; return GUSTO_ERR_STATE; }
     if (!h->have_problems) { h->err = "gusto_set_trust_state: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
     { int rc = setter_enter(h); if (rc) return rc; }
     std::vector<int> st((size_t)h->B * ST_NI);
@@ -443,6 +556,8 @@ int gusto_set_trust_state(gusto_handle h, const double* Delta, const double* ome
 
 int gusto_subproblem(gusto_handle h, int B, const double* Xp, const double* Up, const double* Delta, const double* omega,
                      const double* toggle, double* Xn, double* Un, double* obj, int* status, int* iters) {
+    // (before any copy: on a TrajOpt handle h->m is u_dim + x_dim and the caller's [B][N][u_dim] buffer would be over-read)
+    if (h && h->trajopt) { h->err = "TrajOpt handle: use gusto_solve_trajopt / gusto_subproblem_trajopt"; return GUSTO_ERR_STATE; }
     if (!h || !h->have_problems || B != h->B || !Xp || !Up || !Delta || !omega || !toggle) {
         if (h) h->err = "gusto_subproblem: call gusto_set_problems with the same B first";
         return GUSTO_ERR_STATE;

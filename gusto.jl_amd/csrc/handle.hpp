@@ -21,6 +21,10 @@ struct gusto_handle_s {
     gusto_ipm_opts io{};
     int n_box = 0, n_sph = 0;
     double *d_box = nullptr, *d_sph = nullptr;
+    // gusto_set_env_batch: one keep-out set per problem -- d_box / d_sph hold the concatenated tables, d_env the
+    // (box offset, n_box, sphere offset, n_sph) record of every problem, env_B their number, n_obs_max the largest count
+    int* d_env = nullptr;
+    int env_B = 0, n_obs_max = 0;
     double *d_X = nullptr, *d_U = nullptr, *d_xinit = nullptr, *d_glo = nullptr, *d_ghi = nullptr, *d_tf = nullptr;
     int* d_sti = nullptr;
     double* d_std = nullptr;
@@ -44,6 +48,11 @@ struct gusto_handle_s {
     int lds_bytes = 0, per_cu = 0;   // ... its dynamic LDS per workgroup and workgroups per CU (gusto_dev_launch_info)
     int sched_init[gusto::SQ_WORDS] = {0};   // initial scheduler words of a launch (host side of an async copy)
     bool have_problems = false, have_shoot = false;
+    int sched_err = 0;             // latched scheduler error of the last solve (gusto_finish): getters fail until the next set_problems / solve
+    int* h_sched_err = nullptr;    // pinned host word the error flag is copied to on the handle's stream, before the stream is waited for
+    double *d_gX = nullptr, *d_gU = nullptr;   // gusto_gather_peer: the shards of several handles, one after the other, on this handle's GPU
+    size_t gather_cap = 0;                     // ... capacity in problems
+    double* d_Upub = nullptr;      // TrajOpt handles: U compacted to the public [B][N][u_dim] layout for gusto_get_traj_dev
     // indirect shooting (shoot.hip): trajectories, converged costates, seeds, residuals, status, Newton iterations
     double *d_shX = nullptr, *d_shU = nullptr, *d_shP = nullptr, *d_shP0 = nullptr, *d_shRes = nullptr;
     double *d_shXt = nullptr, *d_shUt = nullptr;   // knot-major staging of the shooting trajectories ([N][n][B])
@@ -70,23 +79,35 @@ template <class Tp> static hipError_t dalloc(Tp** p, size_t count) {
 
 
 // completes an enqueued solve: blocks on the handle's stream and takes the kernel time from its events
+static inline int gusto_sched_err_rc(gusto_handle h) {
+    if (!h->sched_err) return GUSTO_OK;
+    h->err = h->sched_err == 1 ? "scheduler: a claimed waiting-list entry never arrived (problem lost); set the problems again"
+                               : "scheduler: workgroups gave up waiting for problems still in their probing slices; set the problems again";
+    return GUSTO_ERR_STATE;
+}
+// The device-side scheduler reports a problem it lost instead of leaving it half-solved (scp.hpp: sched_pop).  The flag is
+// copied on the handle's OWN stream into pinned memory right behind the kernel (launch.hpp), so reading it here needs no
+// blocking copy on the null stream (which would serialise with the other handle of an overlapped pair).  The error is
+// LATCHED: every getter keeps failing until gusto_set_problems or the next solve clears it.
 static inline int gusto_finish(gusto_handle h) {
-    if (!h->pending) return GUSTO_OK;
+    if (!h->pending) return gusto_sched_err_rc(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_ms = ms;
     h->pending = false;
-    if (h->d_queue) {   // the device-side scheduler reports a problem it lost instead of leaving it half-solved (scp.hpp: sched_pop)
-        int serr = 0;
-        HIPCHK(h, hipMemcpy(&serr, h->d_queue + gusto::SQ_ERR, sizeof(int), hipMemcpyDeviceToHost));
-        if (serr) {
-            h->err = serr == 1 ? "scheduler: a claimed waiting-list entry never arrived (problem lost)"
-                               : "scheduler: workgroups gave up waiting for problems still in their probing slices";
-            return GUSTO_ERR_STATE;
-        }
+    if (h->h_sched_err && *h->h_sched_err) h->sched_err = *h->h_sched_err;
+    return gusto_sched_err_rc(h);
+}
+// enqueued behind a solve kernel on the handle's stream: the scheduler's error word -> pinned host memory
+static inline hipError_t gusto_fetch_sched_err(gusto_handle h) {
+    if (!h->h_sched_err) {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h->h_sched_err), sizeof(int), hipHostMallocDefault);
+        if (e != hipSuccess) return e;
     }
-    return GUSTO_OK;
+    *h->h_sched_err = 0;
+    if (!h->d_queue) return hipSuccess;
+    return hipMemcpyAsync(h->h_sched_err, h->d_queue + gusto::SQ_ERR, sizeof(int), hipMemcpyDeviceToHost, h->stream);
 }
 
 // defined in model_<id>.hip (the scp launch only enqueues; gusto_finish completes it)

@@ -75,6 +75,9 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     GPtr<const double> x_init, goal_lo, goal_hi;
     unsigned goalmask;  // bit i: coordinate i of x_N has a point goal (goal_lo == goal_hi)
     unsigned boxmask;   // bit i: coordinate i of x_N has BoxGoal rows (goal_lo != goal_hi, at least one of them finite)
+    // the keep-out set of this problem (models.hpp), re-derived where a trip needs it (linearize, rho, the hand-out order) and
+    // not kept: the interior point loop never looks at it and has no scalar registers to spare
+    GD Env env() const { return problem_env(P, b); }
 
     // Knot-private vectors (only lane k ever touches those of knot k): rd qrd dXs | dUs qu dv | gAx gBx gAu gBu.  The one-wave
     // kernels whose phases are inlined keep them in REGISTERS of lane k over the whole interior point iteration (the
@@ -356,9 +359,10 @@ template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
             double xw[T::WS];
 #pragma unroll
             for (int j = 0; j < T::WS; j++) xw[j] = xp[j];
-            for (int i = 0; i < K.P.n_obs; i++) {
+            const Env E = K.env();
+            for (int i = 0; i < E.n_obs; i++) {
                 double nh[T::WS];
-                const double dist = signed_distance<T::WS>(K.P, 0, xw, i, nh);
+                const double dist = signed_distance<T::WS>(K.P, E, 0, xw, i, nh);
                 if (dist < toggle) {
                     mask |= (uint64_t)1 << i;
                     double c0 = K.P.mp.clearance - dist;

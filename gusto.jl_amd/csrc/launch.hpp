@@ -11,11 +11,18 @@
 using namespace gusto;
 
 // ---- kernel dispatch ---------------------------------------------------------------------------------
-template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B) {
+template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B, bool need_env = true) {
     using T = MT<MODEL>;
     memset(&P, 0, sizeof(P));
     P.N = h->N; P.B = B; P.n_box = h->n_box; P.n_sph = h->n_sph;
     P.n_obs = T::HAS_OBS ? h->n_box + h->n_sph : 0;
+    if (T::HAS_OBS && h->d_env) {   // one keep-out set per problem (gusto_set_env_batch): n_obs sizes the slots, the records say the rest
+        if (need_env && h->env_B != B) {
+            h->err = "gusto_set_env_batch described a different number of problems than gusto_set_problems";
+            return GUSTO_ERR_STATE;
+        }
+        P.n_obs = h->n_obs_max; P.n_box = 0; P.n_sph = 0; P.env = h->d_env;
+    }
     P.hist_cap = h->hist_cap;
     P.sp = h->sp; P.mp = h->mp; P.io = h->io;
     P.box = h->d_box; P.sph = h->d_sph; P.X = h->d_X; P.U = h->d_U;
@@ -75,8 +82,12 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     memset(h->sched_init, 0, sizeof(h->sched_init));
     h->sched_init[SQ_PROBING] = dyn ? h->B : 0;     // every problem starts with its probing slices still ahead
     HIPCHK(h, hipMemcpyAsync(h->d_queue, h->sched_init, SQ_WORDS * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    const int slice_q = dyn ? (getenv("GUSTO_SLICE_Q") ? atoi(getenv("GUSTO_SLICE_Q")) : MT<MODEL>::SCHED_SLICE) : 0;
-    const int pushes = probe + (slice_q > 0 ? (max_iter + slice_q - 1) / slice_q + 1 : 0);   // finite slices of a problem at most
+    int slice_q = dyn ? (getenv("GUSTO_SLICE_Q") ? atoi(getenv("GUSTO_SLICE_Q")) : MT<MODEL>::SCHED_SLICE) : 0;
+    int pushes = probe + (slice_q > 0 ? (max_iter + slice_q - 1) / slice_q + 1 : 0);   // finite slices of a problem at most
+    // a waiting-list entry keeps the slice count in its high byte, (slices + 1) << 24 | problem, and a negative entry means
+    // "not published yet": more than 126 finite slices per problem do not fit -- then a problem of level 0 runs to its end
+    // after its probing slices (slicing only moves time)
+    if (pushes >= 127) { slice_q = 0; pushes = probe; }
     if (dyn) {
         const size_t need = (size_t)SCHED_LEVELS * pushes * h->batch_cap;
         if (need > h->order_ints) {
@@ -109,6 +120,8 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     hipLaunchKernelGGL(kern, dim3(slots), dim3(NT), lds, h->stream, P);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->sched_err = 0;
+    HIPCHK(h, gusto_fetch_sched_err(h));
     h->pending = true;   // completed by gusto_finish (handle.hpp)
     return GUSTO_OK;
 }
@@ -142,13 +155,15 @@ template <int MODEL> static int launch_trajopt(gusto_handle h, int mode, int max
     hipLaunchKernelGGL(kern, dim3(slots), dim3(NT), lds, h->stream, P);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->sched_err = 0;
+    HIPCHK(h, gusto_fetch_sched_err(h));
     h->pending = true;
     return GUSTO_OK;
 }
 
 template <int MODEL> static int launch_init(gusto_handle h, bool straight) {
     KParams P;
-    int rc = fill_params<MODEL>(h, P, h->B);
+    int rc = fill_params<MODEL>(h, P, h->B, false);   // (the init kernels do not look at the keep-out sets)
     if (rc) return rc;
     if (straight) {
         const int tot = h->B * h->N;

@@ -233,19 +233,42 @@ template <> struct Dyn<GUSTO_TO_ASTROBEE_SE3> : DynTO<GUSTO_TO_ASTROBEE_SE3, GUS
 typedef const __attribute__((address_space(4))) double cdouble;
 GD const cdouble* as_constant(const double* p) { return (const cdouble*)(uintptr_t)p; }
 
+// The keep-out set of ONE problem (Workspace(robot, env), types.jl:12-24; every ProblemDefinition owns its env, :32-39):
+// n_box AABBs, then n_obs - n_box spheres.  With gusto_set_env the whole batch shares one table (the kernel arguments);
+// with gusto_set_env_batch problem b has its own slice of the concatenated tables, found through KParams::env -- an
+// (offset, count) record per problem that is read ONCE per problem through the constant address space (b is wave-uniform),
+// so the table base stays a scalar and the obstacle loop keeps its s_load form.
+struct Env {
+    const double* box;
+    const double* sph;
+    int n_box, n_obs;
+};
+GD Env problem_env(const KParams& P, int b) {
+    Env e;
+    if (P.env) {
+        typedef const __attribute__((address_space(4))) int cint;
+        const cint* q = (const cint*)(uintptr_t)(P.env + 4 * (size_t)b);
+        const int bo = q[0], nb = q[1], so = q[2], ns = q[3];
+        e.box = P.box + 6 * (size_t)bo; e.sph = P.sph + 4 * (size_t)so; e.n_box = nb; e.n_obs = nb + ns;
+    } else {
+        e.box = P.box; e.sph = P.sph; e.n_box = P.n_box; e.n_obs = P.n_obs;
+    }
+    return e;
+}
+
 template <int WS>
-GD double signed_distance(const KParams& P, int comp, const double* r, int i, double* nh) {
+GD double signed_distance(const KParams& P, const Env& E, int comp, const double* r, int i, double* nh) {
     double q[WS];
 #pragma unroll
     for (int j = 0; j < WS; j++) q[j] = r[j] + P.mp.comp_off[comp][j];
-    if (i < P.n_box) {
-        const cdouble* bx = as_constant(P.box) + 6 * i;
+    if (i < E.n_box) {
+        const cdouble* bx = as_constant(E.box) + 6 * i;
         double lo[WS], hi[WS];
 #pragma unroll
         for (int j = 0; j < WS; j++) { lo[j] = bx[j]; hi[j] = bx[3 + j]; }
         return sdf_box<WS>(q, lo, hi, nh) - P.mp.radius;
     }
-    const cdouble* sp = as_constant(P.sph) + 4 * (i - P.n_box);
+    const cdouble* sp = as_constant(E.sph) + 4 * (i - E.n_box);
     double v[WS], s2 = 0;
 #pragma unroll
     for (int j = 0; j < WS; j++) { v[j] = q[j] - sp[j]; s2 += v[j] * v[j]; }

@@ -51,14 +51,15 @@ template <int MODEL, class BLK> GD double trust_region_ratio(BLK& K, const doubl
             num += sqrt(a); den += sqrt(b);
         }
         if constexpr (T::HAS_OBS) {
+            const Env E = K.env();
             for (int c = 0; c < K.P.mp.n_robot_comp; c++)
-                for (int i = 0; i < K.P.n_obs; i++) {
+                for (int i = 0; i < E.n_obs; i++) {
                     double nh[T::WS], nh1[T::WS];
-                    const double d0 = signed_distance<T::WS>(K.P, c, xp, i, nh);
+                    const double d0 = signed_distance<T::WS>(K.P, E, c, xp, i, nh);
                     double lin = K.P.mp.clearance - d0;
 #pragma unroll
                     for (int j = 0; j < T::WS; j++) lin -= nh[j] * (x[j] - xp[j]);
-                    const double d1 = signed_distance<T::WS>(K.P, c, x, i, nh1);
+                    const double d1 = signed_distance<T::WS>(K.P, E, c, x, i, nh1);
                     num += fabs((K.P.mp.clearance - d1) - lin);
                     den += fabs(lin);
                 }
@@ -448,10 +449,11 @@ template <int MODEL, class BLK> GD double trajopt_ratio(BLK& K, const double* X,
         double xw[T::WS], qw[T::WS];
 #pragma unroll
         for (int j = 0; j < T::WS; j++) { xw[j] = X[k * n + j]; qw[j] = Xq[k * n + j]; }
+        const Env E = K.env();
         for (int c = 0; c < K.P.mp.n_robot_comp; c++)
-            for (int i = 0; i < K.P.n_obs; i++) {
+            for (int i = 0; i < E.n_obs; i++) {
                 double nh[T::WS], nh1[T::WS];
-                const double d0 = signed_distance<T::WS>(K.P, c, qw, i, nh), d1 = signed_distance<T::WS>(K.P, c, xw, i, nh1);
+                const double d0 = signed_distance<T::WS>(K.P, E, c, qw, i, nh), d1 = signed_distance<T::WS>(K.P, E, c, xw, i, nh1);
                 double lin = d0;
 #pragma unroll
                 for (int j = 0; j < T::WS; j++) lin += nh[j] * (xw[j] - qw[j]);
@@ -489,15 +491,16 @@ template <int MODEL, class BLK> GD double trajopt_ctol(BLK& K, const double* X, 
         for (int j = 0; j < nw; j++) { g += x[iw + j] * x[iw + j]; gq += q[iw + j] * q[iw + j]; }
         cls(k < N ? fabs(g - gq) : 0.0, k < N ? fabs(g) : 0.0);
     }
-    if (K.P.n_obs > 0) {   // ncsi_body_obstacle_avoidance_constraints: clearance - dist
+    const Env E = K.env();
+    if (E.n_obs > 0) {   // ncsi_body_obstacle_avoidance_constraints: clearance - dist
         double a = 0, b = 0;
         if (k < N) {
             double xw[T::WS], qw[T::WS], nh[T::WS];
 #pragma unroll
             for (int j = 0; j < T::WS; j++) { xw[j] = x[j]; qw[j] = q[j]; }
-            for (int i = 0; i < K.P.n_obs; i++) {
-                const double g = mp.clearance - signed_distance<T::WS>(K.P, 0, xw, i, nh);
-                const double gq = mp.clearance - signed_distance<T::WS>(K.P, 0, qw, i, nh);
+            for (int i = 0; i < E.n_obs; i++) {
+                const double g = mp.clearance - signed_distance<T::WS>(K.P, E, 0, xw, i, nh);
+                const double gq = mp.clearance - signed_distance<T::WS>(K.P, E, 0, qw, i, nh);
                 a = fmax(a, fabs(g - gq)); b = fmax(b, fabs(g));
             }
         }
@@ -666,7 +669,8 @@ template <int MODEL> __global__ void sched_key_kernel(const KParams P, int* buck
         double xw[T::WS], nh[T::WS], worst = 0.0;
 #pragma unroll
         for (int j = 0; j < T::WS; j++) xw[j] = x[j];
-        for (int i = 0; i < P.n_obs; i++) worst = fmax(worst, P.mp.clearance - signed_distance<T::WS>(P, 0, xw, i, nh));
+        const Env E = problem_env(P, b);
+        for (int i = 0; i < E.n_obs; i++) worst = fmax(worst, P.mp.clearance - signed_distance<T::WS>(P, E, 0, xw, i, nh));
         const double full = 2.0 * (P.mp.radius + P.mp.clearance);      // a robot diameter inside an obstacle: the last bucket
         const int q = (int)fmin((double)(SCHED_BUCKETS - 1), worst / full * (SCHED_BUCKETS - 1));
         if (q > 0) atomicMax(bucket + b, q);

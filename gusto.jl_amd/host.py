@@ -196,9 +196,10 @@ def init_traj_straightline(TOP):
 
 
 # ---- the plug-in: solve_method!(SCPS, SCPP, solver, max_iter, force; kw...) ---------------------------------------
-def _fetch(bs):
-    """Everything a solution needs from one handle, copied device -> host ONCE per solve (not once per problem)."""
-    X, U = bs.traj()
+def _fetch(bs, XU=None):
+    """Everything a solution needs from one handle, copied device -> host ONCE per solve (not once per problem).
+    `XU`: the shard's trajectories when a device-side gather (gusto_gather_peer) has already brought them over."""
+    X, U = XU if XU is not None else bs.traj()
     return dict(X=X, U=U, st=bs.status(), h=bs.history(), dual=bs.dual())
 
 
@@ -279,8 +280,19 @@ def solve_trajopt_hip(SCPS, SCPP, solver="hip", max_iter=125, force=False, devic
     env = SCPP.PD.env
     tp = trajopt_params or _capi.default_trajopt_params(model.model_id)
     total = tp.max_penalty_iteration * tp.max_convex_iteration * tp.max_trust_iteration
-    bs = _capi.TrajOptSolver(model.model_id, N, 1, hist_cap=2 * total + 16, device=device, boxes=env.boxes, spheres=env.spheres,
-                             model_params=SCPP.model_params, trajopt_params=tp)
+    # one handle per SCPSolution: a repeated call re-uses it (device allocations, kernel attributes) and only sets the problem
+    # again -- solve_trajopt_jump! has no resume either, every call runs the whole three-loop schedule from SCPS.traj
+    bs = SCPS._solver
+    if not (isinstance(bs, _capi.TrajOptSolver) and bs.model == model.model_id and bs.N == N and bs.device == device
+            and bs.hist_cap >= 2 * total + 16):
+        if bs is not None:
+            bs.close()
+        bs = _capi.TrajOptSolver(model.model_id, N, 1, hist_cap=2 * total + 16, device=device, boxes=env.boxes,
+                                 spheres=env.spheres, model_params=SCPP.model_params, trajopt_params=tp)
+    else:
+        bs.set_env(env.boxes, env.spheres)
+        bs._chk(bs.L.gusto_set_params(bs.h, None, _capi.C.byref(SCPP.model_params)), "set_params")
+        bs._chk(bs.L.gusto_set_trajopt_params(bs.h, _capi.C.byref(tp)), "set_trajopt_params")
     lo, hi = _goal_bounds(SCPP.PD.goal_set, n, SCPP.tf_guess)
     bs.set_problems(SCPP.PD.x_init[None], lo[None], hi[None], [SCPP.tf_guess], SCPS.traj.X.T[None].copy(), SCPS.traj.U.T[None].copy())
     bs.solve(max_iter)
@@ -406,7 +418,7 @@ def shard_bounds(B, world_size, rank):
 
 def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straightline, solver="hip", max_iter=30,
                     force=False, device=0, devices=None):
-    """All TOPs must share model, N and environment; one gusto_solve covers the whole list.
+    """All TOPs must share model and N (each may bring its own environment); one gusto_solve covers the whole list.
 
     `devices` = list of GPU ordinals: the problems are sharded in contiguous blocks (shard_bounds) over
     one handle per entry, every shard is enqueued with gusto_solve_async and the shards run concurrently -- the
@@ -422,8 +434,10 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
     for t in TOPs[1:]:      # one gusto_handle = one model, one horizon, one Workspace
         if type(t.PD.model) is not type(model) or t.N != N:
             raise ValueError("solve_SCP_batch!: all problems must share the model type and N")
-        if not (np.array_equal(t.PD.env.boxes, TOP0.PD.env.boxes) and np.array_equal(t.PD.env.spheres, TOP0.PD.env.spheres)):
-            raise ValueError("solve_SCP_batch!: all problems must share the environment")
+    # every ProblemDefinition owns its env (types.jl:32-39): a batch whose environments differ goes through
+    # gusto_set_env_batch (one Workspace per problem), a batch that shares one through gusto_set_env
+    same_env = all(np.array_equal(t.PD.env.boxes, TOP0.PD.env.boxes) and np.array_equal(t.PD.env.spheres, TOP0.PD.env.spheres)
+                   for t in TOPs[1:])
     devs = list(devices) if devices else [device]
     sp, mp = _capi.default_params(model.model_id)
     x0 = np.stack([t.PD.x_init for t in TOPs])
@@ -442,13 +456,20 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
             continue
         bs = BatchSolver(model.model_id, N, b1 - b0, hist_cap=_hist_cap(max_iter), device=dv,
                          boxes=TOP0.PD.env.boxes, spheres=TOP0.PD.env.spheres, scp_params=sp, model_params=mp)
+        if not same_env:
+            bs.set_env_batch([t.PD.env.boxes for t in TOPs[b0:b1]], [t.PD.env.spheres for t in TOPs[b0:b1]])
         bs.set_problems(x0[b0:b1], lo[b0:b1], hi[b0:b1], tf[b0:b1], X0[b0:b1], U0[b0:b1])
         bs.solve_async(max_iter, force)
         shards.append((b0, b1, bs))
     out = [None] * B
+    gathered = None
+    if len(shards) > 1:
+        # the final gather of the multi-GPU path below the host language: every shard to the first handle's GPU by one
+        # direct peer copy over xGMI (gusto_gather_peer; it completes each shard's solve first), then ONE copy to the host
+        gathered = shards[0][2].gather_peer([bs for _, _, bs in shards])
     for b0, b1, bs in shards:
         bs.wait()
-        snap = _fetch(bs)                    # one device -> host copy per shard
+        snap = _fetch(bs, None if gathered is None else (gathered[0][b0:b1], gathered[1][b0:b1]))
         per = bs.last_solve_ms() * 1e-3 / (b1 - b0)
         for b in range(b0, b1):
             SCPP = SCPProblem(TOPs[b])

@@ -31,14 +31,18 @@ function solve_shooting_hip!(SS::ShootingSolution, SP::ShootingProblem, SCPS::SC
   nothing
 end
 
-# Batch entry point (the reference has none): every TOP must share model, N and environment.  `devices` = GPU ordinals:
+# Batch entry point (the reference has none): every TOP must share model and N (each may bring its own environment).  `devices` = GPU ordinals:
 # the problems are split in contiguous blocks of ceil(B/G) (SURVEY.md 8(e)), one handle per entry, every block enqueued
 # with gusto_solve_async so the GPUs run concurrently; the results come back in problem order.
 function solve_SCP_batch!(TOSs::Vector, TOPs::Vector, init_method=init_traj_straightline; max_iter=30, force=false, device=0, devices=nothing)
   TOP0 = TOPs[1]; model, N = TOP0.PD.model, TOP0.N
   n, m, B = model.x_dim, model.u_dim, length(TOPs)
-  all(T -> typeof(T.PD.model) == typeof(model) && T.N == N && T.PD.env === TOP0.PD.env, TOPs) ||
-    error("solve_SCP_batch!: all problems must share the model type, N and the environment")
+  all(T -> typeof(T.PD.model) == typeof(model) && T.N == N, TOPs) ||
+    error("solve_SCP_batch!: all problems must share the model type and N")
+  # every ProblemDefinition owns its env (types.jl:32-39): problems with different environments go through
+  # gusto_set_env_batch (one Workspace per problem), a batch sharing one env through gusto_set_env
+  same_env = all(T -> T.PD.env === TOP0.PD.env, TOPs)
+  envs = same_env ? nothing : [gusto_env_tables(T.PD.env) for T in TOPs]
   devs = devices === nothing ? [device] : collect(devices)
   G = length(devs); per = cld(B, G)
   boxes, spheres = gusto_env_tables(TOP0.PD.env)
@@ -63,17 +67,36 @@ function solve_SCP_batch!(TOSs::Vector, TOPs::Vector, init_method=init_traj_stra
                       h, sp, gusto_model_params(TOP0.PD.robot, model)), h, "set_params")
     gusto_check(ccall((:gusto_set_env, libgusto_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}),
                       h, length(boxes) ÷ 6, boxes, length(spheres) ÷ 4, spheres), h, "set_env")
+    if !same_env
+      nb = Cint[length(e[1]) ÷ 6 for e in envs[b0:b1]]; ns = Cint[length(e[2]) ÷ 4 for e in envs[b0:b1]]
+      bx = vcat((vec(e[1]) for e in envs[b0:b1])...); sx = vcat((vec(e[2]) for e in envs[b0:b1])...)
+      gusto_check(ccall((:gusto_set_env_batch, libgusto_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}),
+                        h, b1 - b0 + 1, nb, bx, ns, sx), h, "set_env_batch")
+    end
     gusto_check(ccall((:gusto_set_problems, libgusto_hip), Cint,
                       (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
                       h, b1 - b0 + 1, x0[:, b0:b1], lo[:, b0:b1], hi[:, b0:b1], tf[b0:b1], X0[:, :, b0:b1], U0[:, :, b0:b1]), h, "set_problems")
     gusto_check(ccall((:gusto_solve_async, libgusto_hip), Cint, (Ptr{Cvoid}, Cint, Cint), h, max_iter, force), h, "solve_async")
     push!(shards, (b0, b1, h))
   end
+  # the final gather of the multi-GPU path (north_star: "RCCL over xGMI for the final gather"; one process here, so direct
+  # peer copies): every shard to the first handle's GPU, one hop each over xGMI, then ONE copy to the host
+  Xall, Uall = zeros(n, N, B), zeros(m, N, B)
+  if length(shards) > 1
+    hs = Ptr{Cvoid}[h for (_, _, h) in shards]
+    gusto_check(ccall((:gusto_gather_peer, libgusto_hip), Cint,
+                      (Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cdouble}}, Ptr{Ptr{Cdouble}}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}),
+                      hs[1], length(hs), hs, C_NULL, C_NULL, Xall, Uall, C_NULL), hs[1], "gather_peer")
+  end
   for (b0, b1, h) in shards
     Bs = b1 - b0 + 1
     gusto_check(ccall((:gusto_wait, libgusto_hip), Cint, (Ptr{Cvoid},), h), h, "wait")
     X, U = zeros(n, N, Bs), zeros(m, N, Bs)
-    gusto_check(ccall((:gusto_get_traj, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), h, X, U), h, "get_traj")
+    if length(shards) > 1
+      X .= Xall[:, :, b0:b1]; U .= Uall[:, :, b0:b1]
+    else
+      gusto_check(ccall((:gusto_get_traj, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), h, X, U), h, "get_traj")
+    end
     its, conv, succ, stop = zeros(Cint, Bs), zeros(Cint, Bs), zeros(Cint, Bs), zeros(Cint, Bs)
     gusto_check(ccall((:gusto_get_status, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cvoid}),
                       h, its, conv, succ, stop, C_NULL), h, "get_status")

@@ -170,3 +170,23 @@ def astrobee_manifold_batch(B, first=0, tf=40.0, eps=1e-4):
         glo[i, :3] = ghi[i, :3] = pts[1]
         glo[i, 6:10], ghi[i, 6:10] = q - eps, q + eps
     return x0, glo, ghi, np.full(B, tf)
+
+
+# ---- batches whose problems bring their own obstacle layouts (north_star: "random initial states / obstacle layouts") ----
+def freeflyer_random_layouts(B, first=0, keep=0.6, sphere_prob=0.3):
+    """One keep-out set per problem: the four table slabs (always), each of the ten notebook boxes kept with probability
+    `keep`, and with probability `sphere_prob` one extra sphere (a disc for the planar model) of radius 0.10..0.20 m away
+    from start corner and goal.  Problem b draws from its own splitmix64 stream (seed 0xA0761D6478BD642F + first + b).
+    Returns (boxes_list, spheres_list): [n_box_b, 6] and [n_sph_b, 4] arrays."""
+    slabs, obs = table_stanford_boxes(), freeflyer_notebook_boxes()
+    boxes, spheres = [], []
+    for i in range(B):
+        g = splitmix64(0xA0761D6478BD642F + first + i)
+        sel = [o for o in obs if next(g) < keep]
+        boxes.append(np.vstack([slabs] + [o[None] for o in sel]) if sel else slabs.copy())
+        if next(g) < sphere_prob:
+            c = np.array([0.8 + 1.8 * next(g), 0.6 + 1.4 * next(g), 0.0])
+            spheres.append(np.array([[c[0], c[1], c[2], 0.10 + 0.10 * next(g)]]))
+        else:
+            spheres.append(np.zeros((0, 4)))
+    return boxes, spheres

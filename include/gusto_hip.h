@@ -64,6 +64,12 @@ typedef struct {
 } gusto_model_params;
 
 /* inner convex solver (stands in for the `kwarg...` forwarded to the optimizer, scp_gusto.jl:82-92) */
+/* tr_tol: slack of trust_region_satisfied_gusto.  The reference tests `max_k ||x_k - xp_k||^2 - Delta <= 0` (scp_gusto.jl:34-44)
+ * on the optimum its solver returns; whenever the trust region row is ACTIVE the left-hand side is zero up to the solver's
+ * accuracy, so the literal test is decided by the last digits of Ipopt / Gurobi (or of the interior point method here).
+ * This library evaluates `<= tr_tol * max(1, Delta)` with the DEFAULT tr_tol = 1e-6 (100 x the primal tolerance `tol`), which
+ * makes the verdict independent of solver noise; tr_tol = 0 selects the literal test (1 of the 44 844 accept / reject decisions
+ * of the 4096-problem freeflyerSE2 batch changes; tests/test_gpu_parity.py runs both settings against the oracle). */
 typedef struct {
     double tol, tol_acc, mu_floor, tr_tol;
     double mu_warm; /* complementarity of the centred start used from the second subproblem of an SCP run on (the
@@ -89,6 +95,13 @@ int gusto_set_ipm_opts(gusto_handle h, const gusto_ipm_opts* o);
 /* Workspace(robot, env) (types.jl:12-24): keep-out set = keepout_zones then obstacle_set, as AABBs
  * (min xyz, max xyz) followed by spheres (centre xyz, radius) */
 int gusto_set_env(gusto_handle h, int n_box, const double* box_min_max, int n_sph, const double* sph_c_r);
+/* One Workspace PER PROBLEM -- in the reference every ProblemDefinition owns its env (types.jl:32-39) and its
+ * Workspace(robot, env) (types.jl:12-24), so a batch may mix obstacle layouts.  Problem b has n_box[b] AABBs and n_sph[b]
+ * spheres (at most 64 components together); box_min_max / sph_c_r hold the tables of all B problems one after the other
+ * in problem order ([sum n_box][6], [sum n_sph][4]).  B must equal the B of gusto_set_problems by the time of the solve
+ * (either call may come first).  gusto_set_env returns the handle to one shared keep-out set. */
+int gusto_set_env_batch(gusto_handle h, int B, const int* n_box, const double* box_min_max, const int* n_sph,
+                        const double* sph_c_r);
 /* Longest-first schedule of a gusto_solve call (new; affects time only, results are bit-identical).  gusto_solve is ONE
  * launch of persistent workgroups that pull work from a device-side scheduler.  In batches of at least `min_batch`
  * problems the first `probe_iters` time slices of a problem are one SCP iteration each; between slices the problem
@@ -126,6 +139,14 @@ int gusto_last_solve_ms(gusto_handle h, double* ms);
 /* SCPS.traj (X,U) -- TOS.traj aliases it (traj_opt.jl:58) */
 int gusto_get_traj(gusto_handle h, double* X, double* U);
 int gusto_get_traj_dev(gusto_handle h, const double** X_dev, const double** U_dev);
+/* Final gather of a multi-GPU run from ONE host process (one handle per GPU, shards enqueued with gusto_solve_async): completes
+ * every source's solve and copies the shards, in the order of `src`, into buffers on the GPU of `dst` -- one direct peer copy
+ * per shard over xGMI (fan-in); `dst` may itself be one of the sources.  Outputs (any may be NULL): device
+ * pointers to X [B_total][N][x_dim] and U [B_total][N][u_dim] on dst's GPU (valid until the next gather on dst), host copies
+ * of the same, the number of problems.  New: the reference is one process, one problem.  (Between processes -- one rank per
+ * GPU -- the same gather runs over RCCL from the views of gusto_get_traj_dev: gusto.jl_amd/host.py gather_batch_results.) */
+int gusto_gather_peer(gusto_handle dst, int n_src, const gusto_handle* src, const double** X_dev, const double** U_dev,
+                      double* X_host, double* U_host, int* B_total);
 /* SCPS.iterations / converged / successful per problem, plus stop reason and inner iteration count */
 int gusto_get_status(gusto_handle h, int* iterations, int* converged, int* successful, int* stop_reason,
                      int* ipm_iters);

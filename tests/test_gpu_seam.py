@@ -140,3 +140,65 @@ def test_c_program_through_the_c_abi(tmp_path):
     xN = np.array([float(x) for x in v[p:p + 6]]); p += 6
     um = np.array([float(x) for x in v[p:p + 3]])
     assert np.abs(xN - P.FREEFLYER_X_GOAL).max() < 1e-7 and np.abs(um - r["U"][25]).max() < 1e-3
+
+
+def test_device_side_gather_of_two_handles():
+    """gusto_gather_peer (SURVEY.md 8(b) threading row, 8(e)): the final gather of a one-process multi-GPU run in the C ABI --
+    two handles (here on one GPU: the box has one) with shards of different sizes, solves still in flight when the gather
+    is called; host copies and the device views equal what each handle returns on its own.  Also a TrajOpt pair, whose
+    device rows (u | defect) are compacted to u_dim columns before they travel, and the error paths."""
+    env = P.freeflyer_env()
+    x0, glo, ghi, tf = P.freeflyer_batch(40)
+    a = g.BatchSolver(g.FREEFLYER_SE2, 50, 24, hist_cap=40, boxes=env)
+    b = g.BatchSolver(g.FREEFLYER_SE2, 50, 16, hist_cap=40, boxes=env)
+    a.set_problems(x0[:24], glo[:24], ghi[:24], tf[:24])
+    b.set_problems(x0[24:], glo[24:], ghi[24:], tf[24:])
+    a.solve_async(30)
+    b.solve_async(30)
+    X, U = a.gather_peer([a, b])                       # completes both solves
+    Xa, Ua = a.traj()
+    Xb, Ub = b.traj()
+    assert np.array_equal(X, np.concatenate([Xa, Xb])) and np.array_equal(U, np.concatenate([Ua, Ub]))
+    Xd, Ud = b.gather_peer([b, a], host=False)         # the other way round, device views
+    assert np.array_equal(Xd.cpu().numpy(), np.concatenate([Xb, Xa])) and np.array_equal(Ud.cpu().numpy(), np.concatenate([Ub, Ua]))
+    one = g.BatchSolver(g.FREEFLYER_SE2, 50, 40, hist_cap=40, boxes=env)
+    one.set_problems(x0, glo, ghi, tf)
+    one.solve(30)
+    assert np.array_equal(one.traj()[0], X)            # ... and what one handle solving the whole batch produces
+    # a handle of another horizon / without problems is refused
+    c = g.BatchSolver(g.FREEFLYER_SE2, 40, 4, hist_cap=40, boxes=env)
+    with pytest.raises(g.GustoError):
+        a.gather_peer([a, c])
+    # TrajOpt handles: U travels with the model's u_dim columns
+    ta = g.TrajOptSolver(g.FREEFLYER_SE2, 20, 3, boxes=env)
+    tb = g.TrajOptSolver(g.FREEFLYER_SE2, 20, 2, boxes=env)
+    ta.set_problems(x0[:3], glo[:3], ghi[:3], tf[:3])
+    tb.set_problems(x0[3:5], glo[3:5], ghi[3:5], tf[3:5])
+    ta.solve(10)
+    tb.solve(10)
+    Xt, Ut = ta.gather_peer([ta, tb])
+    assert Ut.shape == (5, 20, 3)
+    assert np.array_equal(Ut, np.concatenate([ta.traj()[1], tb.traj()[1]])) and np.array_equal(Xt, np.concatenate([ta.traj()[0], tb.traj()[0]]))
+    Xv, Uv = ta.traj_dev()                              # (the device view of a TrajOpt handle is the compact layout too)
+    assert np.array_equal(Uv.cpu().numpy(), ta.traj()[1])
+    with pytest.raises(g.GustoError):
+        a.gather_peer([a, ta])
+
+
+def test_trajopt_handle_is_refused_by_the_gusto_only_entry_points():
+    """gusto_subproblem / gusto_set_trust_state / gusto_get_history on a TrajOpt handle: GUSTO_ERR_STATE before any buffer is
+    touched (on such a handle the device rows of U are u_dim + x_dim wide: the caller's [B][N][u_dim] array would be over-read)."""
+    env = P.freeflyer_env()
+    x0, glo, ghi, tf = P.freeflyer_batch(2)
+    t = g.TrajOptSolver(g.FREEFLYER_SE2, 20, 2, boxes=env)
+    t.set_problems(x0, glo, ghi, tf)
+    Xp, Up = t.traj()
+    with pytest.raises(g.GustoError) as e:
+        g.BatchSolver.subproblem(t, Xp, Up, 3.0, 1.0, 0.4)
+    assert "-3" in str(e.value)
+    with pytest.raises(g.GustoError):
+        t.set_trust_state(3.0, 1.0)
+    with pytest.raises(g.GustoError):
+        g.BatchSolver.history(t)
+    Xq, Uq = t.traj()
+    assert np.array_equal(Xq, Xp) and np.array_equal(Uq, Up)      # nothing was overwritten

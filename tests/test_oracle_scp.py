@@ -195,3 +195,66 @@ def test_clearance_of_successful_trajectories():
         d = min(o.signed_distance(0, r["X"][k, :2], i)[0] for k in range(1, 50) for i in range(len(env)))
         assert d >= 0.05 - 1e-2 - 1e-3       # linearised rows within eps = 1e-2 (convex_ineq_satisfied)
     assert n_ok >= 6
+
+
+def test_dubins_trip0_failures_are_infeasible():
+    """Config 3 (dubins_car, B = 65 536) has a yield of ~0.65: part of the batch stops with SubproblemFailed.  The ones that
+    fail in their FIRST trip are certified here without the oracle's interior point method: the HARD rows of that
+    subproblem -- x_1 = x_init, x_N = goal, the trapezoid rows linearised at the straight-line guess (dubins_car.jl:134-146,
+    Jacobians by complex step of an independent f) and |u_k| <= 10 for k < N (dynamics.jl:73-81; u_N is free, the a10
+    quirk) -- form a linear feasibility problem, which HiGHS declares infeasible.  The penalised state box rows cannot make a
+    subproblem infeasible and are left out.  So `SubproblemFailed` at trip 0 is the right verdict of the reference's own
+    formulation (scp_gusto.jl:106-111 returns on such a solver status), not a weakness of the solver in oracle/."""
+    from scipy.optimize import linprog
+    N, n, m, tf, v, kk = 30, 3, 1, 10.0, 2.0, 1.0
+    dt = tf / (N - 1)
+    x0s, glo, ghi, tfs = P.dubins_batch(1200)
+    o = go.Oracle(go.DUBINS_CAR, N)
+    failures, feasible_checked = [], 0
+
+    def f(x, u):
+        return np.array([v * np.cos(x[2]), v * np.sin(x[2]), kk * u[0]])
+
+    def lp_feasible(b):
+        t = np.arange(N) / (N - 1)
+        Xp = (1 - t)[:, None] * x0s[b][None] + t[:, None] * glo[b][None]      # init_traj_straightline, dubins_car.jl:86-96
+        Up = np.zeros((N, m))
+        nz = n + m
+        Aeq, beq = [], []
+        for i in range(n):                                                   # x_1 = x_init, x_N = goal
+            r = np.zeros(N * nz); r[i] = 1; Aeq.append(r); beq.append(x0s[b][i])
+            r = np.zeros(N * nz); r[(N - 1) * nz + i] = 1; Aeq.append(r); beq.append(glo[b][i])
+        lin = []
+        for k in range(N):
+            A = np.zeros((n, n))
+            for j in range(n):
+                e = np.zeros(n, complex); e[j] = 1e-30j
+                A[:, j] = np.array([v * np.cos(Xp[k, 2] + e[2]), v * np.sin(Xp[k, 2] + e[2]), kk * Up[k, 0] + 0 * e[2]]).imag / 1e-30
+            Bm = np.array([[0.0], [0.0], [kk]])
+            lin.append((f(Xp[k], Up[k]) - A @ Xp[k] - Bm @ Up[k], A, Bm))
+        for k in range(1, N):                                                # (x_{k-1} - x_k) + dt/2 (lin_{k-1} + lin_k) = 0
+            (c0, A0, B0), (c1, A1, B1) = lin[k - 1], lin[k]
+            for i in range(n):
+                r = np.zeros(N * nz)
+                r[(k - 1) * nz + i] += 1; r[k * nz + i] -= 1
+                r[(k - 1) * nz:(k - 1) * nz + n] += 0.5 * dt * A0[i]; r[(k - 1) * nz + n] += 0.5 * dt * B0[i, 0]
+                r[k * nz:k * nz + n] += 0.5 * dt * A1[i]; r[k * nz + n] += 0.5 * dt * B1[i, 0]
+                Aeq.append(r); beq.append(-0.5 * dt * (c0[i] + c1[i]))
+        bounds = []
+        for k in range(N):
+            bounds += [(None, None)] * n + [(-10.0, 10.0) if k < N - 1 else (None, None)]
+        res = linprog(np.zeros(N * nz), A_eq=np.array(Aeq), b_eq=np.array(beq), bounds=bounds, method="highs")
+        return res.status       # 0 = feasible optimum found, 2 = infeasible
+
+    for b in range(len(x0s)):
+        o.set_problem(x0s[b], glo[b], ghi[b], tfs[b])
+        r = o.solve(1)
+        if r["stop_reason"] == 2 and r["iterations"] == 0:
+            failures.append(b)
+            assert lp_feasible(b) == 2, b                  # HiGHS: infeasible
+        elif feasible_checked < 16 and r["iterations"] == 1:
+            feasible_checked += 1
+            assert lp_feasible(b) == 0, b                  # ... and the certificate is not vacuous
+        if len(failures) >= 32 and feasible_checked >= 16:
+            break
+    assert len(failures) >= 32, len(failures)
