@@ -284,12 +284,12 @@ struct LdsLayout {
     int lc;     // offset of the linearisation cache (LdsC::LC_LDS: 2 doubles per knot), -1 if none
     int pp;     // offset of the packed P | Pi records (LdsC::PP_LDS: N + 1 records of PPS doubles), -1 if in the global workspace
 };
-template <int MODEL> inline LdsLayout make_lds_layout(int N) {
+template <int MODEL> inline LdsLayout make_lds_layout(int N, bool multi_wave = false) {
     using C1 = LdsC<MODEL, true>;
     using CM = LdsC<MODEL, false>;
     LdsLayout L;
     // (the TrajOpt variants run the multi-wave phases whatever N: their layout is the multi-wave one)
-    const bool one = N <= 64 && MT<MODEL>::NDEF == 0;
+    const bool one = N <= 64 && MT<MODEL>::NDEF == 0 && !multi_wave;
     L.total = (one ? C1::vecs : CM::vecs) + N * (C1::NVN * C1::n + C1::NVM * C1::m);
     L.phicl = -1; L.kd = -1;
     if (C1::KD_LDS && one) { L.kd = L.total; L.total += N * C1::KDS; }

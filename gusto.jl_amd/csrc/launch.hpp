@@ -10,6 +10,15 @@
 
 using namespace gusto;
 
+// waves per problem of the GuSTO kernel: one per 64 knots unless the caller (or GUSTO_DEV_WAVES) asks for more -- the generic
+// multi-wave phases then run with the extra waves splitting the entry-parallel sweeps (a latency / throughput trade for
+// batches smaller than the GPU)
+static inline int launch_waves(gusto_handle h) {
+    int w = h->waves;
+    if (const char* e = getenv("GUSTO_DEV_WAVES")) w = atoi(e);
+    const int need = (h->N + 63) / 64;
+    return std::min(4, std::max(w, need));
+}
 // ---- kernel dispatch ---------------------------------------------------------------------------------
 template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B, bool need_env = true) {
     using T = MT<MODEL>;
@@ -35,7 +44,7 @@ template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B, b
     P.ipm_it = h->d_ipm;
     P.tp = h->tp; P.to_mu = h->d_to_mu; P.to_xtol = h->d_to_xtol; P.to_ftol = h->d_to_ftol; P.to_ctol = h->d_to_ctol;
     P.wl = make_ws_layout<MODEL>(h->N, P.n_obs);
-    P.ll = make_lds_layout<MODEL>(h->N);
+    P.ll = make_lds_layout<MODEL>(h->N, launch_waves(h) > (h->N + 63) / 64);
     if (!h->d_queue) HIPCHK(h, dalloc(&h->d_queue, (size_t)SQ_WORDS));
 #ifdef GUSTO_PROFILE
     if (!h->d_prof) HIPCHK(h, dalloc(&h->d_prof, (size_t)h->batch_cap * PROF_N));
@@ -50,7 +59,7 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     int rc = fill_params<MODEL>(h, P, h->B);
     if (rc) return rc;
     P.mode = mode; P.max_iter = max_iter; P.force = force;
-    const int NT = 64 * ((h->N + 63) / 64);
+    const int NT = 64 * launch_waves(h);
     size_t lds = (size_t)P.ll.total * sizeof(double);
     if (const char* pad = getenv("GUSTO_DEV_LDS_KB")) lds = std::max(lds, (size_t)atoi(pad) * 1024);  // occupancy experiments
     if (lds > 160 * 1024) { h->err = "problem does not fit the 160 KiB LDS of a CU"; return GUSTO_ERR_ARG; }

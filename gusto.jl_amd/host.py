@@ -297,25 +297,31 @@ def solve_trajopt_hip(SCPS, SCPP, solver="hip", max_iter=125, force=False, devic
     bs.set_problems(SCPP.PD.x_init[None], lo[None], hi[None], [SCPP.tf_guess], SCPS.traj.X.T[None].copy(), SCPS.traj.U.T[None].copy())
     bs.solve(max_iter)
     X, U = bs.traj()
-    st, h = bs.status(), bs.history()
-    ns = int(st["iterations"][0])
-    SCPS.traj.X, SCPS.traj.U = X[0].T.copy(), U[0].T.copy()
-    SCPS.J_true = list(h["J_true"][0, :ns + 1])
-    SCPS.J_full = list(h["J_full"][0, :ns])
-    SCPS.convergence_measure = [0.0] + list(h["convergence_measure"][0, 1:ns + 1])
-    stop = int(st["stop_reason"][0])
-    SCPS.solver_status = [SOLVER_STATUS[int(v)] for v in h["solver_status"][0, :ns + 1 + (stop == 2)]]
-    SCPS.iterations, SCPS.converged, SCPS.successful = ns, bool(st["converged"][0]), False
-    SCPS.stop_reason = _capi.STOP_REASON[stop]
-    SCPS.dual = bs.dual()[0].copy()
-    SCPS.total_time += bs.last_solve_ms() * 1e-3
-    SCPS.iter_elapsed_times = [0.0] + [SCPS.total_time / max(1, ns)] * ns
-    SCPP.rho_vec, SCPP.s_vec = list(h["rho_vec"][0, :ns + 1]), list(h["s_vec"][0, :ns + 1])
-    SCPP.mu_vec = list(h["mu_vec"][0, :h["n_mu"][0]])
-    SCPP.xtol_vec, SCPP.ftol_vec = list(h["xtol_vec"][0, :h["n_xtol"][0]]), list(h["ftol_vec"][0, :h["n_ftol"][0]])
-    SCPP.ctol_vec = list(h["ctol_vec"][0, :h["n_ctol"][0]])
-    SCPP.obstacle_toggle_distance = SCPP.model_params.clearance + 1.0      # scp_trajopt.jl:64
+    _fill_trajopt_solution(SCPS, SCPP, dict(X=X, U=U, st=bs.status(), h=bs.history(), dual=bs.dual()), 0,
+                           bs.last_solve_ms() * 1e-3)
     SCPS._solver = bs
+
+
+def _fill_trajopt_solution(SCPS, SCPP, snap, b, elapsed):
+    """The vectors solve_trajopt_jump! pushes (scp_trajopt.jl:60-157) for problem b of a TrajOpt handle's snapshot."""
+    X, U, st, h = snap["X"], snap["U"], snap["st"], snap["h"]
+    ns = int(st["iterations"][b])
+    SCPS.traj.X, SCPS.traj.U = X[b].T.copy(), U[b].T.copy()
+    SCPS.J_true = list(h["J_true"][b, :ns + 1])
+    SCPS.J_full = list(h["J_full"][b, :ns])
+    SCPS.convergence_measure = [0.0] + list(h["convergence_measure"][b, 1:ns + 1])
+    stop = int(st["stop_reason"][b])
+    SCPS.solver_status = [SOLVER_STATUS[int(v)] for v in h["solver_status"][b, :ns + 1 + (stop == 2)]]
+    SCPS.iterations, SCPS.converged, SCPS.successful = ns, bool(st["converged"][b]), False
+    SCPS.stop_reason = _capi.STOP_REASON[stop]
+    SCPS.dual = snap["dual"][b].copy()
+    SCPS.total_time += elapsed
+    SCPS.iter_elapsed_times = [0.0] + [SCPS.total_time / max(1, ns)] * ns
+    SCPP.rho_vec, SCPP.s_vec = list(h["rho_vec"][b, :ns + 1]), list(h["s_vec"][b, :ns + 1])
+    SCPP.mu_vec = list(h["mu_vec"][b, :h["n_mu"][b]])
+    SCPP.xtol_vec, SCPP.ftol_vec = list(h["xtol_vec"][b, :h["n_xtol"][b]]), list(h["ftol_vec"][b, :h["n_ftol"][b]])
+    SCPP.ctol_vec = list(h["ctol_vec"][b, :h["n_ctol"][b]])
+    SCPP.obstacle_toggle_distance = SCPP.model_params.clearance + 1.0      # scp_trajopt.jl:64
 
 
 # ---- indirect shooting seeded by the SCP dual (src/shooting.jl, src/traj_opt.jl:4-45, src/types.jl:187-227) --------------
@@ -423,8 +429,9 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
     `devices` = list of GPU ordinals: the problems are sharded in contiguous blocks (shard_bounds) over
     one handle per entry, every shard is enqueued with gusto_solve_async and the shards run concurrently -- the
     single-process form of the multi-GPU path (an ordinal may repeat: two shards on one GPU overlap like two batches)."""
-    if solve_method not in (None, solve_gusto_hip):
-        raise NotImplementedError("solve_SCP_batch! runs the batched GuSTO kernels: solve_method must be solve_gusto_hip")
+    if solve_method not in (None, solve_gusto_hip, solve_trajopt_hip):
+        raise NotImplementedError("solve_SCP_batch! runs the batched kernels: solve_method must be solve_gusto_hip or solve_trajopt_hip")
+    trajopt = solve_method is solve_trajopt_hip
     if len(TOSs) != len(TOPs) or not TOPs:
         raise ValueError("solve_SCP_batch!: need as many solutions as problems, at least one")
     TOP0 = TOPs[0]
@@ -454,12 +461,21 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
         b0, b1 = shard_bounds(B, len(devs), r)
         if b1 <= b0:
             continue
-        bs = BatchSolver(model.model_id, N, b1 - b0, hist_cap=_hist_cap(max_iter), device=dv,
-                         boxes=TOP0.PD.env.boxes, spheres=TOP0.PD.env.spheres, scp_params=sp, model_params=mp)
+        if trajopt:     # the second algorithm behind the seam (scp_trajopt.jl:33): one gusto_solve_trajopt per shard
+            tp = _capi.default_trajopt_params(model.model_id)
+            total = tp.max_penalty_iteration * tp.max_convex_iteration * tp.max_trust_iteration
+            bs = _capi.TrajOptSolver(model.model_id, N, b1 - b0, hist_cap=2 * total + 16, device=dv, boxes=TOP0.PD.env.boxes,
+                                     spheres=TOP0.PD.env.spheres, model_params=mp, trajopt_params=tp)
+        else:
+            bs = BatchSolver(model.model_id, N, b1 - b0, hist_cap=_hist_cap(max_iter), device=dv,
+                             boxes=TOP0.PD.env.boxes, spheres=TOP0.PD.env.spheres, scp_params=sp, model_params=mp)
         if not same_env:
             bs.set_env_batch([t.PD.env.boxes for t in TOPs[b0:b1]], [t.PD.env.spheres for t in TOPs[b0:b1]])
         bs.set_problems(x0[b0:b1], lo[b0:b1], hi[b0:b1], tf[b0:b1], X0[b0:b1], U0[b0:b1])
-        bs.solve_async(max_iter, force)
+        if trajopt:
+            bs.solve(max_iter)          # (gusto_solve_trajopt is synchronous: the shards of a TrajOpt batch run one after the other)
+        else:
+            bs.solve_async(max_iter, force)
         shards.append((b0, b1, bs))
     out = [None] * B
     gathered = None
@@ -474,7 +490,7 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
         for b in range(b0, b1):
             SCPP = SCPProblem(TOPs[b])
             SCPS = SCPSolution(SCPP, inits[b])
-            _fill_solution(SCPS, SCPP, snap, b - b0, per)
+            (_fill_trajopt_solution if trajopt else _fill_solution)(SCPS, SCPP, snap, b - b0, per)
             TOSs[b].traj, TOSs[b].SCPS = SCPS.traj, SCPS
             out[b] = SCPS
     return out

@@ -189,3 +189,33 @@ def test_through_the_seam_and_error_paths():
     small.set_problems(x0, glo, ghi, tf)
     with pytest.raises(g.GustoError):
         small.solve(125)                           # hist_cap below the schedule's needs: refused, not truncated
+
+
+def test_batch_through_the_seam_and_handle_reuse():
+    """solve_SCP_batch!(TOSs, TOPs, solve_trajopt_hip!, ...): one gusto_solve_trajopt for the list (also sharded over two
+    handles) gives what solve_SCP! gives problem by problem; a second solve_trajopt_hip! on the same SCPSolution re-uses
+    its handle (no new device allocation per call) and, like solve_trajopt_jump!, starts the schedule again from SCPS.traj."""
+    x0, glo, ghi, tf = P.freeflyer_batch(5)
+    TOPs = []
+    for b in range(5):
+        model = H.FreeflyerSE2()
+        gs = H.GoalSet()
+        H.add_goal(gs, H.Goal(H.PointGoal(glo[b]), tf[b], model))
+        TOPs.append(H.TrajectoryOptimizationProblem(H.ProblemDefinition(H.Robot(), model, H.Environment(P.freeflyer_env()), x0[b], gs),
+                                                    30, tf[b], fixed_final_time=True))
+    ones = [H.solve_SCP(H.TrajectoryOptimizationSolution(t), t, H.solve_trajopt_hip, H.init_traj_straightline, "hip", max_iter=125)
+            for t in TOPs]
+    for devices in (None, [0, 0]):
+        TOSs = [H.TrajectoryOptimizationSolution(t) for t in TOPs]
+        out = H.solve_SCP_batch(TOSs, TOPs, H.solve_trajopt_hip, H.init_traj_straightline, "hip", max_iter=125, devices=devices)
+        for b in range(5):
+            assert out[b].iterations == ones[b].iterations and out[b].converged == ones[b].converged
+            assert np.array_equal(out[b].traj.X, ones[b].traj.X) and np.array_equal(out[b].traj.U, ones[b].traj.U)
+            assert out[b].SCPP.mu_vec == ones[b].SCPP.mu_vec and out[b].SCPP.s_vec == ones[b].SCPP.s_vec
+            assert TOSs[b].traj is out[b].traj and out[b].traj.U.shape == (3, 30)
+    S = ones[0]
+    handle = S._solver
+    n1 = S.iterations
+    H.solve_trajopt_hip(S, S.SCPP, "hip", 125)
+    assert S._solver is handle and S.iterations > 0 and len(S.J_true) == S.iterations + 1
+    assert n1 > 0

@@ -69,4 +69,14 @@ for m, cfg in ((2, "config4_astrobee_se3"), (3, "config5_manifold")):
     f = os.path.join(src, f"stats_m{m}", "stats_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_{cfg}.csv"))
+for name in ("config3", "config4", "config5", "trajopt_config2"):       # tools/pmc_config.py summaries (profile_round.sh)
+    f = os.path.join(src, f"pmc_{name}.json")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, f"{tag}_pmc_{name}.json"))
+for d_, name in (("stats_c3", "kernel_stats_config3_dubins.csv"), ("stats_trajopt", "kernel_stats_trajopt_freeflyer.csv")):
+    f = os.path.join(src, d_, "stats_kernel_stats.csv")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, f"{tag}_{name}"))
+if os.path.exists(os.path.join(src, "bench_trajopt.json")):
+    shutil.copy(os.path.join(src, "bench_trajopt.json"), os.path.join(dst, f"{tag}_bench_trajopt.json"))
 print(json.dumps({k: v for k, v in out.items() if k != "calibration"}, indent=1))

@@ -21,6 +21,20 @@ done
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc -o $c -- python tools/pmc_probe.py > $OUT/pmc_$c.log 2>&1
 done
+# HBM traffic of the other BASELINE configs and of TrajOpt: two --pmc passes each, summarised by tools/pmc_config.py
+for w in "3 gusto" "4 gusto" "5 gusto" "2 trajopt"; do
+  set -- $w
+  D=$OUT/pmc_c$1_$2; mkdir -p $D
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $D -o $c -- python tools/pmc_probe.py $1 $2 > $D/$c.log 2>&1
+    f=$(find $D -name "${c}_counter_collection.csv" | head -1); [ -n "$f" ] && [ "$f" != "$D/${c}_counter_collection.csv" ] && cp "$f" $D/${c}_counter_collection.csv
+  done
+  name=$([ $2 = trajopt ] && echo trajopt_config$1 || echo config$1)
+  python tools/pmc_config.py $D $OUT/pmc_$name.json > $D/summary.log 2>&1
+done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -o stats -- python bench.py --config 3 --steps 4 --warmup 1 --no-extras --no-cpu-baseline > $OUT/stats_c3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_trajopt -o stats -- python bench.py --algo trajopt --steps 6 --warmup 1 --no-extras --no-cpu-baseline > $OUT/stats_trajopt.log 2>&1
+timeout 600 python bench.py --algo trajopt > $OUT/bench_trajopt.json 2>> $OUT/bench.err
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
