@@ -84,7 +84,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(_ROOT, "include"), "-fPIC",
              "-Wno-unused-value", "-Wno-pass-failed"]
-    units = ["gusto_hip", "shoot", "model_0", "model_1", "model_2", "model_3", "model_4", "model_5"]
+    units = ["gusto_hip", "shoot", "model_0", "model_1", "model_2", "model_3", "model_4", "model_5", "model_6"]
     bdir = os.path.join(_HERE, "build")
     os.makedirs(bdir, exist_ok=True)
 
@@ -399,7 +399,7 @@ class BatchSolver:
 
 class TrajOptSolver(BatchSolver):
     """A gusto_handle created by gusto_create_trajopt: the TrajOpt algorithm (src/scp/scp_trajopt.jl) for a batch of problems
-    of FreeflyerSE2 or AstrobeeSE3.  set_env / set_problems / traj / status / dual / last_solve_ms as for BatchSolver."""
+    of FreeflyerSE2, AstrobeeSE3 or AstrobeeSE3Manifold.  set_env / set_problems / traj / status / dual / last_solve_ms as for BatchSolver."""
 
     def __init__(self, model, N, batch_cap, hist_cap=272, device=0, boxes=None, spheres=None, model_params=None,
                  trajopt_params=None, ipm_opts=None):

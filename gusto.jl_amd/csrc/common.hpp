@@ -49,7 +49,7 @@ constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5,
 // controls (u_k, d_k), d_k = the n defect variables of the interval (k, k+1) -- the L1-penalised dynamics.  In the LQR form
 // of the Newton system a defect moves y_k = F_k x_k + b_k u_k + d_k directly (Gam_d = I) and not x_k (b_d = 0); MT::NDEF
 // marks the few places that differ (ipm.hpp).  They run the generic multi-wave phases (one wave of them for N <= 64).
-constexpr int GUSTO_TO_FREEFLYER_SE2 = 4, GUSTO_TO_ASTROBEE_SE3 = 5;
+constexpr int GUSTO_TO_FREEFLYER_SE2 = 4, GUSTO_TO_ASTROBEE_SE3 = 5, GUSTO_TO_ASTROBEE_SE3_MANIFOLD = 6;
 // vanishing quadratic cost on the defects next to their L1 penalty (the oracle's GO_TRAJOPT_DEFECT_REG)
 constexpr double TRAJOPT_DEFECT_REG = 1e-4;
 template <int MODEL> struct MT;
@@ -170,6 +170,24 @@ template <> struct MT<GUSTO_TO_ASTROBEE_SE3> {
     static constexpr bool Gnz(int i, int j) { return j < G::m ? G::Gnz(i, j) : i == j - G::m; }
     static constexpr bool Hnz(int, int) { return true; }   // (the hard trust region row couples every pair of states)
 };
+
+template <> struct MT<GUSTO_TO_ASTROBEE_SE3_MANIFOLD> {
+    using G = MT<GUSTO_ASTROBEE_SE3_MANIFOLD>;
+    // fixed state rows of a knot: the +- band of the (hard) quaternion norm row, orientation sign, speed, rate
+    static constexpr int NDEF = 13, n = 13, m = 6 + NDEF, WS = 3, NFIX = 5, NHU = 2 + 2 * NDEF;
+    static constexpr int WAVES_PER_EU = 1, SCHED_PROBE = 0, SCHED_SLICE = 0;
+    static constexpr bool SWEEP_CALL = false, MFMA = false, LTI = false, HAS_OBS = true, PG2 = false;
+    static constexpr int pg_r0(int) { return 0; }
+    static constexpr int pg_r1(int) { return 0; }
+    static constexpr bool Anz(int i, int j) { return G::Anz(i, j); }
+    static constexpr bool Mnz(int i, int j) { return G::Mnz(i, j); }
+    static constexpr bool Bnz(int i, int j) { return j < G::m && G::Bnz(i, j); }
+    static constexpr bool Gnz(int i, int j) { return j < G::m ? G::Gnz(i, j) : i == j - G::m; }
+    static constexpr bool Hnz(int, int) { return true; }
+};
+// TrajOpt keeps convex_state_eq rows hard (scp_trajopt.jl:200-208): the manifold model's linearised quaternion norm is carried
+// as the hard band |h_k| <= 1e-4 -- the width of the notebook's own BoxGoal on the goal quaternion (the oracle's GO_TRAJOPT_EQ_BAND)
+constexpr double TRAJOPT_EQ_BAND = 1e-4;
 
 // symmetric packed index (upper triangle, row-major)
 GD constexpr int sidx(int i, int j, int n) {

@@ -98,8 +98,8 @@ static int create_impl(gusto_handle* out, int model, int N, int batch_cap, int h
         g_err = "gusto_create: no usable HIP device (libgusto_hip has no CPU fallback)";
         return GUSTO_ERR_NO_DEVICE;
     }
-    if (trajopt && model != GUSTO_FREEFLYER_SE2 && model != GUSTO_ASTROBEE_SE3) {
-        g_err = "gusto_create_trajopt: FreeflyerSE2 and AstrobeeSE3 have a TrajOpt variant";
+    if (trajopt && model != GUSTO_FREEFLYER_SE2 && model != GUSTO_ASTROBEE_SE3 && model != GUSTO_ASTROBEE_SE3_MANIFOLD) {
+        g_err = "gusto_create_trajopt: FreeflyerSE2, AstrobeeSE3 and AstrobeeSE3Manifold have a TrajOpt variant";
         return GUSTO_ERR_ARG;
     }
     gusto_handle h = new gusto_handle_s();
@@ -107,7 +107,8 @@ static int create_impl(gusto_handle* out, int model, int N, int batch_cap, int h
     h->model_pub = model; h->m_pub = m; h->trajopt = trajopt;
     gusto_default_params(model, &h->sp, &h->mp);
     if (trajopt) {   // internal variant: controls (u, d), d = the n defect variables of a knot
-        h->model = model == GUSTO_FREEFLYER_SE2 ? gusto::GUSTO_TO_FREEFLYER_SE2 : gusto::GUSTO_TO_ASTROBEE_SE3;
+        h->model = model == GUSTO_FREEFLYER_SE2 ? gusto::GUSTO_TO_FREEFLYER_SE2
+                 : (model == GUSTO_ASTROBEE_SE3 ? gusto::GUSTO_TO_ASTROBEE_SE3 : gusto::GUSTO_TO_ASTROBEE_SE3_MANIFOLD);
         h->m = m = m + n;
         gusto_default_trajopt_params(model, &h->tp);
     }
@@ -143,8 +144,8 @@ int gusto_create(gusto_handle* out, int model, int N, int batch_cap, int hist_ca
 int gusto_create_trajopt(gusto_handle* out, int model, int N, int batch_cap, int hist_cap, int device) {
     return create_impl(out, model, N, batch_cap, hist_cap, device, true);
 }
-int gusto_default_trajopt_params(int model, gusto_trajopt_params* tp) {   // freeflyer_se2.jl:49-64, astrobee_se3.jl:50-65
-    if (!tp || (model != GUSTO_FREEFLYER_SE2 && model != GUSTO_ASTROBEE_SE3)) return GUSTO_ERR_ARG;
+int gusto_default_trajopt_params(int model, gusto_trajopt_params* tp) {   // freeflyer_se2.jl:49-64, astrobee_se3.jl:50-65, astrobee_se3_manifold.jl:56-70
+    if (!tp || (model != GUSTO_FREEFLYER_SE2 && model != GUSTO_ASTROBEE_SE3 && model != GUSTO_ASTROBEE_SE3_MANIFOLD)) return GUSTO_ERR_ARG;
     memset(tp, 0, sizeof(*tp));
     tp->mu0 = 1.0; tp->c = 10.0; tp->tau_plus = 2.0; tp->tau_minus = 0.5; tp->k = 5.0; tp->ftol = 0.01; tp->ctol = 0.01;
     tp->max_penalty_iteration = 5; tp->max_convex_iteration = 5; tp->max_trust_iteration = 5;
@@ -270,6 +271,7 @@ static int do_init(gusto_handle h, bool straight) {
     case 3: return gusto_launch_init_m3(h, straight);
     case 4: return gusto_launch_init_m4(h, straight);
     case 5: return gusto_launch_init_m5(h, straight);
+    case 6: return gusto_launch_init_m6(h, straight);
     }
     return GUSTO_ERR_ARG;
 }
@@ -277,6 +279,7 @@ static int do_trajopt(gusto_handle h, int mode, int max_iter) {
     switch (h->model) {
     case 4: return gusto_launch_trajopt_m4(h, mode, max_iter);
     case 5: return gusto_launch_trajopt_m5(h, mode, max_iter);
+    case 6: return gusto_launch_trajopt_m6(h, mode, max_iter);
     }
     h->err = "not a TrajOpt handle (gusto_create_trajopt)";
     return GUSTO_ERR_STATE;

@@ -124,3 +124,5 @@ int gusto_launch_init_m4(gusto_handle h, bool straight);
 int gusto_launch_init_m5(gusto_handle h, bool straight);
 int gusto_launch_trajopt_m4(gusto_handle h, int mode, int max_iter);
 int gusto_launch_trajopt_m5(gusto_handle h, int mode, int max_iter);
+int gusto_launch_init_m6(gusto_handle h, bool straight);
+int gusto_launch_trajopt_m6(gusto_handle h, int mode, int max_iter);

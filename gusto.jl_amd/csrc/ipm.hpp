@@ -210,7 +210,8 @@ GD void stage_M(const gusto_model_params& mp, XP xp, UP up, double h, double* M,
     for (int i = 0; i < n; i++)
 #pragma unroll
         for (int j = 0; j < n; j++) G[i * n + j] = (i == j ? 1.0 : 0.0) - h * A[i * n + j];
-    if constexpr (MODEL == GUSTO_ASTROBEE_SE3 || MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD || MODEL == GUSTO_TO_ASTROBEE_SE3) {
+    if constexpr (MODEL == GUSTO_ASTROBEE_SE3 || MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD || MODEL == GUSTO_TO_ASTROBEE_SE3 ||
+                  MODEL == GUSTO_TO_ASTROBEE_SE3_MANIFOLD) {
         // x = (r, v, attitude a, w): G = I - hA = [I -hI 0 0; 0 I 0 0; 0 0 P Q; 0 0 0 W] (Anz), so
         // M = G^-1 = [I hI 0 0; 0 I 0 0; 0 0 P^-1 -P^-1 Q W^-1; 0 0 0 W^-1]: two small inverses instead of a
         // pivoted 12 x 24 / 13 x 26 elimination in registers (which was most of this phase for these models)

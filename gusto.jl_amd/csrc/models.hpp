@@ -229,6 +229,7 @@ template <int MODEL, int BASE> struct DynTO {
 };
 template <> struct Dyn<GUSTO_TO_FREEFLYER_SE2> : DynTO<GUSTO_TO_FREEFLYER_SE2, GUSTO_FREEFLYER_SE2> {};
 template <> struct Dyn<GUSTO_TO_ASTROBEE_SE3> : DynTO<GUSTO_TO_ASTROBEE_SE3, GUSTO_ASTROBEE_SE3> {};
+template <> struct Dyn<GUSTO_TO_ASTROBEE_SE3_MANIFOLD> : DynTO<GUSTO_TO_ASTROBEE_SE3_MANIFOLD, GUSTO_ASTROBEE_SE3_MANIFOLD> {};
 
 typedef const __attribute__((address_space(4))) double cdouble;
 GD const cdouble* as_constant(const double* p) { return (const cdouble*)(uintptr_t)p; }

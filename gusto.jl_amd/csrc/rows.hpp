@@ -97,9 +97,24 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
         // TrajOpt subproblem (scp_trajopt.jl:159-279): the same registry treated differently -- state trust region HARD
         // (||x - xp||^2 - s <= 0, :165-173; c.Delta = s, normalised by s), state, obstacle AND control rows L1-penalised with
         // weight mu (:222-235; c.omega = mu), the dynamics as mu |d_kj| on the defect controls (:257-275, the pair +-mu d <= v)
-        constexpr bool is2 = MODEL == GUSTO_TO_FREEFLYER_SE2;
-        constexpr int nv = is2 ? 2 : 3, iw = is2 ? 5 : 9, nw = is2 ? 1 : 3, m0 = T::m - T::NDEF;
-        quad_row<false, 0, n>(op, 0, ROW_HARD, xs, one, c.xp, -c.Delta, 1.0 / c.Delta, 0.0);
+        constexpr bool is2 = MODEL == GUSTO_TO_FREEFLYER_SE2, man = MODEL == GUSTO_TO_ASTROBEE_SE3_MANIFOLD;
+        constexpr int nv = is2 ? 2 : 3, iw = is2 ? 5 : (man ? 10 : 9), nw = is2 ? 1 : 3, m0 = T::m - T::NDEF;
+        if constexpr (!man) {
+            quad_row<false, 0, n>(op, 0, ROW_HARD, xs, one, c.xp, -c.Delta, 1.0 / c.Delta, 0.0);
+        } else {
+            // the manifold model registers no trust region row (astrobee_se3_manifold.jl:601); its convex_state_eq row, the
+            // linearised quaternion norm (:308-313), is HARD in TrajOpt (scp_trajopt.jl:200-208): the band |h| <= TRAJOPT_EQ_BAND;
+            // csi_orientation_sign (:316-319) is penalised like every convex_state_ineq row
+            const double* qp = c.xp + 6;
+            const double qn = sqrt(qp[0] * qp[0] + qp[1] * qp[1] + qp[2] * qp[2] + qp[3] * qp[3]);
+            double bp[4], bm[4], c0 = qn - 1.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { bp[j] = qp[j] / qn; bm[j] = -bp[j]; c0 -= qp[j] * qp[j] / qn; }
+            lin_row<false, 6, 4>(op, 0, ROW_HARD, xs, bm, -c0, 1.0, TRAJOPT_EQ_BAND);
+            lin_row<false, 6, 4>(op, 3, ROW_HARD, xs, bp, c0, 1.0, TRAJOPT_EQ_BAND);
+            const double m1 = -1.0;
+            lin_row<false, 6, 1>(op, 4, ROW_PEN, xs, &m1, 0.0, kw, 0.0);
+        }
         quad_row<false, 3, nv>(op, 1, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
         quad_row<false, iw, nw>(op, 2, ROW_PEN, xs, one, nullptr, -mp.hard_limit_omega * mp.hard_limit_omega, kw, 0.0);
         uint64_t mk = c.mask;

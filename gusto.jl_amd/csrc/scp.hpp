@@ -470,8 +470,8 @@ template <int MODEL, class BLK> GD double trajopt_ratio(BLK& K, const double* X,
 template <int MODEL, class BLK> GD double trajopt_ctol(BLK& K, const double* X, const double* U, const double* Xq, const double* Uq) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m;
-    constexpr bool is2 = MODEL == GUSTO_TO_FREEFLYER_SE2;
-    constexpr int nv = is2 ? 2 : 3, iw = is2 ? 5 : 9, nw = is2 ? 1 : 3;
+    constexpr bool is2 = MODEL == GUSTO_TO_FREEFLYER_SE2, man = MODEL == GUSTO_TO_ASTROBEE_SE3_MANIFOLD;
+    constexpr int nv = is2 ? 2 : 3, iw = is2 ? 5 : (man ? 10 : 9), nw = is2 ? 1 : 3;
     const int k = K.tid, N = K.N;
     const gusto_model_params& mp = K.P.mp;
     double JN = 0, JD = 0;
@@ -481,6 +481,14 @@ template <int MODEL, class BLK> GD double trajopt_ctol(BLK& K, const double* X, 
     double x[n], q[n];
 #pragma unroll
     for (int i = 0; i < n; i++) { x[i] = (k < N) ? X[k * n + i] : 0.0; q[i] = (k < N) ? Xq[k * n + i] : 0.0; }
+    if constexpr (man) {   // csi_orientation_sign (-qw) and cse_quaternion_norm(traj, traj) = |q_k| - 1 (manifold.jl:308-319)
+        cls(k < N ? fabs(-x[6] + q[6]) : 0.0, k < N ? fabs(-x[6]) : 0.0);
+        double a = 0, b = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { a += x[6 + j] * x[6 + j]; b += q[6 + j] * q[6 + j]; }
+        const double g = sqrt(a) - 1.0, gq = sqrt(b) - 1.0;
+        cls(k < N ? fabs(g - gq) : 0.0, k < N ? fabs(g) : 0.0);
+    }
     {   // csi_translational_velocity_bound, csi_angular_velocity_bound
         double g = -mp.hard_limit_vel * mp.hard_limit_vel, gq = g;
 #pragma unroll

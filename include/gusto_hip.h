@@ -200,8 +200,9 @@ int gusto_subproblem(gusto_handle h, int B, const double* Xp, const double* Up, 
 
 /* ---- TrajOpt: solve_trajopt_jump!(SCPS, SCPP, solver, max_iter, force) (src/scp/scp_trajopt.jl:33-157), the second SCP
  * algorithm the reference passes through the same `solve_method!` argument of solve_SCP! (src/traj_opt.jl:47-72) ----------
- * FreeflyerSE2 and AstrobeeSE3 (the models of this library with a SCPParam_TrajOpt: freeflyer_se2.jl:49-64,
- * astrobee_se3.jl:50-65).  A TrajOpt handle is a gusto_handle created by gusto_create_trajopt: gusto_set_env,
+ * FreeflyerSE2, AstrobeeSE3 and AstrobeeSE3Manifold (the models of this library with a SCPParam_TrajOpt: freeflyer_se2.jl:49-64,
+ * astrobee_se3.jl:50-65, astrobee_se3_manifold.jl:56-70; the manifold model has no trust region row, and its quaternion
+ * norm row -- a convex_state_eq row, hard in TrajOpt, scp_trajopt.jl:200-208 -- is carried as the hard band |h| <= 1e-4).  A TrajOpt handle is a gusto_handle created by gusto_create_trajopt: gusto_set_env,
  * gusto_set_problems(_dev), gusto_get_traj, gusto_get_status, gusto_get_dual, gusto_last_solve_ms work on it unchanged
  * (U has the model's u_dim columns on the host side).  Where the file cannot run as written the math it states is built;
  * the list is in DESIGN.md section 4 (intended L1 dynamics penalty, hard x_1 = x_init, index typos of

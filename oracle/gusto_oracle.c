@@ -27,6 +27,12 @@
  * L1 term alone leaves a defect that is off its kink without curvature, the Newton systems of the interior point method
  * then lose the goal rows at complementarity 1e-9 (LP-like degeneracy).  DESIGN.md section 4. */
 #define GO_TRAJOPT_DEFECT_REG 1e-4
+/* TrajOpt keeps convex_state_eq rows HARD (`== 0`, scp_trajopt.jl:200-208).  The only such row of the library's models is the
+ * manifold model's linearised quaternion norm, one row per knot on x_k alone; the interior point method carries it as the
+ * hard band |h_k| <= 1e-4 (two hard inequality rows): the width the notebook itself uses when it writes the equality on the
+ * goal quaternion as a BoxGoal of +-1e-4 (examples/astrobeeSE3manifold.ipynb cell 1).  1e-6 was tried: the barrier weights
+ * lambda / t ~ 1e8 on the quaternion block then break the Cholesky of the condensed stage Hessians in 2 of 3 problems. */
+#define GO_TRAJOPT_EQ_BAND 1e-4
 #define ROW_HARD 0     /* hard inequality  (scp_gusto.jl:213-221, 236-245)                  */
 #define ROW_PEN 1      /* L1-penalised state inequality, part of the post-check (:281-295)  */
 #define ROW_PEN_TR 2   /* L1-penalised trust region (:265-279), not part of the post-check  */
@@ -641,9 +647,26 @@ static void assemble_rows_trajopt(go_problem* p, const double* Xp, double s_tr, 
         p->row_start[k] = p->nrows;
         const double* xp = Xp + k * n;
         go_row* r;
-        r = new_row(p, k, 0, ROW_HARD);   /* stri_state_trust_region - s <= 0, normalised by s */
-        for (int j = 0; j < n; j++) row_add(r, j, 1.0, xp[j], 0.0);
-        r->c0 = -s_tr; r->mul = 1.0 / s_tr;
+        if (!man) {   /* (the manifold model registers no state_trust_region_ineq row: astrobee_se3_manifold.jl:601) */
+            r = new_row(p, k, 0, ROW_HARD);   /* stri_state_trust_region - s <= 0, normalised by s */
+            for (int j = 0; j < n; j++) row_add(r, j, 1.0, xp[j], 0.0);
+            r->c0 = -s_tr; r->mul = 1.0 / s_tr;
+        } else {
+            /* cse_quaternion_norm (manifold.jl:308-313), a convex_state_eq row: hard `== 0` here (:200-208), as the band
+             * |h| <= GO_TRAJOPT_EQ_BAND (above);  csi_orientation_sign (:316-319) penalised like every convex_state_ineq row */
+            double qn = sqrt(xp[6] * xp[6] + xp[7] * xp[7] + xp[8] * xp[8] + xp[9] * xp[9]);
+            double c0 = qn - 1.0;
+            for (int j = 0; j < 4; j++) c0 -= xp[6 + j] * xp[6 + j] / qn;
+            r = new_row(p, k, 0, ROW_HARD);
+            for (int j = 0; j < 4; j++) row_add(r, 6 + j, 0.0, 0.0, -xp[6 + j] / qn);
+            r->c0 = -c0; r->mul = 1.0; r->off = GO_TRAJOPT_EQ_BAND;
+            r = new_row(p, k, 0, ROW_HARD);
+            for (int j = 0; j < 4; j++) row_add(r, 6 + j, 0.0, 0.0, xp[6 + j] / qn);
+            r->c0 = c0; r->mul = 1.0; r->off = GO_TRAJOPT_EQ_BAND;
+            r = new_row(p, k, 0, ROW_PEN);
+            row_add(r, 6, 0.0, 0.0, -1.0);
+            r->mul = kappa * mu;
+        }
         r = new_row(p, k, 0, ROW_PEN);    /* csi_translational_velocity_bound */
         for (int j = 0; j < nv; j++) row_add(r, 3 + j, 1.0, 0.0, 0.0);
         r->c0 = -mp->hard_limit_vel * mp->hard_limit_vel; r->mul = kappa * mu;
@@ -1766,11 +1789,11 @@ void go_default_trajopt_params(int model, go_trajopt_params* tp) {
     tp->mu0 = 1.0; tp->c = 10.0; tp->tau_plus = 2.0; tp->tau_minus = 0.5; tp->k = 5.0; tp->ftol = 0.01; tp->ctol = 0.01;
     tp->max_penalty_iteration = 5; tp->max_convex_iteration = 5; tp->max_trust_iteration = 5;
     if (model == GO_FREEFLYER_SE2) { tp->s0 = 1.0; tp->xtol = 0.1; }   /* freeflyer_se2.jl:49-64 */
-    else { tp->s0 = 10.0; tp->xtol = 0.01; }                            /* astrobee_se3.jl:50-65  */
+    else { tp->s0 = 10.0; tp->xtol = 0.01; }                            /* astrobee_se3.jl:50-65, astrobee_se3_manifold.jl:56-70 */
 }
 go_problem* go_create_trajopt(int model, int N, const go_model_params* mp, const go_trajopt_params* tp, int n_box,
                               const double* box, int n_sph, const double* sph) {
-    if (model != GO_FREEFLYER_SE2 && model != GO_ASTROBEE_SE3) return NULL;
+    if (model != GO_FREEFLYER_SE2 && model != GO_ASTROBEE_SE3 && model != GO_ASTROBEE_SE3_MANIFOLD) return NULL;
     go_scp_params sp; go_model_params dmp;
     go_default_params(model, &sp, &dmp);
     go_problem* p = create_impl(model, N, &sp, mp ? mp : &dmp, n_box, box, n_sph, sph, 1);
@@ -1843,8 +1866,22 @@ static void defect_true(go_problem* p, const double* X, const double* U, int k, 
 }
 double go_trajopt_ctol(go_problem* p, const double* X, const double* U, const double* Xp, const double* Up) {
     const int n = p->n, N = p->N;
-    const int is2 = p->model == GO_FREEFLYER_SE2, nv = is2 ? 2 : 3, iw = is2 ? 5 : 9, nw = is2 ? 1 : 3;
+    const int is2 = p->model == GO_FREEFLYER_SE2, man = p->model == GO_ASTROBEE_SE3_MANIFOLD;
+    const int nv = is2 ? 2 : 3, iw = is2 ? 5 : (man ? 10 : 9), nw = is2 ? 1 : 3;
     double JN = 0, JD = 0, tn, td;
+    if (man) {   /* csi_orientation_sign (-qw) and cse_quaternion_norm(traj, traj) = |q_k| - 1 (manifold.jl:308-319) */
+        tn = td = 0;
+        for (int k = 0; k < N; k++) { tn = fmax(tn, fabs(-X[k * n + 6] + Xp[k * n + 6])); td = fmax(td, fabs(-X[k * n + 6])); }
+        JN += tn; JD += td;
+        tn = td = 0;
+        for (int k = 0; k < N; k++) {
+            double a = 0, b = 0;
+            for (int j = 0; j < 4; j++) { a += X[k * n + 6 + j] * X[k * n + 6 + j]; b += Xp[k * n + 6 + j] * Xp[k * n + 6 + j]; }
+            const double g = sqrt(a) - 1.0, gp = sqrt(b) - 1.0;
+            tn = fmax(tn, fabs(g - gp)); td = fmax(td, fabs(g));
+        }
+        JN += tn; JD += td;
+    }
     /* csi_translational_velocity_bound, csi_angular_velocity_bound */
     for (int cls = 0; cls < 2; cls++) {
         tn = td = 0;

@@ -14,7 +14,7 @@ cat > $D/build/stub.hip <<EOS
                  int gusto_launch_trajopt_m##i(gusto_handle h, int, int) { h->err = "model not in this dev build"; return GUSTO_ERR_ARG; }
 EOS
 for i in 0 1 2 3; do [ $i != $M ] && echo "STUB($i)" >> $D/build/stub.hip; done
-for i in 4 5; do [ $i != $M ] && echo "STUBT($i)" >> $D/build/stub.hip; done
+for i in 4 5 6; do [ $i != $M ] && echo "STUBT($i)" >> $D/build/stub.hip; done
 /opt/rocm/bin/hipcc $F -c $D/csrc/gusto_hip.hip -o $D/build/gusto_hip.o &
 /opt/rocm/bin/hipcc $F -c $D/build/stub.hip -o $D/build/stub.o &
 /opt/rocm/bin/hipcc $F -c $D/csrc/shoot.hip -o $D/build/shoot.o &
