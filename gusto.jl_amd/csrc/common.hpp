@@ -503,13 +503,32 @@ template <class Tp> GD Tp* as_global(Tp* p) {
 // global loads in flight as well.  The 12/13-state kernels had 4 200 flat and 146 global memory instructions that way.
 // These wrappers keep the pointer TYPED with its address space (a cast pair generic -> global -> generic at the point
 // of use is folded away before the address space inference runs).
+#ifdef GUSTO_DEBUG_LDS
+// Debug builds (-DGUSTO_DEBUG_LDS, tools/debug_lds.sh): every indexed LDS access through an LPtr is checked against the
+// workgroup's LDS allocation (static + dynamic bytes, published by the kernel in gusto_dbg_lds_limit); an access past it
+// names itself and traps instead of silently reading a neighbour's memory -- the sanitizer this single-source kernel
+// family can have ("debug-build LDS index asserts").
+__device__ inline unsigned& gusto_dbg_lds_limit() { static __shared__ unsigned lim; return lim; }
+#endif
 template <class Tp, int AS> struct ASPtr {
     typedef __attribute__((address_space(AS))) Tp A;
     A* p;
     ASPtr() = default;
     GD ASPtr(Tp* q) : p((A*)q) {}
     template <class U> GD ASPtr(const ASPtr<U, AS>& o) : p(o.p) {}
-    template <class I> GD A& operator[](I i) const { return p[i]; }
+    template <class I> GD A& operator[](I i) const {
+#ifdef GUSTO_DEBUG_LDS
+        if constexpr (AS == 3) {
+            const unsigned at = (unsigned)(uintptr_t)(p + i);
+            if (at + sizeof(Tp) > gusto_dbg_lds_limit()) {
+                printf("gusto: LDS access out of bounds: byte %u + %u of %u (block %d thread %d)\n", at, (unsigned)sizeof(Tp),
+                       gusto_dbg_lds_limit(), (int)blockIdx.x, (int)threadIdx.x);
+                __builtin_trap();
+            }
+        }
+#endif
+        return p[i];
+    }
     template <class I> GD ASPtr operator+(I i) const { ASPtr r; r.p = p + i; return r; }
     GD A& operator*() const { return *p; }
     GD operator Tp*() const { return (Tp*)p; }   // (generic again: for the few callers that take a plain pointer)

@@ -136,11 +136,64 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         PG = al16((double*)PG); QQ = al16((double*)QQ); Paft = al16((double*)Paft); Piaft = al16((double*)Piaft); KD = al16((double*)KD);
     }
 
+    // What a phase that runs as a REAL CALL (MT::SWEEP_CALL) receives instead of the Blk itself.  Passed by value the Blk is
+    // ~650 bytes of per-lane arguments: the AMDGPU calling convention has no scalar arguments for such a struct, so every
+    // wave-uniform pointer travels as a VGPR (x 64 lanes) and, beyond the argument registers, through scratch -- 41 KB
+    // written by the caller and read back by the callee per call and wave, eleven calls per KKT solve: about 0.9 MB of the
+    // 1.96 MB of L2 <-> fabric traffic per KKT solve measured for astrobeeSE3 (profiles/r04_pmc_config4.json).  The callee
+    // now gets these eight dwords, makes them scalar again (readfirstlane) and rebuilds the view from the kernel arguments
+    // with scalar loads, so the ~45 base pointers live in SGPRs there as they do in the kernel body.
+    struct Args {
+        const KParams* Pk;
+        int b, slot;
+        unsigned goalmask, boxmask;
+        double dt;
+    };
+    int slot_;            // (the workspace slot, kept for args())
+    const KParams* Pk;    // the kernel arguments where they really live: the kernarg segment (KParams is the FIRST argument of
+                          // every kernel that reaches a called phase).  The address of the kernel's own `P` must not travel --
+                          // the compiler may keep that copy in private memory, whose flat address is lane-swizzled scratch: read
+                          // through the constant address space it is an aperture violation -- and a callee cannot ask for the
+                          // segment itself (__builtin_amdgcn_kernarg_segment_ptr() folds to null outside a kernel).
+    GD Args args() const { return Args{Pk, b, slot_, goalmask, boxmask, dt}; }
+    GD static const KParams* uniform_ptr(const KParams* p) {
+        const unsigned long long u = (unsigned long long)(uintptr_t)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu)), hi = __builtin_amdgcn_readfirstlane((int)(u >> 32));
+        return (const KParams*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    }
+    // callee side of a real call: the same view, every base pointer from scalar loads of the kernel arguments (through the
+    // constant address space); nothing is initialised (the goal values in LDS, the index table: the kernel body did that)
+    GD Blk(const Args& a, double* lds_) : P(*uniform_ptr(a.Pk)), lds(lds_) {
+        typedef const __attribute__((address_space(4))) KParams CP;
+        Pk = &P;
+        CP* Pc = (CP*)(uintptr_t)Pk;
+        b = __builtin_amdgcn_readfirstlane(a.b); slot_ = __builtin_amdgcn_readfirstlane(a.slot);
+        tid = threadIdx.x; NTr = ONEWAVE ? 64 : blockDim.x; N = Pc->N;
+        rebind_lds(lds_);
+        double* w = Pc->ws + (size_t)slot_ * Pc->wl.total;
+        rowstate = w + Pc->wl.rowstate; obs_nh = w + Pc->wl.obs_nh; obs_c0 = w + Pc->wl.obs_c0;
+        obs_mask = reinterpret_cast<uint64_t*>(w + Pc->wl.obs_mask);
+        PG = al16(w + Pc->wl.PG); QQ = al16(w + Pc->wl.QQ); Paft = al16(w + Pc->wl.Paft); Piaft = al16(w + Pc->wl.Piaft);
+        KD = al16(w + Pc->wl.KD); Phicl = w + Pc->wl.Phicl;
+        {
+            double* q = w + Pc->wl.pvt;
+            rd = q; qrd = q + N * n; dXs = q + 2 * N * n; dUs = q + 3 * N * n; qu = dUs + N * m; dv = qu + N * m;
+            gAx = dv + N * m; gBx = gAx + N * n; gAu = gBx + N * n; gBu = gAu + N * m;
+            Xp = Pc->X + (size_t)b * N * n; Up = Pc->U + (size_t)b * N * m;
+        }
+        x_init = Pc->x_init + (size_t)b * n; goal_lo = Pc->goal_lo + (size_t)b * n; goal_hi = Pc->goal_hi + (size_t)b * n;
+        const unsigned long long du = __builtin_bit_cast(unsigned long long, a.dt);
+        dt = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(du >> 32)) << 32) |
+                                            (unsigned)__builtin_amdgcn_readfirstlane((int)(du & 0xffffffffu)));
+        goalmask = __builtin_amdgcn_readfirstlane((int)a.goalmask); boxmask = __builtin_amdgcn_readfirstlane((int)a.boxmask);
+    }
+
     // b = the problem, slot = the resident workgroup: the interior point workspace belongs to the SLOT (a few hundred
     // KB that every problem this workgroup pulls from the queue reuses, so the working set of a launch is
     // #slots x wl.total, cache-resident, instead of B x wl.total streamed through HBM once per problem)
     GD Blk(const KParams& P_, double* lds_, int b_, int slot) : P(P_), lds(lds_) {
-        b = b_; tid = threadIdx.x; NTr = blockDim.x; N = P.N;
+        b = b_; tid = threadIdx.x; NTr = blockDim.x; N = P.N; slot_ = slot;
+        Pk = (const KParams*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // (this constructor is inlined into the kernel)
         rebind_lds(lds_);
         double* w = P.ws + (size_t)slot * P.wl.total;
         const WsLayout& W = P.wl;
@@ -2067,25 +2120,24 @@ template <int MODEL> GD void costate_pass_1w(SweepView<MODEL> K, const double* m
     }
     K.sync();
 }
-template <int MODEL> __device__ __noinline__ void costate_pass_1w_call(SweepView<MODEL> K) {
-    K.rebind_lds(gusto_dyn_lds);
-    K.rebind_global();
-    costate_pass_1w<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 48);
+template <int MODEL> __device__ __noinline__ void costate_pass_1w_call(typename Blk<MODEL, true>::Args a) {
+    Blk<MODEL, true> B(a, gusto_dyn_lds);
+    costate_pass_1w<MODEL>(SweepView<MODEL>::make(B), gusto_dyn_lds + LdsC<MODEL, true>::misc + 48);
 }
 
 // MT::SWEEP_CALL (measured per model: astrobeeSE3 +9 %, the manifold model -10 %): the sweep as a real call.  Inlined, its 50-stage loop shares one register allocation with the whole
 // interior point iteration and the allocator spills INSIDE the loop; called, the loop gets the register file to itself
 // and the caller's live values are saved once around the call.
-template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(SweepView<MODEL> K, Prof* pf) {
-    K.rebind_lds(gusto_dyn_lds);
-    K.rebind_global();
+template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(typename Blk<MODEL, true>::Args a, Prof* pf) {
+    Blk<MODEL, true> B(a, gusto_dyn_lds);
+    SweepView<MODEL> K = SweepView<MODEL>::make(B);
     if constexpr (MT<MODEL>::MFMA) factor_sweep_mfma<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
     else factor_sweep_1w<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
 }
 template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof& pf) {
     if constexpr (!BLK::ONE) factor_sweep_mw<MODEL>(K, fail, pf);
 #ifndef GUSTO_SWEEP_INLINE
-    else if constexpr (MT<MODEL>::SWEEP_CALL) factor_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K), &pf);
+    else if constexpr (MT<MODEL>::SWEEP_CALL) factor_sweep_1w_call<MODEL>(K.args(), &pf);
 #endif
     else if constexpr (MT<MODEL>::MFMA) factor_sweep_mfma<MODEL>(SweepView<MODEL>::make(K), fail, pf);
 #ifndef GUSTO_NO_FACTOR_PIPE
@@ -2093,24 +2145,22 @@ template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof&
 #endif
     else factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail, pf);
 }
-template <int MODEL> __device__ __noinline__ void backward_sweep_1w_call(SweepView<MODEL> K) {
-    K.rebind_lds(gusto_dyn_lds);
-    K.rebind_global();
-    backward_sweep_1w(K);
+template <int MODEL> __device__ __noinline__ void backward_sweep_1w_call(typename Blk<MODEL, true>::Args a) {
+    Blk<MODEL, true> B(a, gusto_dyn_lds);
+    backward_sweep_1w(SweepView<MODEL>::make(B));
 }
-template <int MODEL> __device__ __noinline__ void forward_sweep_1w_call(SweepView<MODEL> K) {
-    K.rebind_lds(gusto_dyn_lds);
-    K.rebind_global();
-    forward_sweep_1w(K);
+template <int MODEL> __device__ __noinline__ void forward_sweep_1w_call(typename Blk<MODEL, true>::Args a) {
+    Blk<MODEL, true> B(a, gusto_dyn_lds);
+    forward_sweep_1w(SweepView<MODEL>::make(B));
 }
 template <int MODEL, class BLK> GD void backward_sweep(BLK& K) {
     if constexpr (!BLK::ONE) backward_sweep_mw(K);
-    else if constexpr (MT<MODEL>::SWEEP_CALL) backward_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K));
+    else if constexpr (MT<MODEL>::SWEEP_CALL) backward_sweep_1w_call<MODEL>(K.args());
     else backward_sweep_1w(SweepView<MODEL>::make(K));
 }
 template <int MODEL, class BLK> GD void forward_sweep(BLK& K) {
     if constexpr (!BLK::ONE) forward_sweep_mw(K);
-    else if constexpr (MT<MODEL>::SWEEP_CALL) forward_sweep_1w_call<MODEL>(SweepView<MODEL>::make(K));
+    else if constexpr (MT<MODEL>::SWEEP_CALL) forward_sweep_1w_call<MODEL>(K.args());
     else forward_sweep_1w(SweepView<MODEL>::make(K));
 }
 
@@ -2338,10 +2388,8 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
     MT_(PF_M_SYNC);
 #undef MT_
 }
-template <int MODEL, class BLK> __device__ __noinline__ void mid_phase_call(BLK K, int k, bool act, double hdt, double* red,
-                                                                            double* mugn, Prof* pf) {
-    K.rebind_lds(gusto_dyn_lds);
-    K.rebind_global();
+template <int MODEL, class BLK> __device__ __noinline__ void mid_phase_call(typename BLK::Args a, int k, bool act, double hdt, Prof* pf) {
+    BLK K(a, gusto_dyn_lds);
     using C = typename BLK::C;
     mid_phase<MODEL>(K, k, act, hdt, gusto_dyn_lds + C::misc, gusto_dyn_lds + C::misc + 48, pf);
 }
@@ -2459,12 +2507,27 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
     }
     return StepOut{l_amax, l_c0, l_c1, l_c2};
 }
+// the row context of knot k, as ipm_solve builds it (the called phases rebuild theirs from three numbers)
 template <int MODEL, class BLK>
-__device__ __noinline__ StepOut step_phase_call(BLK K, RowCtx<MODEL> ctx, RowState rs, int k, bool act, int pass, int ncomp,
-                                                double hdt, double tau, double mu_t, const double* mugn, const double* gxs) {
-    K.rebind_lds(gusto_dyn_lds);
-    K.rebind_global();
+GD void make_row_ctx(const BLK& K, int k, bool act, double kappa, double omega, double Delta, RowCtx<MODEL>& ctx, RowState& rs) {
+    constexpr int n = BLK::n;
+    ctx.P = &K.P; ctx.N = K.N; ctx.k = k; ctx.nslot = K.P.wl.nslot; ctx.kappa = kappa; ctx.omega = omega; ctx.Delta = Delta;
+    ctx.xp = K.Xp + (act ? k : 0) * n; ctx.mask = act ? K.obs_mask[k] : 0; ctx.obs_nh = K.obs_nh; ctx.obs_c0 = K.obs_c0;
+    ctx.goal_lo = K.goal_lo; ctx.goal_hi = K.goal_hi; ctx.boxmask = K.boxmask;
+    rs = RowState{K.rowstate, K.P.wl.nslot, K.N, act ? k : 0};
+}
+struct RowScal { double kappa, omega, Delta; };
+template <int MODEL, class BLK>
+__device__ __noinline__ StepOut step_phase_call(typename BLK::Args a, RowScal sc, int k, bool act, int pass, int ncomp,
+                                                double hdt, double tau, double mu_t, Prof* pf) {
+    BLK K(a, gusto_dyn_lds);
     using C = typename BLK::C;
+    RowCtx<MODEL> ctx;
+    RowState rs;
+    make_row_ctx<MODEL>(K, k, act, sc.kappa, sc.omega, sc.Delta, ctx, rs);
+#ifdef GUSTO_PROFILE
+    ctx.pf = pf; ctx.pfb = PF_S0;
+#endif
     return step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, gusto_dyn_lds + C::misc + 48,
                              gusto_dyn_lds + C::misc + 16);
 }
@@ -2676,11 +2739,16 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
     return ResidOut{l_resp, l_resd, l_comp, l_numax};
 }
 template <int MODEL, class BLK>
-__device__ __noinline__ ResidOut resid_phase_call(BLK K, RowCtx<MODEL> ctx, RowState rs, int k, bool act, double hdt, double wk,
-                                                  double alpha_prev, const double* mug) {
-    K.rebind_lds(gusto_dyn_lds);
-    K.rebind_global();
+__device__ __noinline__ ResidOut resid_phase_call(typename BLK::Args a, RowScal sc, int k, bool act, double hdt, double wk,
+                                                  double alpha_prev, Prof* pf) {
+    BLK K(a, gusto_dyn_lds);
     using C = typename BLK::C;
+    RowCtx<MODEL> ctx;
+    RowState rs;
+    make_row_ctx<MODEL>(K, k, act, sc.kappa, sc.omega, sc.Delta, ctx, rs);
+#ifdef GUSTO_PROFILE
+    ctx.pf = pf; ctx.pfb = PF_R0;
+#endif
     return resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, gusto_dyn_lds + C::misc + 32);
 }
 
@@ -2794,7 +2862,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
 #ifdef GUSTO_PROFILE
         ctx.pf = &pf; ctx.pfb = PF_R0;
 #endif
-        if constexpr (T::SWEEP_CALL) ro = resid_phase_call<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
+        if constexpr (T::SWEEP_CALL) ro = resid_phase_call<MODEL, BLK>(K.args(), RowScal{kappa, omega, Delta}, k, act, hdt, wk, alpha_prev, &pf);
         else ro = resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
         const double l_resp = ro.resp, l_resd = ro.resd, l_comp = ro.comp, l_numax = ro.numax;
         res_p = block_reduce<BLK::ONE>(l_resp, OpNanMax(), red);
@@ -2905,12 +2973,12 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             backward_sweep<MODEL>(K);
             pf.tick(PF_BACK);
             GUSTO_REFRESH_K();
-            if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL>(K, k, act, hdt, red, mugn, &pf);
+            if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL, BLK>(K.args(), k, act, hdt, &pf);
             else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf);
             pf.tick(PF_MID);
             forward_sweep<MODEL>(K);
             if constexpr (GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL)
-                if (pass == 1 || ncomp == 0) costate_pass_1w_call<MODEL>(SweepView<MODEL>::make(K));
+                if (pass == 1 || ncomp == 0) costate_pass_1w_call<MODEL>(K.args());
             pf.tick(PF_FWD);
             GUSTO_REFRESH_K();
             // primal step of this knot, the new costates, row steps + fraction to the boundary
@@ -2919,7 +2987,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
 #ifdef GUSTO_PROFILE
             ctx.pf = &pf; ctx.pfb = PF_S0;
 #endif
-            if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
+            if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL, BLK>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
             else so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
             const double l_amax = so.amax, l_c0 = so.c0, l_c1 = so.c1, l_c2 = so.c2;
             const double a_max = block_reduce<BLK::ONE>(l_amax, OpMin(), red);

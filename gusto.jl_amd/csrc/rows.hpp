@@ -110,8 +110,8 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
             double bp[4], bm[4], c0 = qn - 1.0;
 #pragma unroll
             for (int j = 0; j < 4; j++) { bp[j] = qp[j] / qn; bm[j] = -bp[j]; c0 -= qp[j] * qp[j] / qn; }
-            lin_row<false, 6, 4>(op, 0, ROW_HARD, xs, bm, -c0, 1.0, TRAJOPT_EQ_BAND);
-            lin_row<false, 6, 4>(op, 3, ROW_HARD, xs, bp, c0, 1.0, TRAJOPT_EQ_BAND);
+            lin_row<false, 6, 4>(op, 0, ROW_HARD, xs, bm, -c0, 1.0 / TRAJOPT_EQ_BAND, 1.0);   // (scaled to O(1) like every hard row)
+            lin_row<false, 6, 4>(op, 3, ROW_HARD, xs, bp, c0, 1.0 / TRAJOPT_EQ_BAND, 1.0);
             const double m1 = -1.0;
             lin_row<false, 6, 1>(op, 4, ROW_PEN, xs, &m1, 0.0, kw, 0.0);
         }

@@ -337,6 +337,10 @@ template <int MODEL, bool ONEWAVE> __global__ void __launch_bounds__(ONEWAVE ? 6
 scp_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int slot = blockIdx.x;
+#ifdef GUSTO_DEBUG_LDS
+    if (threadIdx.x == 0) gusto_dbg_lds_limit() = __builtin_amdgcn_groupstaticsize() + (unsigned)P.ll.total * 8u;
+    __syncthreads();
+#endif
     for (;;) {
         int b = 0, ci = 0, from = 0;
         if constexpr (ONEWAVE) {
@@ -651,6 +655,10 @@ template <int MODEL> GD void trajopt_problem(const KParams& P, double* lds, int 
 // problems in a static round robin over the resident workgroups (no device-side scheduler: TrajOpt problems take 5-25 solves)
 template <int MODEL> __global__ void __launch_bounds__(256, 1) trajopt_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+#ifdef GUSTO_DEBUG_LDS
+    if (threadIdx.x == 0) gusto_dbg_lds_limit() = __builtin_amdgcn_groupstaticsize() + (unsigned)P.ll.total * 8u;
+    __syncthreads();
+#endif
     for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
         __syncthreads();
         trajopt_problem<MODEL>(P, lds, b, blockIdx.x);

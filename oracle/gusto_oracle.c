@@ -659,10 +659,10 @@ static void assemble_rows_trajopt(go_problem* p, const double* Xp, double s_tr, 
             for (int j = 0; j < 4; j++) c0 -= xp[6 + j] * xp[6 + j] / qn;
             r = new_row(p, k, 0, ROW_HARD);
             for (int j = 0; j < 4; j++) row_add(r, 6 + j, 0.0, 0.0, -xp[6 + j] / qn);
-            r->c0 = -c0; r->mul = 1.0; r->off = GO_TRAJOPT_EQ_BAND;
+            r->c0 = -c0; r->mul = 1.0 / GO_TRAJOPT_EQ_BAND; r->off = 1.0;   /* (scaled to O(1) like every hard row) */
             r = new_row(p, k, 0, ROW_HARD);
             for (int j = 0; j < 4; j++) row_add(r, 6 + j, 0.0, 0.0, xp[6 + j] / qn);
-            r->c0 = c0; r->mul = 1.0; r->off = GO_TRAJOPT_EQ_BAND;
+            r->c0 = c0; r->mul = 1.0 / GO_TRAJOPT_EQ_BAND; r->off = 1.0;
             r = new_row(p, k, 0, ROW_PEN);
             row_add(r, 6, 0.0, 0.0, -1.0);
             r->mul = kappa * mu;

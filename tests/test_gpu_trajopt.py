@@ -21,10 +21,12 @@ def _setup(model, B):
     if model == g.FREEFLYER_SE2:
         return P.freeflyer_batch(B), P.freeflyer_env(), None
     bx, sp = P.iss_corner_env(True)
+    if model == g.ASTROBEE_SE3_MANIFOLD:
+        return P.astrobee_manifold_batch(B), bx, sp
     return P.astrobee_se3_batch(B), bx, sp
 
 
-@pytest.mark.parametrize("model", [g.FREEFLYER_SE2, g.ASTROBEE_SE3])
+@pytest.mark.parametrize("model", [g.FREEFLYER_SE2, g.ASTROBEE_SE3, g.ASTROBEE_SE3_MANIFOLD])
 @pytest.mark.parametrize("mu,s_tr", [(1.0, 1.0), (5.0, 0.25), (125.0, 0.03)])
 def test_subproblem_parity(model, mu, s_tr):
     B = 24
@@ -39,13 +41,23 @@ def test_subproblem_parity(model, mu, s_tr):
         ro = o.subproblem(X0[b], U0[b], mu, s_tr)
         assert r["status"][b] == ro["status"] and ro["status"] in (1, 2), (b, r["status"][b], ro["status"])
         tol = 5e-5 * max(1.0, mu)
-        assert np.abs(r["X"][b] - ro["X"]).max() < tol and np.abs(r["U"][b] - ro["U"]).max() < tol, b
+        # (manifold model: the state is determined only up to its +-1e-4 bands -- BoxGoal on q, quaternion-norm rows -- as in the
+        # GuSTO lock-step test of that model: X within 5e-4, the controls and defects at the common tolerance)
+        xtol = 10 * tol if model == g.ASTROBEE_SE3_MANIFOLD else tol
+        assert np.abs(r["X"][b] - ro["X"]).max() < xtol and np.abs(r["U"][b] - ro["U"]).max() < tol, b
         assert np.abs(r["D"][b] - ro["D"]).max() < tol
         assert abs(r["obj"][b] - ro["obj"]) <= 1e-6 * max(1.0, mu) * max(1.0, abs(ro["obj"]))
-        assert np.abs(r["dual"][b] - ro["dual"]).max() < 1e-5 * max(1.0, np.abs(ro["dual"]).max()) * max(1.0, mu)
+        # (manifold model: x_1 is pinned, so its quaternion-norm band rows of knot 1 are constants and their multipliers free --
+        # the quaternion components of the init dual are determined to the complementarity tolerance only)
+        ed = np.abs(r["dual"][b] - ro["dual"])
+        wd = 1e-5 * max(1.0, np.abs(ro["dual"]).max()) * max(1.0, mu)
+        if model == g.ASTROBEE_SE3_MANIFOLD:
+            assert ed[:6].max() < wd and ed[10:].max() < wd and ed[6:10].max() < 1e-2 * max(1.0, mu)
+        else:
+            assert ed.max() < wd
 
 
-@pytest.mark.parametrize("model,B", [(g.FREEFLYER_SE2, 48), (g.ASTROBEE_SE3, 24)])
+@pytest.mark.parametrize("model,B", [(g.FREEFLYER_SE2, 48), (g.ASTROBEE_SE3, 24), (g.ASTROBEE_SE3_MANIFOLD, 16)])
 def test_whole_runs_match_the_oracle(model, B):
     """solve_trajopt_jump! end to end: identical schedules (number of solves, s_vec, mu_vec, lengths of every vector,
     converged, stop reason), rho / xtol / ftol / ctol / J histories and the final trajectory."""
@@ -76,13 +88,16 @@ def test_whole_runs_match_the_oracle(model, B):
         for k, ref in (("xtol_vec", R["xtol_vec"]), ("ftol_vec", R["ftol_vec"]), ("ctol_vec", R["ctol_vec"])):
             assert np.allclose(h[k][b, :len(ref)], ref, rtol=1e-4, atol=1e-9), (b, k)
         assert np.allclose(h["J_true"][b, :S + 1], R["J_true"], rtol=1e-7, atol=1e-12)
-        assert np.allclose(h["J_full"][b, :S], R["J_full"], rtol=1e-6, atol=1e-9)
-        assert np.allclose(h["convergence_measure"][b, 1:S + 1], R["conv"][1:S + 1], rtol=1e-4, atol=1e-9)
-        assert np.abs(X[b] - R["X"]).max() < 5e-5 * R["mu_vec"][-1] and np.abs(U[b] - R["U"]).max() < 5e-5 * R["mu_vec"][-1], b
+        # (manifold model: its states float inside the +-1e-4 bands of the quaternion rows, test_subproblem_parity: the
+        # objective of a solve agrees to 2e-5, the final X to 5e-4)
+        man = model == g.ASTROBEE_SE3_MANIFOLD
+        assert np.allclose(h["J_full"][b, :S], R["J_full"], rtol=2e-5 if man else 1e-6, atol=1e-9)
+        assert np.allclose(h["convergence_measure"][b, 1:S + 1], R["conv"][1:S + 1], rtol=1e-4, atol=1e-9 if not man else 1e-6)
+        assert np.abs(X[b] - R["X"]).max() < (10 if man else 1) * 5e-5 * R["mu_vec"][-1] and np.abs(U[b] - R["U"]).max() < 5e-5 * R["mu_vec"][-1], b
     assert trips >= 5 * B and n_soft <= 2, (trips, n_soft)
 
 
-@pytest.mark.parametrize("model,B", [(g.FREEFLYER_SE2, 32), (g.ASTROBEE_SE3, 16)])
+@pytest.mark.parametrize("model,B", [(g.FREEFLYER_SE2, 32), (g.ASTROBEE_SE3, 16), (g.ASTROBEE_SE3_MANIFOLD, 12)])
 def test_lockstep_every_trip(model, B):
     """Every trip of every problem from the ORACLE's own state: its (traj, defects, mu, s) before the trip goes through
     gusto_subproblem_trajopt and the optimum must be the oracle's optimum of that trip."""
@@ -113,9 +128,10 @@ def test_lockstep_every_trip(model, B):
             trips += 1
             assert sub["status"][b] == R["solver_status"][i + 1] or {int(sub["status"][b]), int(R["solver_status"][i + 1])} == {1, 2}, (b, t)
             tol = 5e-5 * max(1.0, mu[b])
-            assert np.abs(sub["X"][b] - tr[i]["Xn"]).max() < tol and np.abs(sub["U"][b] - tr[i]["Un"][:, :m0]).max() < tol, (b, t)
+            man = model == g.ASTROBEE_SE3_MANIFOLD       # (X inside its +-1e-4 bands, see test_subproblem_parity)
+            assert np.abs(sub["X"][b] - tr[i]["Xn"]).max() < (10 if man else 1) * tol and np.abs(sub["U"][b] - tr[i]["Un"][:, :m0]).max() < tol, (b, t)
             assert np.abs(sub["D"][b] - tr[i]["Un"][:, m0:]).max() < tol
-            assert abs(sub["obj"][b] - R["J_full"][i]) <= 1e-6 * max(1.0, mu[b]) * max(1.0, abs(R["J_full"][i]))
+            assert abs(sub["obj"][b] - R["J_full"][i]) <= (2e-5 if man else 1e-6) * max(1.0, mu[b]) * max(1.0, abs(R["J_full"][i]))
     assert trips == sum(R["solves"] for R, _ in runs) >= 5 * B
 
 

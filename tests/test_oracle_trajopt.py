@@ -150,3 +150,58 @@ def test_three_loop_schedule(model):
     assert o.solve_trajopt(3)["solves"] == 3
     with pytest.raises(RuntimeError):
         go.OracleTrajOpt(go.DUBINS_CAR, 30)
+
+
+def test_manifold_subproblem_rows_as_the_reference_registers_them():
+    """TrajOpt for AstrobeeSE3Manifold (astrobee_se3_manifold.jl:56-70,533-608; scp_trajopt.jl:159-279): no trust region row
+    (none is registered, :601), the linearised quaternion norm of every knot held hard -- inside the band the oracle states --,
+    BoxGoal rows on q hard, -qw / speed / rate / obstacle / control rows and the dynamics penalised.  Checked on the optimum of
+    one subproblem: the trust region argument s does not move it, the hard rows hold, the reported objective is the control
+    effort plus the L1 penalties evaluated independently in numpy.  Then the three-loop schedule of whole runs."""
+    boxes, spheres = P.iss_corner_env(True)
+    x0, glo, ghi, tf = P.astrobee_manifold_batch(3)
+    N, mu = 50, 5.0
+    o = go.OracleTrajOpt(go.ASTROBEE_SE3_MANIFOLD, N, boxes=boxes, spheres=spheres)
+    mp = o.mp
+    for b in range(3):
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        Xp, Up = o.init_straightline()
+        r = o.subproblem(Xp, Up, mu, 10.0)
+        r2 = o.subproblem(Xp, Up, mu, 1e-3)
+        assert r["status"] == 1 and r2["status"] == 1
+        assert np.array_equal(r["X"], r2["X"]) and np.array_equal(r["U"], r2["U"])      # no trust region row at all
+        X, U, D = r["X"], r["U"], r["D"]
+        qn = np.linalg.norm(Xp[:, 6:10], axis=1)
+        h = qn + ((Xp[:, 6:10] / qn[:, None]) * (X[:, 6:10] - Xp[:, 6:10])).sum(1) - 1.0
+        assert np.abs(h).max() <= 1e-4 * (1 + 1e-6)                                       # cse_quaternion_norm: hard (band)
+        assert np.abs(X[0] - x0[b]).max() < 1e-9
+        pt = glo[b] == ghi[b]
+        assert np.abs(X[-1][pt] - glo[b][pt]).max() < 1e-7
+        assert (X[-1][~pt] <= ghi[b][~pt] + 1e-9).all() and (X[-1][~pt] >= glo[b][~pt] - 1e-9).all()
+        dt = tf[b] / (N - 1)
+        cost = sum(0.5 * dt * (U[k - 1] @ U[k - 1] + U[k] @ U[k]) for k in range(1, N))
+        pen = 0.0
+        for k in range(N):
+            pen += max(0.0, mu * -X[k, 6]) + max(0.0, mu * (X[k, 3:6] @ X[k, 3:6] - mp.hard_limit_vel ** 2))
+            pen += max(0.0, mu * (X[k, 10:13] @ X[k, 10:13] - mp.hard_limit_omega ** 2))
+            for i in range(len(boxes) + len(spheres)):
+                d0, nh = o.signed_distance(0, Xp[k, :3], i)
+                if d0 < mp.clearance + 1.0:
+                    pen += max(0.0, mu * (mp.clearance - (d0 + nh @ (X[k, :3] - Xp[k, :3]))))
+            if k < N - 1:
+                pen += max(0.0, mu * (U[k, :3] @ U[k, :3] / mp.mass ** 2 - mp.hard_limit_accel ** 2))
+                pen += max(0.0, mu * (sum((U[k, 3 + j] / mp.Jdiag[j]) ** 2 for j in range(3)) - mp.hard_limit_alpha ** 2))
+            pen += mu * np.abs(D[k]).sum()
+        reg = sum(1e-4 * (0.5 * dt if k in (0, N - 1) else dt) * (D[k] @ D[k]) for k in range(N))
+        assert abs(r["obj"] - (cost + pen + reg)) <= 1e-5 * max(1.0, abs(r["obj"])), (r["obj"], cost, pen, reg)
+    o = go.OracleTrajOpt(go.ASTROBEE_SE3_MANIFOLD, 50, boxes=boxes, spheres=spheres)
+    tp = o.tp
+    assert (tp.s0, tp.xtol, tp.mu0, tp.k) == (10.0, 0.01, 1.0, 5.0)                       # astrobee_se3_manifold.jl:56-70
+    for b in range(3):
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        R = o.solve_trajopt(125)
+        S = R["solves"]
+        assert S >= 1 and R["stop_reason"] in (0, 1) and len(R["s_vec"]) == S + 1
+        for i in range(S):
+            assert R["s_vec"][i + 1] == (tp.tau_plus if R["rho_vec"][i + 1] > tp.c else tp.tau_minus) * R["s_vec"][i]
+        assert np.abs(np.linalg.norm(R["X"][:, 6:10], axis=1) - 1.0).max() < 5e-3          # near the unit sphere
