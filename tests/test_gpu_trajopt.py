@@ -89,7 +89,7 @@ def test_whole_runs_match_the_oracle(model, B):
         assert np.allclose(h["rho_vec"][b, :S + 1], R["rho_vec"], rtol=rt, atol=1e-8)
         for k, ref in (("xtol_vec", R["xtol_vec"]), ("ftol_vec", R["ftol_vec"]), ("ctol_vec", R["ctol_vec"])):
             assert np.allclose(h[k][b, :len(ref)], ref, rtol=rt, atol=1e-9 if rt == 1e-4 else 1e-6), (b, k)
-        assert np.allclose(h["J_true"][b, :S + 1], R["J_true"], rtol=1e-7, atol=1e-12)
+        assert np.allclose(h["J_true"][b, :S + 1], R["J_true"], rtol=1e-7 if model != g.ASTROBEE_SE3_MANIFOLD else 2e-6, atol=1e-12)
         # (manifold model: its states float inside the +-1e-4 bands of the quaternion rows, test_subproblem_parity: the
         # objective of a solve agrees to 2e-5, the final X to 5e-4)
         man = model == g.ASTROBEE_SE3_MANIFOLD
