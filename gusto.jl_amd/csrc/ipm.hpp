@@ -138,11 +138,12 @@ template <int MODEL, bool ONEWAVE> struct Blk {
 
     // What a phase that runs as a REAL CALL (MT::SWEEP_CALL) receives instead of the Blk itself.  Passed by value the Blk is
     // ~650 bytes of per-lane arguments: the AMDGPU calling convention has no scalar arguments for such a struct, so every
-    // wave-uniform pointer travels as a VGPR (x 64 lanes) and, beyond the argument registers, through scratch -- 41 KB
-    // written by the caller and read back by the callee per call and wave, eleven calls per KKT solve: about 0.9 MB of the
-    // 1.96 MB of L2 <-> fabric traffic per KKT solve measured for astrobeeSE3 (profiles/r04_pmc_config4.json).  The callee
-    // now gets these eight dwords, makes them scalar again (readfirstlane) and rebuilds the view from the kernel arguments
-    // with scalar loads, so the ~45 base pointers live in SGPRs there as they do in the kernel body.
+    // wave-uniform pointer travels as a VGPR (x 64 lanes) and, beyond the argument registers, through scratch -- ~80 scratch
+    // stores in front of each call and as many loads in the callee, eleven calls per KKT solve (the stack stays in the L2:
+    // the fabric counters FETCH_SIZE / WRITE_SIZE do not see it, the wave waits for it all the same).  The callee now
+    // gets these eight dwords, makes them scalar again (readfirstlane) and rebuilds the view from the kernel arguments
+    // with scalar loads, so the ~45 base pointers live in SGPRs there as they do in the kernel body: scratch 3.1 -> 1.2 KB
+    // per lane, astrobeeSE3 B = 8192 122.7 -> 114.5 ms.
     struct Args {
         const KParams* Pk;
         int b, slot;
@@ -2075,6 +2076,12 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
     K.sync();
 }
 
+// (Round 4 tried the vector sweeps on the fp64 DPP broadcast gfx950 has -- `v_fmac_f64_dpp ... row_newbcast:L`, the n-vector
+// replicated in every row of 16 lanes -- instead of 2 n v_readlane per step.  In isolation a step of n = 6 is 67 cycles against
+// 136 (tools/ub/dpp.hip), but the sweep then forms its column of Phicl per knot and lane instead of once per ten knots by groups
+// of lanes: bit-identical and 35.9 ms against 34.1 ms per config-2 batch.  The variant without per-knot operands,
+// Phi^T p - K^T (Gam^T p), is as fast as the readlane sweep and numerically worse -- it subtracts two large terms that
+// Phi - Gam K cancels entry by entry first: 1.5 % more interior point iterations, lock-step tolerances missed.  Neither kept.)
 // nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g of every knot (the new costates of the corrector), for the 12/13-state models by
 // groups of n lanes: lane i of group g forms row i for knot k0 + g from ITS rows of the P_k and Pi_k records (stored transposed:
 // the lanes of a group read consecutive doubles), the next chunk's rows in flight while this one is summed.  A load
