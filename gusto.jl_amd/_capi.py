@@ -19,7 +19,7 @@ STOP_REASON = {0: "MaxIter", 1: "Converged", 2: "SubproblemFailed", 3: "OmegaMax
 
 # every symbol include/gusto_hip.h declares
 SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims", "gusto_create", "gusto_destroy",
-           "gusto_last_error", "gusto_set_params", "gusto_set_ipm_opts", "gusto_set_env", "gusto_set_env_batch", "gusto_set_schedule",
+           "gusto_last_error", "gusto_set_params", "gusto_set_ipm_opts", "gusto_set_env", "gusto_set_env_batch", "gusto_set_schedule", "gusto_set_decomposition",
            "gusto_set_stream",
            "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_solve_async", "gusto_wait",
            "gusto_last_solve_ms", "gusto_get_traj",
@@ -133,6 +133,7 @@ def lib():
         L.gusto_set_problems.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
         L.gusto_set_problems_dev.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
         L.gusto_set_schedule.argtypes = [vp, ci, ci]
+        L.gusto_set_decomposition.argtypes = [vp, ci]
         L.gusto_solve.argtypes = [vp, ci, ci]
         L.gusto_solve_async.argtypes = [vp, ci, ci]
         L.gusto_wait.argtypes = [vp]
@@ -268,6 +269,10 @@ class BatchSolver:
         W = None if omega is None else _arr(np.broadcast_to(np.asarray(omega, dtype=np.float64), (self.B,)))
         self._chk(self.L.gusto_set_trust_state(self.h, None if D is None else D.ctypes.data,
                                                None if W is None else W.ctypes.data), "set_trust_state")
+
+    def set_decomposition(self, decomposition):
+        """0 auto, 1 a wave per problem, 2 a lane per problem (dubins_car; gusto_hip.h: gusto_set_decomposition)."""
+        self._chk(self.L.gusto_set_decomposition(self.h, int(decomposition)), "set_decomposition")
 
     def set_schedule(self, probe_iters=2, min_batch=2048):
         self._chk(self.L.gusto_set_schedule(self.h, int(probe_iters), int(min_batch)), "set_schedule")

@@ -199,6 +199,14 @@ int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch) {
     return GUSTO_OK;
 }
 
+int gusto_set_decomposition(gusto_handle h, int decomposition) {
+    if (!h || decomposition < GUSTO_DECOMP_AUTO || decomposition > GUSTO_DECOMP_LANE) return GUSTO_ERR_ARG;
+    { int rc = setter_enter(h); if (rc) return rc; }
+    // (a lane per problem exists for the models without obstacle rows -- dubins_car; the others keep their wave per problem)
+    h->decomposition = decomposition;
+    return GUSTO_OK;
+}
+
 int gusto_set_stream(gusto_handle h, void* s) {
     if (!h) return GUSTO_ERR_ARG;
     { int rc = setter_enter(h); if (rc) return rc; }   // a pending solve is synchronised on the stream it runs on

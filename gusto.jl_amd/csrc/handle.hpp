@@ -48,6 +48,7 @@ struct gusto_handle_s {
     int lds_bytes = 0, per_cu = 0;   // ... its dynamic LDS per workgroup and workgroups per CU (gusto_dev_launch_info)
     int sched_init[gusto::SQ_WORDS] = {0};   // initial scheduler words of a launch (host side of an async copy)
     bool have_problems = false, have_shoot = false;
+    int decomposition = 0;         // gusto_set_decomposition: 0 auto, 1 a wave per problem, 2 a lane per problem (lane.hpp)
     int waves = 0;                 // gusto_set_waves: waves per problem of the GuSTO kernel (0 = one per 64 knots)
     int sched_err = 0;             // latched scheduler error of the last solve (gusto_finish): getters fail until the next set_problems / solve
     int* h_sched_err = nullptr;    // pinned host word the error flag is copied to on the handle's stream, before the stream is waited for

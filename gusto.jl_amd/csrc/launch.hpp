@@ -7,6 +7,7 @@
 
 #include "handle.hpp"
 #include "scp.hpp"
+#include "lane.hpp"
 
 using namespace gusto;
 
@@ -132,6 +133,53 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     h->sched_err = 0;
     HIPCHK(h, gusto_fetch_sched_err(h));
     h->pending = true;   // completed by gusto_finish (handle.hpp)
+    return GUSTO_OK;
+}
+
+// Which decomposition a GuSTO solve of this handle runs (models that have the lane-per-problem kernel, lane.hpp): the
+// caller's choice (gusto_set_decomposition), else GUSTO_DEV_LANE=0/1, else a wave per problem -- measured on MI355X
+// (profiles/r04_lane_vs_wave.txt) the lane kernel is the slower one at every batch size of BASELINE.json: an interior point
+// iteration of 64 problems issues ~170 k instructions (0.33 ms on an idle GPU) and a wave runs as long as the longest of
+// its 64 problems (813 iterations + trips in the config-3 batch, against 80 on average), DESIGN.md section 3
+static inline bool lane_decomposition(gusto_handle h) {
+    if (h->decomposition == 1) return false;
+    if (h->decomposition == 2) return true;
+    if (const char* e = getenv("GUSTO_DEV_LANE")) return atoi(e) != 0;
+    return false;
+}
+// One lane per problem (lane.hpp): ceil(B / lanes per wave) one-wave workgroups, each with its own block of the lane
+// workspace; no device-side scheduler (every problem is resident from the start, a lane runs its problem to the end)
+template <int MODEL> static int launch_lane(gusto_handle h, int mode, int max_iter, int force) {
+    using Y = LaneLay<MODEL>;
+    KParams P;
+    int rc = fill_params<MODEL>(h, P, h->B);
+    if (rc) return rc;
+    P.mode = mode; P.max_iter = max_iter; P.force = force;
+    int cus = 0;
+    HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    // lanes per wave: 64 unless the batch is too small to give every SIMD a wave (then fewer problems per wave: the
+    // instruction stream of a wave costs the same for 16 problems as for 64)
+    int lpw = 64;
+    if (const char* e = getenv("GUSTO_DEV_LANES_PER_WAVE")) lpw = std::max(1, std::min(64, atoi(e)));
+    else while (lpw > 8 && (h->B + lpw - 1) / lpw < 4 * std::max(1, cus)) lpw >>= 1;
+    const int nw = (h->B + lpw - 1) / lpw;
+    const size_t need = (size_t)nw * (size_t)h->N * (size_t)(Y::EK * 64);
+    if (need > h->ws_doubles) {
+        if (h->d_ws) hipFree(h->d_ws);
+        h->d_ws = nullptr; h->ws_doubles = 0;
+        HIPCHK(h, dalloc(&h->d_ws, need));
+        h->ws_doubles = need;
+    }
+    P.ws = h->d_ws;
+    h->slots = nw; h->lds_bytes = 0; h->per_cu = 4;
+    if (h->d_queue) HIPCHK(h, hipMemsetAsync(h->d_queue, 0, SQ_WORDS * sizeof(int), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(lane_kernel<MODEL>, dim3(nw), dim3(64), 0, h->stream, P, lpw);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->sched_err = 0;
+    HIPCHK(h, gusto_fetch_sched_err(h));
+    h->pending = true;
     return GUSTO_OK;
 }
 

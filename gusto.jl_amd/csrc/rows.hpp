@@ -254,7 +254,7 @@ struct RowState {
 // the pass reaches it, behind the stores of the row before, and the pass pays one memory round trip per row.
 template <int NP> struct RowPre {
     double v[RS_NVAR][NP > 0 ? NP : 1];
-    template <class F> GD void load(const RowState& rs, int nfix, int slot_u, F&& want) {
+    template <class RST, class F> GD void load(const RST& rs, int nfix, int slot_u, F&& want) {
 #pragma unroll
         for (int var = 0; var < RS_NVAR; var++)
 #pragma unroll
@@ -267,7 +267,7 @@ template <int NP> struct RowPre {
 // id FX_OBS + q of a row = position q of the current batch.
 struct ObsPre {
     double v[RS_NVAR][OBS_BATCH];
-    template <class F> GD void load(const RowState& rs, const int* slot, F&& want) {
+    template <class RST, class F> GD void load(const RST& rs, const int* slot, F&& want) {
 #pragma unroll
         for (int var = 0; var < RS_NVAR; var++)
             if (want(var)) {
@@ -283,8 +283,8 @@ struct ObsPre {
 // Warm (the iterate starts at the optimum of the previous subproblem): every penalised row is put ON the central
 // path at muw for its value g at the start point:  s - t = g, t lam_a = s lam_b = muw, lam_a + lam_b = 1
 //   <=>  {s, t} = muw + (sqrt(g^2 + 4 muw^2) +- g) / 2;   hard rows get lam = muw / t.
-struct OpInit {
-    RowState rs;
+template <class RST = RowState> struct OpInitT {
+    RST rs;
     double muw;
     int ncomp = 0;
     GD void obs_load(const int*) {}
@@ -307,6 +307,8 @@ struct OpInit {
     }
 };
 
+using OpInit = OpInitT<>;
+
 // residuals + condensed Hessian:  H += sigma * grad grad^T + lam * hess,  dual residual += lam * grad.
 // The row update of the previous interior point step (t += alpha dt, ...) is folded into this pass, and so is the
 // row part of the PREDICTOR right-hand side (the coefficient of a row, the predicted new multiplier at dz = 0, reduces to
@@ -314,14 +316,18 @@ struct OpInit {
 // saves the predictor its own pass over the rows.
 // LRTR: a row over ALL states (the trust region) is not added to H_x; its dyad sigma * grad grad^T and diagonal come back
 // as (trs, trg, trh) and resid_phase applies them to the stage cost in factored form.
-template <int n, int m, int NP, bool LRTR = false> struct OpResidHess {
-    RowState rs;
+// (RST: the accessor of the per-row interior point state -- RowState for the wave-per-problem kernels, whose lane k walks
+// [var][slot][k] arrays, LaneRS for the lane-per-problem kernel, lane.hpp; ssum: the slacks of the penalised rows after the
+// update, for the kernels that take the objective from this pass)
+template <int n, int m, int NP, bool LRTR = false, class RST = RowState> struct OpResidHess {
+    RST rs;
     double *Hx, *Hu, *rdx, *rdu, *gx0, *gu0;
     double alpha_prev;  // 0 on the first trip
     const RowPre<NP>* pre;
     double comp = 0, maxrp = 0;
     ObsPre ob;
     double trs = 0, trg[LRTR ? n : 1], trh[LRTR ? n : 1];
+    double ssum = 0;
     GD void obs_load(const int* slot) {
         const bool upd = alpha_prev != 0.0;
         ob.load(rs, slot, [&](int var) {
@@ -355,6 +361,7 @@ template <int n, int m, int NP, bool LRTR = false> struct OpResidHess {
                 rs.at(RS_S, slot) = s; rs.at(RS_LAMB, slot) = lamb;
             }
             rp = ev.g - s + t;
+            ssum += s;
             comp += t * lam + s * lamb;
             sig = lam * lamb * rcp_nr(t * lamb + lam * s);   // = lam / (t + lam s / lamb)
         }
@@ -406,8 +413,8 @@ struct StepFrac {
 // affine in the centring parameter, coef = A + mu_t B, and everything A and B need is in registers right here, so the
 // pass leaves gA = sum A grad and gB = sum B grad per knot and the corrector forms gA + mu_t gB once mu_t is known: one
 // row pass (6 row-state reads per row) less per interior point iteration.
-template <int NP> struct OpStep {
-    RowState rs;
+template <int NP, class RST = RowState> struct OpStep {
+    RST rs;
     const double *dxs, *dus;
     int pass;
     double mu_t, tau;
@@ -477,14 +484,16 @@ template <int NP> struct OpStep {
     }
 };
 
-struct OpSlackSum {
-    RowState rs;
+template <class RST = RowState> struct OpSlackSumT {
+    RST rs;
     double sum = 0;
     GD void obs_load(const int*) {}
     template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>&) {
         if (!row_is_hard(kind)) sum += rs.at(RS_S, slot);   // (the last residual pass already applied every update)
     }
 };
+
+using OpSlackSum = OpSlackSumT<>;
 
 // convex_ineq_satisfied_gusto_jump (scp_gusto.jl:316-343): raw row values against eps
 struct OpCheck {

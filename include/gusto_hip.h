@@ -111,6 +111,17 @@ int gusto_set_env_batch(gusto_handle h, int B, const int* n_box, const double* b
  * level 0: in slices of four iterations).  probe_iters = 0: first come, first served.  Without this call: batches of
  * >= 2048 problems, 2 probing slices for freeflyerSE2, 1 for the other models.  Results do not depend on the schedule. */
 int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch);
+/* How a gusto_solve maps problems to the GPU (new; affects time only -- both kernels run scp_gusto.jl:49-176 on the same
+ * subproblem, scp_gusto.jl:178-314, to the same tolerances).  WAVE: one wavefront per problem, lane k = knot k, the
+ * Newton system staged in LDS (every model).  LANE: one LANE per problem, 64 problems per wavefront, the Riccati recursion
+ * in that lane's registers and its per-knot data streamed through HBM in a [wave][knot][entry][lane] layout -- built for
+ * dubins_car (BASELINE.json configs[2]: n = 3, N = 30, batches of 65 536, where a wave per problem leaves 34 of 64 lanes
+ * idle and spends its time on 3 x 3 blocks); other models ignore the setting.  AUTO (default) = WAVE: as measured on MI355X
+ * the LANE kernel is correct (same trips, statuses and trajectories to 1e-12) but slower at the BASELINE batch sizes, because a
+ * wavefront runs as long as the longest of its 64 problems.  The scheduler of gusto_set_schedule belongs
+ * to the WAVE kernel. */
+enum { GUSTO_DECOMP_AUTO = 0, GUSTO_DECOMP_WAVE = 1, GUSTO_DECOMP_LANE = 2 };
+int gusto_set_decomposition(gusto_handle h, int decomposition);
 /* run on a caller-owned hipStream_t (NULL = a new stream owned by the handle).  Like every setter it first completes
  * a pending gusto_solve_async on the stream that solve was enqueued on. */
 int gusto_set_stream(gusto_handle h, void* hip_stream);
