@@ -189,6 +189,27 @@ template <> struct MT<GUSTO_TO_ASTROBEE_SE3_MANIFOLD> {
 // as the hard band |h_k| <= 1e-4 -- the width of the notebook's own BoxGoal on the goal quaternion (the oracle's GO_TRAJOPT_EQ_BAND)
 constexpr double TRAJOPT_EQ_BAND = 1e-4;
 
+// Warm start of the interior point method (gusto_ipm_opts: mu_warm, mu_warm_gain, mu_warm_max; gusto_hip.h).  The model
+// defaults, resolved on the host when a launch is prepared (mu_warm < 0 = "the model's"): measured on the BASELINE batches
+// (tools/ipm_opts_scan.py).  dubins_car -- bound rows only, most of them inactive -- is best started almost ON the boundary
+// at every trip (3.06 M interior point iterations for the config-3 batch at 1e-10, 3.08 M at 1e-9, 4.15 M at 1e-4); the
+// models with obstacle rows pay for a start that close to the boundary whenever the linearisation point has moved (their
+// first warm trip took 17 iterations against 11 for the cold one), hence the level that follows the last trajectory change.
+inline void warm_defaults(int model, gusto_ipm_opts& io) {
+    if (!(io.mu_warm < 0)) { if (io.mu_warm_gain < 0) io.mu_warm_gain = 0.0; return; }
+    switch (model) {
+    case GUSTO_DUBINS_CAR: io.mu_warm = 1e-9; io.mu_warm_gain = 0.0; io.mu_warm_max = 1e-9; break;
+    case GUSTO_FREEFLYER_SE2: io.mu_warm = 1e-4; io.mu_warm_gain = 0.1; io.mu_warm_max = 1e-2; break;
+    case GUSTO_ASTROBEE_SE3: io.mu_warm = 1e-6; io.mu_warm_gain = 1.0; io.mu_warm_max = 1e-2; break;
+    default: io.mu_warm = 1e-4; io.mu_warm_gain = 1.0; io.mu_warm_max = 1e-2; break;   // (astrobeeSE3manifold)
+    }
+}
+// start level of a warm subproblem: c = the convergence measure of the previous SCP iteration
+GD double warm_mu(const gusto_ipm_opts& io, double c) {
+    if (io.mu_warm == 0.0) return 0.0;
+    return fmin(fmax(io.mu_warm, io.mu_warm_max), fmax(io.mu_warm, io.mu_warm_gain * c * c));
+}
+
 // symmetric packed index (upper triangle, row-major)
 GD constexpr int sidx(int i, int j, int n) {
     return i <= j ? i * n - i * (i - 1) / 2 + (j - i) : j * n - j * (j - 1) / 2 + (i - j);

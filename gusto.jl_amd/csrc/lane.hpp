@@ -947,7 +947,7 @@ template <int MODEL> __global__ void __launch_bounds__(64, 1) lane_kernel(const 
     for (;;) {
         if (alive && phase == 0) {
             if (hook || (iterations < call_cap && n_hist < P.hist_cap && nJ < P.hist_cap && n_rho < P.hist_cap)) {
-                K.lin_init(Delta, omega, (warm && !hook) ? P.io.mu_warm : 0.0);   // :95-102
+                K.lin_init(Delta, omega, (warm && !hook) ? warm_mu(P.io, conv_prev) : 0.0);   // :95-102
                 phase = 1;
             } else {
                 // a history vector is full although iterations remain: say so instead of posing as MaxIter

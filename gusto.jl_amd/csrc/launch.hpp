@@ -35,6 +35,7 @@ template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B, b
     }
     P.hist_cap = h->hist_cap;
     P.sp = h->sp; P.mp = h->mp; P.io = h->io;
+    warm_defaults(MODEL, P.io);
     P.box = h->d_box; P.sph = h->d_sph; P.X = h->d_X; P.U = h->d_U;
     P.x_init = h->d_xinit; P.goal_lo = h->d_glo; P.goal_hi = h->d_ghi; P.tf = h->d_tf;
     P.sub_Delta = h->d_subD; P.sub_omega = h->d_subW; P.sub_toggle = h->d_subT; P.sub_X = h->d_subX; P.sub_U = h->d_subU;

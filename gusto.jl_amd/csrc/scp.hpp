@@ -123,7 +123,7 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
         linearize<MODEL>(K, toggle);                       // :95  update_model_params!
         pf.tick(PF_LIN);
         IpmOut io;
-        ipm_solve<MODEL>(K, Delta, omega, (warm && !hook) ? P.io.mu_warm : 0.0, io, pf);  // :96-104
+        ipm_solve<MODEL>(K, Delta, omega, (warm && !hook) ? warm_mu(P.io, conv_prev) : 0.0, io, pf);  // :96-104
         if (hook) {
             pf.flush(P.prof, b, cont);
             store_traj(K, K.Xw, K.Uw, P.sub_X + (size_t)b * N * n, P.sub_U + (size_t)b * N * m);

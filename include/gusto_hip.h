@@ -73,8 +73,17 @@ typedef struct {
 typedef struct {
     double tol, tol_acc, mu_floor, tr_tol;
     double mu_warm; /* complementarity of the centred start used from the second subproblem of an SCP run on (the
-                       iterate then starts at the previous optimum); 0 = always the cold start */
+                       iterate then starts at the previous optimum); 0 = always the cold start; < 0 (the default) = the model's
+                       own triple (mu_warm, mu_warm_gain, mu_warm_max), see below */
     int max_iter;
+    /* The start level follows the size of the last trajectory change: a subproblem whose linearisation point moved far from
+     * the previous one is started further from the boundary,
+     *     mu_start = min(max(mu_warm, mu_warm_max), max(mu_warm, mu_warm_gain * c^2)),   c = convergence_measure[end]
+     * (traj_opt.jl:74-85, the relative change of the trajectory in the previous SCP iteration).  mu_warm_gain = 0: the fixed
+     * level mu_warm.  Model defaults (measured, tools/ipm_opts_scan.py; an internal heuristic of the interior point method, the
+     * optimum it converges to is the same): freeflyerSE2 (1e-4, 0.1, 1e-2), dubins_car (1e-9, 0, -), astrobeeSE3
+     * (1e-6, 1, 1e-2), astrobeeSE3manifold (1e-4, 1, 1e-2). */
+    double mu_warm_gain, mu_warm_max;
 } gusto_ipm_opts;
 
 typedef struct gusto_handle_s* gusto_handle;

@@ -243,7 +243,8 @@ void go_default_params(int model, go_scp_params* sp, go_model_params* mp) {
     }
 }
 void go_default_ipm_opts(go_ipm_opts* o) {
-    o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = 1e-11; o->tr_tol = 1e-6; o->mu_warm = 1e-4; o->max_iter = 60;
+    o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = 1e-11; o->tr_tol = 1e-6; o->max_iter = 60;
+    o->mu_warm = -1.0; o->mu_warm_gain = -1.0; o->mu_warm_max = -1.0; /* the model's warm-start triple */
 }
 int go_model_dims(int model, int* n, int* m) {
     switch (model) {
@@ -1028,7 +1029,18 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
      * freeflyer batch).  Warm (the iterate starts at the optimum of the previous subproblem): every penalised row is
      * put ON the central path at mu_warm for its value g at the start point -- s - t = g, t*lam_a = s*lam_b = mu,
      * lam_a + lam_b = 1  <=>  s,t = mu + (sqrt(g^2 + 4 mu^2) +- g)/2 -- and hard rows get lam = mu/t. */
-    const double muw = p->warm ? io->mu_warm : 0.0;
+    double muw = 0.0;
+    if (p->warm) { /* start level from the size of the last trajectory change (gusto_hip.h: gusto_ipm_opts, common.hpp: warm_mu) */
+        double lo = io->mu_warm, gain = io->mu_warm_gain, hi = io->mu_warm_max;
+        if (lo < 0) { /* the model's triple, as common.hpp: warm_defaults */
+            if (p->model == GO_DUBINS_CAR) { lo = 1e-9; gain = 0.0; hi = 1e-9; }
+            else if (p->model == GO_FREEFLYER_SE2) { lo = 1e-4; gain = 0.1; hi = 1e-2; }
+            else if (p->model == GO_ASTROBEE_SE3) { lo = 1e-6; gain = 1.0; hi = 1e-2; }
+            else { lo = 1e-4; gain = 1.0; hi = 1e-2; }
+        } else if (gain < 0) gain = 0.0;
+        const double c = p->n_hist >= 1 ? p->conv[p->n_hist - 1] : 0.0;
+        muw = (lo == 0.0) ? 0.0 : fmin(fmax(lo, hi), fmax(lo, gain * c * c));
+    }
     p->warm = 0;
     int ncomp = 0;
     for (int i = 0; i < nr; i++) {

@@ -62,8 +62,10 @@ typedef struct {
     double mu_floor;   /* smallest complementarity target                        */
     double tr_tol;     /* slack on the `max||dx||^2 - Delta <= 0` post-check     */
     double mu_warm;    /* centred start at this mu once a subproblem of the same SCP run has been solved
-                          (the iterate starts at the previous optimum); 0 = always the cold start */
+                          (the iterate starts at the previous optimum); 0 = always the cold start; < 0 = the model's triple */
     int max_iter;
+    double mu_warm_gain; /* start level = min(max(mu_warm, mu_warm_max), max(mu_warm, mu_warm_gain * conv[end]^2)): it follows */
+    double mu_warm_max;  /* the size of the last trajectory change (gusto_hip.h: gusto_ipm_opts)                              */
 } go_ipm_opts;
 
 /* Study knob (tests/test_oracle_scp.py): alternative models of what the reference's external
