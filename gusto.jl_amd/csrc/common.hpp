@@ -204,6 +204,12 @@ inline void warm_defaults(int model, gusto_ipm_opts& io) {
     default: io.mu_warm = 1e-4; io.mu_warm_gain = 1.0; io.mu_warm_max = 1e-2; break;   // (astrobeeSE3manifold)
     }
 }
+// An interior point solve whose mean complementarity has grown to this multiple of max(1, its value at the start point) is
+// diverging -- the subproblem is infeasible (dubins_car: 7 % of the config-3 batch at trip 0, certified by an LP in
+// tests/test_oracle_scp.py; mu then runs to 1e15 and the multipliers to 1e20 before the iteration cap ends the solve with the
+// same verdict, GUSTO_SOLVER_FAILED): stop there instead of at the cap.  Convergent solves never come near it (their mu
+// falls from the first iteration on; checked on every BASELINE batch: identical statuses with and without the test).
+constexpr double IPM_DIVERGED = 1e3;
 // start level of a warm subproblem: c = the convergence measure of the previous SCP iteration
 GD double warm_mu(const gusto_ipm_opts& io, double c) {
     if (io.mu_warm == 0.0) return 0.0;

@@ -2832,8 +2832,8 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         }
         K.sync();
     }
-    int status = GUSTO_SOLVER_FAILED, it = 0;
-    double res_p = 0, res_d = 0, mu = 0, alpha_prev = 0.0;
+    int status = GUSTO_SOLVER_FAILED, it = 0, n_acc = 0;
+    double res_p = 0, res_d = 0, mu = 0, alpha_prev = 0.0, mu_start = 0.0;
     for (it = 0;; it++) {
         GUSTO_REFRESH_K();
         // (1) linearised xdot at each knot: a_k = f_k + A_k (x_k - xp_k) + B (u_k - up_k)
@@ -2880,11 +2880,15 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         K.sync();
         pf.tick(PF_RESID);
         if (res_p <= io.tol && res_d <= io.tol * (1 + numax) && mu <= 0.1 * io.tol) { status = GUSTO_SOLVER_OPTIMAL; break; }
-        if (it >= io.max_iter) {
-            if (res_p <= io.tol_acc && res_d <= io.tol_acc * (1 + numax) && mu <= io.tol_acc) status = GUSTO_SOLVER_ALMOST;
+        const bool acceptable = res_p <= io.tol_acc && res_d <= io.tol_acc * (1 + numax) && mu <= io.tol_acc;
+        n_acc = acceptable ? n_acc + 1 : 0;   // (gusto_ipm_opts.acc_iter: a solve that cycles at the acceptable level does not run to the cap)
+        if (it >= io.max_iter || (io.acc_iter > 0 && n_acc >= io.acc_iter)) {
+            if (acceptable) status = GUSTO_SOLVER_ALMOST;
             break;
         }
         if (!isfinite(res_p) || !isfinite(res_d) || !isfinite(mu)) break;
+        if (it == 0) mu_start = mu;
+        if (mu > IPM_DIVERGED * fmax(1.0, mu_start)) break;   // (diverging: an infeasible subproblem, common.hpp)
         pf.tick(PF_BUILD);
         // (4) factorise
         factor_sweep<MODEL>(K, fail, pf);

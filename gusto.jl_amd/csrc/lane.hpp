@@ -104,8 +104,8 @@ template <int MODEL> struct LaneSolver {
 
     // ---- interior point state of the running subproblem (registers of the lane) ----
     double Delta, omega, kappa, muw;
-    int it, status, ncomp;
-    double alpha_prev, mu, resp, resd, obj;
+    int it, status, ncomp, n_acc;
+    double alpha_prev, mu, resp, resd, obj, mu_start;
     double mug[n], nu0[n];
 
     GD LaneSolver(const KParams& P_, double* ws, int wave, int lane_, int b_) : P(P_), lane(lane_), b(b_), N(P_.N) {
@@ -224,7 +224,7 @@ template <int MODEL> struct LaneSolver {
     GD void lin_init(double Delta_, double omega_, double muw_) {
         Delta = Delta_; omega = omega_; muw = muw_;
         kappa = 1.0 / fmax(1.0, omega);
-        it = 0; status = GUSTO_SOLVER_FAILED; alpha_prev = 0.0; mu = 0; resp = 0; resd = 0; obj = 0;
+        it = 0; n_acc = 0; status = GUSTO_SOLVER_FAILED; alpha_prev = 0.0; mu = 0; resp = 0; resd = 0; obj = 0;
         int nc = 0;
 #pragma unroll
         for (int i = 0; i < n; i++) { mug[i] = 0; nu0[i] = 0; }
@@ -878,11 +878,15 @@ template <int MODEL> struct LaneSolver {
         Fact F;
         passA(F);
         if (resp <= io.tol && resd <= io.tol * (1 + numax_) && mu <= 0.1 * io.tol) { status = GUSTO_SOLVER_OPTIMAL; return true; }
-        if (it >= io.max_iter) {
-            if (resp <= io.tol_acc && resd <= io.tol_acc * (1 + numax_) && mu <= io.tol_acc) status = GUSTO_SOLVER_ALMOST;
+        const bool acceptable = resp <= io.tol_acc && resd <= io.tol_acc * (1 + numax_) && mu <= io.tol_acc;
+        n_acc = acceptable ? n_acc + 1 : 0;
+        if (it >= io.max_iter || (io.acc_iter > 0 && n_acc >= io.acc_iter)) {
+            if (acceptable) status = GUSTO_SOLVER_ALMOST;
             return true;
         }
         if (!isfinite(resp) || !isfinite(resd) || !isfinite(mu)) return true;
+        if (it == 0) mu_start = mu;
+        if (mu > IPM_DIVERGED * fmax(1.0, mu_start)) return true;   // (diverging: an infeasible subproblem, common.hpp)
         if (F.fail) return true;
         // predictor (mu_t = 0) and centred corrector share the factorisation
         double alpha, mu_t;

@@ -76,6 +76,11 @@ typedef struct {
                        iterate then starts at the previous optimum); 0 = always the cold start; < 0 (the default) = the model's
                        own triple (mu_warm, mu_warm_gain, mu_warm_max), see below */
     int max_iter;
+    int acc_iter;   /* stop with ALMOST_LOCALLY_SOLVED once the acceptable level tol_acc has held for this many consecutive
+                       iterations without reaching tol (Ipopt's acceptable_iter; the reference takes MOI.ALMOST_LOCALLY_SOLVED as
+                       solved, scp_gusto.jl:107).  0 = only at the iteration cap.  An interior point solve that cycles at the 1e-6
+                       level (seen on astrobeeSE3manifold: a period-4 cycle of mu between 3e-10 and 3e-9) then costs 10 extra
+                       iterations instead of running to the cap of 60 */
     /* The start level follows the size of the last trajectory change: a subproblem whose linearisation point moved far from
      * the previous one is started further from the boundary,
      *     mu_start = min(max(mu_warm, mu_warm_max), max(mu_warm, mu_warm_gain * c^2)),   c = convergence_measure[end]

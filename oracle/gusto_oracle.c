@@ -243,7 +243,7 @@ void go_default_params(int model, go_scp_params* sp, go_model_params* mp) {
     }
 }
 void go_default_ipm_opts(go_ipm_opts* o) {
-    o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = 1e-11; o->tr_tol = 1e-6; o->max_iter = 60;
+    o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = 1e-11; o->tr_tol = 1e-6; o->max_iter = 60; o->acc_iter = 0;
     o->mu_warm = -1.0; o->mu_warm_gain = -1.0; o->mu_warm_max = -1.0; /* the model's warm-start triple */
 }
 int go_model_dims(int model, int* n, int* m) {
@@ -998,6 +998,7 @@ static void riccati_solve(go_problem* p, int ng, const int* gidx, const double* 
  *   min  kappa * sum_k w_k |u_k|^2 + sum_pen s_i
  *   s.t. x_1 = x_init, C x_N = goal, trapezoid rows (hard);  mul*g_i - off <= 0 (hard rows);
  *        mul*g_i - off <= s_i, s_i >= 0 (penalised rows)                                          */
+#define GO_IPM_DIVERGED 1e3
 static double max_step(double a, double v, double dv, double tau) {
     if (dv < 0) { double c = -tau * v / dv; if (c < a) a = c; }
     return a;
@@ -1065,8 +1066,8 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
     double wk[256];
     for (int k = 0; k < N; k++) wk[k] = kappa * ((k == 0 || k == N - 1) ? 0.5 * p->dt : p->dt);
 
-    int status = GO_SOLVER_FAILED, it;
-    double res_p = 0, res_d = 0, mu = 0, rg[NX];
+    int status = GO_SOLVER_FAILED, it, n_acc = 0;
+    double res_p = 0, res_d = 0, mu = 0, mu_start = 0, rg[NX];
     for (it = 0;; it++) {
         /* residuals ----------------------------------------------------------------------- */
         res_p = 0;
@@ -1153,11 +1154,15 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
         }
         if (getenv("GO_DEBUG_IPM")) fprintf(stderr, "   test: res_p %.3e res_d %.3e numax %.3e mu %.3e tol %.3e\n", res_p, res_d, numax, mu, io->tol);
         if (res_p <= io->tol && res_d <= io->tol * (1 + numax) && mu <= 0.1 * io->tol) { status = GO_SOLVER_OPTIMAL; break; }
-        if (it >= io->max_iter) {
-            if (res_p <= io->tol_acc && res_d <= io->tol_acc * (1 + numax) && mu <= io->tol_acc) status = GO_SOLVER_ALMOST;
+        const int acceptable = res_p <= io->tol_acc && res_d <= io->tol_acc * (1 + numax) && mu <= io->tol_acc;
+        n_acc = acceptable ? n_acc + 1 : 0;
+        if (it >= io->max_iter || (io->acc_iter > 0 && n_acc >= io->acc_iter)) {
+            if (acceptable) status = GO_SOLVER_ALMOST;
             break;
         }
         if (!isfinite(res_p) || !isfinite(res_d) || !isfinite(mu)) break;
+        if (it == 0) mu_start = mu;
+        if (mu > GO_IPM_DIVERGED * fmax(1.0, mu_start)) break; /* diverging: an infeasible subproblem (common.hpp: IPM_DIVERGED) */
 
         /* Hessian blocks (shared by predictor and corrector) ----------------------------------- */
         memset(p->Hx, 0, sizeof(double) * n * n * N);

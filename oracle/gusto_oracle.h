@@ -64,6 +64,7 @@ typedef struct {
     double mu_warm;    /* centred start at this mu once a subproblem of the same SCP run has been solved
                           (the iterate starts at the previous optimum); 0 = always the cold start; < 0 = the model's triple */
     int max_iter;
+    int acc_iter;        /* ALMOST once tol_acc has held for this many consecutive iterations (0: only at the cap) */
     double mu_warm_gain; /* start level = min(max(mu_warm, mu_warm_max), max(mu_warm, mu_warm_gain * conv[end]^2)): it follows */
     double mu_warm_max;  /* the size of the last trajectory change (gusto_hip.h: gusto_ipm_opts)                              */
 } go_ipm_opts;
