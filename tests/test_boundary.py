@@ -66,6 +66,7 @@ def test_bad_arguments_are_rejected():
     assert L.gusto_solve_async(None, 30, 0) == -1
     assert L.gusto_wait(None) == -1
     assert L.gusto_set_schedule(None, 2, 2048) == -1
+    assert L.gusto_set_decomposition(None, 1) == -1
 
 
 def test_product_never_imports_the_oracle():
