@@ -888,3 +888,27 @@ def test_freeflyer_launch_keeps_four_problems_per_cu():
     s.solve(3)
     slots, lds, per_cu = s.launch_info()
     assert per_cu == 4 and lds <= 160 * 1024 // 4 and slots == min(B, slots) and slots % per_cu == 0
+
+
+def test_warm_start_defaults_on_device_are_the_documented_triples():
+    """gusto_ipm_opts.mu_warm < 0 = the model's triple (gusto_hip.h, common.hpp: warm_defaults): the same batch with the
+    documented triple spelled out is the default run bit for bit; the oracle's table is held to the same numbers by
+    tests/test_oracle_scp.py, and the parity tests compare the two defaults."""
+    g, _ = _mods()
+    P = g.problems
+    boxes, spheres = P.iss_corner_env(True)
+    cases = [(g.FREEFLYER_SE2, 50, P.freeflyer_env(), None, P.freeflyer_batch(64), (1e-4, 0.1, 1e-2)),
+             (g.DUBINS_CAR, 30, None, None, P.dubins_batch(256), (1e-9, 0.0, 1e-9)),
+             (g.ASTROBEE_SE3, 50, boxes, spheres, P.astrobee_se3_batch(32), (1e-6, 1.0, 1e-2)),
+             (g.ASTROBEE_SE3_MANIFOLD, 50, boxes, spheres, P.astrobee_manifold_batch(32), (1e-4, 1.0, 1e-2))]
+    for model, N, bx, sp, (x0, glo, ghi, tf), (lo, gain, hi) in cases:
+        io = g.default_ipm_opts()
+        io.mu_warm, io.mu_warm_gain, io.mu_warm_max = lo, gain, hi
+        out = []
+        for opts in (None, io):
+            s = g.BatchSolver(model, N, len(x0), hist_cap=40, boxes=bx, spheres=sp, ipm_opts=opts)
+            s.set_problems(x0, glo, ghi, tf)
+            s.solve(30)
+            out.append((s.traj()[0], s.status()["ipm_iters"].copy()))
+        np.testing.assert_array_equal(out[0][0], out[1][0])
+        np.testing.assert_array_equal(out[0][1], out[1][1])
