@@ -917,22 +917,32 @@ template <int MODEL> __global__ void __launch_bounds__(64, 1) lane_kernel(const 
     using Y = LaneLay<MODEL>;
     constexpr int n = T::n, m = T::m;
     const int lane = threadIdx.x, wave = blockIdx.x;
-    const int b = wave * lanes_per_wave + lane;
-    bool alive = lane < lanes_per_wave && b < P.B;
-    LaneSolver<MODEL> K(P, P.ws, wave, lane, alive ? b : 0);
+    const int b0 = wave * lanes_per_wave + lane;
+    bool alive = false;
+    LaneSolver<MODEL> K(P, P.ws, wave, lane, 0);
     const bool hook = P.mode == 1;
     const gusto_scp_params& sp = P.sp;
-    int* sti = P.st_i + (size_t)K.b * ST_NI;
-    double* std_ = P.st_d + (size_t)K.b * SD_ND;
-    const size_t hb = (size_t)K.b * P.hist_cap;
+    int* sti = P.st_i;
+    double* std_ = P.st_d;
+    size_t hb = 0;
     int iterations = 0, converged = 0, successful = 0, stop = GUSTO_STOP_MAXITER, total_ipm = 0, n_hist = 1, nJ = 0, n_rho = 1, call_cap = 0;
     double Delta = 0, omega = 0, toggle = 0, conv_prev = 0, Jt = 0;
     bool warm = false;
-    int phase = 0;   // 0: at the top of the GuSTO loop, 1: inside the interior point method
-    if (alive) {
+    // 0: at the top of the GuSTO loop, 1: inside the interior point method, 2: stopped, state to be written back,
+    // 3: wants the next problem of the batch, 5: retired (the batch has no more)
+    int phase = 5;
+    // PERSISTENT lanes: the grid is what the GPU keeps resident (one wave per SIMD), a lane that has finished its problem takes
+    // the next one of the batch from a counter (KParams::queue[SQ_HEAD_A], preset to the number of problems handed out at
+    // launch).  A wave therefore runs as long as the longest SEQUENCE of problems among its lanes -- with many problems per
+    // lane that evens out, which is what makes this decomposition the faster one for batches of several hundred thousand.
+    auto start_problem = [&](int bb) {
+        K.b = bb;
+        sti = P.st_i + (size_t)bb * ST_NI;
+        std_ = P.st_d + (size_t)bb * SD_ND;
+        hb = (size_t)bb * P.hist_cap;
         K.bind_problem();
         K.load_traj();
-        iterations = sti[ST_ITER]; converged = sti[ST_CONV]; successful = sti[ST_SUCC];
+        iterations = sti[ST_ITER]; converged = sti[ST_CONV]; successful = sti[ST_SUCC]; stop = GUSTO_STOP_MAXITER;
         total_ipm = sti[ST_IPM]; n_hist = sti[ST_NHIST]; nJ = sti[ST_NJ]; n_rho = sti[ST_NRHO];
         call_cap = iterations + P.max_iter;   // scp_gusto.jl:67
         if (!hook) {   // scp_gusto.jl:73-76
@@ -942,13 +952,19 @@ template <int MODEL> __global__ void __launch_bounds__(64, 1) lane_kernel(const 
             if (n_rho < P.hist_cap) P.rho[hb + n_rho] = rho0;
             nJ++; n_rho++;
         }
-        Delta = hook ? P.sub_Delta[K.b] : P.Delta[hb + n_hist - 1];
-        omega = hook ? P.sub_omega[K.b] : P.omega[hb + n_hist - 1];
-        toggle = hook ? P.sub_toggle[K.b] : Delta / 8 + P.mp.clearance;
+        Delta = hook ? P.sub_Delta[bb] : P.Delta[hb + n_hist - 1];
+        omega = hook ? P.sub_omega[bb] : P.omega[hb + n_hist - 1];
+        toggle = hook ? P.sub_toggle[bb] : Delta / 8 + P.mp.clearance;
         conv_prev = (n_hist >= 1) ? P.conv[hb + n_hist - 1] : 0.0;
         warm = sti[ST_WARM] != 0;   // the previous subproblem ended OPTIMAL: the next one starts centred at mu_warm
-    }
+        alive = true; phase = 0;
+    };
+    if (lane < lanes_per_wave && b0 < P.B) start_problem(b0);
     for (;;) {
+        if (phase == 3) {   // the next problem of the batch, if there is one
+            const int nb = (lane < lanes_per_wave) ? atomicAdd(P.queue + SQ_HEAD_A, 1) : P.B;
+            if (nb < P.B) start_problem(nb); else phase = 5;
+        }
         if (alive && phase == 0) {
             if (hook || (iterations < call_cap && n_hist < P.hist_cap && nJ < P.hist_cap && n_rho < P.hist_cap)) {
                 K.lin_init(Delta, omega, (warm && !hook) ? warm_mu(P.io, conv_prev) : 0.0);   // :95-102
@@ -968,7 +984,7 @@ template <int MODEL> __global__ void __launch_bounds__(64, 1) lane_kernel(const 
             std_[SD_TOGGLE] = toggle;
             phase = 3;
         }
-        if (__ballot(alive) == 0) break;
+        if (__ballot(alive || phase == 3) == 0) break;
         bool fin = false;
         if (alive) fin = K.ipm_iteration();   // :96-104, one Newton step of it
         if (alive && fin) {

@@ -163,7 +163,12 @@ template <int MODEL> static int launch_lane(gusto_handle h, int mode, int max_it
     int lpw = 64;
     if (const char* e = getenv("GUSTO_DEV_LANES_PER_WAVE")) lpw = std::max(1, std::min(64, atoi(e)));
     else while (lpw > 8 && (h->B + lpw - 1) / lpw < 4 * std::max(1, cus)) lpw >>= 1;
-    const int nw = (h->B + lpw - 1) / lpw;
+    // persistent lanes: at most the waves the GPU keeps resident (one per SIMD at this kernel's register budget); a lane that
+    // finishes takes the next problem of the batch (lane.hpp)
+    int per_cu = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lane_kernel<MODEL>), 64, 0));
+    int nw = std::min((h->B + lpw - 1) / lpw, std::max(1, per_cu) * std::max(1, cus));
+    if (const char* e = getenv("GUSTO_DEV_SLOTS")) nw = std::max(1, std::min(nw, atoi(e)));
     const size_t need = (size_t)nw * (size_t)h->N * (size_t)(Y::EK * 64);
     if (need > h->ws_doubles) {
         if (h->d_ws) hipFree(h->d_ws);
@@ -172,8 +177,11 @@ template <int MODEL> static int launch_lane(gusto_handle h, int mode, int max_it
         h->ws_doubles = need;
     }
     P.ws = h->d_ws;
-    h->slots = nw; h->lds_bytes = 0; h->per_cu = 4;
-    if (h->d_queue) HIPCHK(h, hipMemsetAsync(h->d_queue, 0, SQ_WORDS * sizeof(int), h->stream));
+    h->slots = nw; h->lds_bytes = 0; h->per_cu = per_cu;
+    memset(h->sched_init, 0, sizeof(h->sched_init));
+    h->sched_init[SQ_HEAD_A] = std::min(h->B, nw * lpw);   // the problems handed out at launch: the counter's start
+    HIPCHK(h, hipMemcpyAsync(h->d_queue, h->sched_init, SQ_WORDS * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    P.queue = h->d_queue;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(lane_kernel<MODEL>, dim3(nw), dim3(64), 0, h->stream, P, lpw);
     HIPCHK(h, hipGetLastError());
