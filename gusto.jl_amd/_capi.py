@@ -46,7 +46,7 @@ class ModelParams(C.Structure):
 
 class IpmOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("tol_acc", C.c_double), ("mu_floor", C.c_double), ("tr_tol", C.c_double),
-                ("mu_warm", C.c_double), ("max_iter", C.c_int), ("acc_iter", C.c_int), ("mu_warm_gain", C.c_double), ("mu_warm_max", C.c_double)]
+                ("mu_warm", C.c_double), ("max_iter", C.c_int), ("acc_iter", C.c_int), ("mu_warm_gain", C.c_double), ("mu_warm_max", C.c_double), ("sigma_max", C.c_double)]
 
 
 class ShootOpts(C.Structure):

@@ -196,6 +196,13 @@ constexpr double TRAJOPT_EQ_BAND = 1e-4;
 // models with obstacle rows pay for a start that close to the boundary whenever the linearisation point has moved (their
 // first warm trip took 17 iterations against 11 for the cold one), hence the level that follows the last trajectory change.
 inline void warm_defaults(int model, gusto_ipm_opts& io) {
+    // (complementarity floor: a tenth of the stopping level for the manifold model -- at 1e-11 the dual residual of its converged
+    // solves sits at its noise floor, 5e-8, for ten iterations before it passes the 3e-8 test: -14 % KKT solves on config 5 --,
+    // a hundredth for the others, whose hard problems agree with the oracle 30 x better that way)
+    if (io.mu_floor < 0) io.mu_floor = (model == GUSTO_ASTROBEE_SE3_MANIFOLD) ? 1e-10 : 1e-11;
+    // (Mehrotra's centring parameter is bounded for GuSTO's subproblems, gusto_hip.h; TrajOpt's -- close to linear programs in
+    // their defect variables -- keep the unbounded rule they were validated with)
+    if (io.sigma_max < 0) io.sigma_max = (model == GUSTO_TO_FREEFLYER_SE2 || model == GUSTO_TO_ASTROBEE_SE3 || model == GUSTO_TO_ASTROBEE_SE3_MANIFOLD) ? 0.0 : 0.1;
     if (!(io.mu_warm < 0)) { if (io.mu_warm_gain < 0) io.mu_warm_gain = 0.0; return; }
     switch (model) {
     case GUSTO_DUBINS_CAR: io.mu_warm = 1e-9; io.mu_warm_gain = 0.0; io.mu_warm_max = 1e-9; break;

@@ -81,8 +81,8 @@ int gusto_default_params(int model, gusto_scp_params* sp, gusto_model_params* mp
 
 int gusto_default_ipm_opts(gusto_ipm_opts* o) {
     if (!o) return GUSTO_ERR_ARG;
-    o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = 1e-11; o->tr_tol = 1e-6; o->max_iter = 60; o->acc_iter = 0;
-    o->mu_warm = -1.0; o->mu_warm_gain = -1.0; o->mu_warm_max = -1.0;   // the model's warm-start triple (common.hpp: warm_defaults)
+    o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = -1.0 /* the model's, common.hpp: warm_defaults */; o->tr_tol = 1e-6; o->max_iter = 60; o->acc_iter = 0;
+    o->mu_warm = -1.0; o->mu_warm_gain = -1.0; o->mu_warm_max = -1.0; o->sigma_max = -1.0;   // (the algorithm's: 0.1 for GuSTO, none for TrajOpt; common.hpp: warm_defaults)   // the model's warm-start triple (common.hpp: warm_defaults)
     return GUSTO_OK;
 }
 

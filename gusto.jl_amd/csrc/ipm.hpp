@@ -3010,6 +3010,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 const double mu_aff = ncomp > 0 ? ca / ncomp : 0.0;
                 const double rr = (mu > 0) ? mu_aff / mu : 0.0;
                 sigma = rr * rr * rr;
+                if (io.sigma_max > 0) sigma = fmin(sigma, io.sigma_max);   // (gusto_hip.h: the corrector always aims at a real reduction of mu)
                 mu_t = fmax(sigma * mu, io.mu_floor);
                 if (ncomp == 0) break;  // equality-constrained QP: the predictor already is the Newton step
             }

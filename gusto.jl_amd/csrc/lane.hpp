@@ -896,7 +896,9 @@ template <int MODEL> struct LaneSolver {
             const double ca = r.c0 + r.amax * (r.c1 + r.amax * r.c2);   // complementarity after the affine step
             const double mu_aff = ncomp > 0 ? ca / ncomp : 0.0;
             const double rr = (mu > 0) ? mu_aff / mu : 0.0;
-            mu_t = fmax(rr * rr * rr * mu, io.mu_floor);
+            double sigma = rr * rr * rr;
+            if (io.sigma_max > 0) sigma = fmin(sigma, io.sigma_max);
+            mu_t = fmax(sigma * mu, io.mu_floor);
         }
         if (ncomp != 0) {   // (an equality-constrained QP: the predictor already is the Newton step)
             passC(F, mu_t);

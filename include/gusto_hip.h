@@ -71,7 +71,7 @@ typedef struct {
  * makes the verdict independent of solver noise; tr_tol = 0 selects the literal test (1 of the 44 844 accept / reject decisions
  * of the 4096-problem freeflyerSE2 batch changes; tests/test_gpu_parity.py runs both settings against the oracle). */
 typedef struct {
-    double tol, tol_acc, mu_floor, tr_tol;
+    double tol, tol_acc, mu_floor /* smallest complementarity target; < 0 (default): 1e-10 for astrobeeSE3manifold, 1e-11 otherwise */, tr_tol;
     double mu_warm; /* complementarity of the centred start used from the second subproblem of an SCP run on (the
                        iterate then starts at the previous optimum); 0 = always the cold start; < 0 (the default) = the model's
                        own triple (mu_warm, mu_warm_gain, mu_warm_max), see below */
@@ -89,6 +89,13 @@ typedef struct {
      * optimum it converges to is the same): freeflyerSE2 (1e-4, 0.1, 1e-2), dubins_car (1e-9, 0, -), astrobeeSE3
      * (1e-6, 1, 1e-2), astrobeeSE3manifold (1e-4, 1, 1e-2). */
     double mu_warm_gain, mu_warm_max;
+    /* Upper bound of Mehrotra's centring parameter sigma = (mu_aff / mu)^3: the corrector never aims at less than a
+     * (1 - sigma_max) reduction of the complementarity.  Without the bound (sigma_max >= 1) a predictor that makes no progress
+     * sets sigma ~ 1, and the method can then cycle near the solution (mu between 3e-10 and 3e-9 with period 4, traced on
+     * astrobeeSE3manifold) until the iteration cap, or fail.  Default (< 0): 0.1 for gusto_solve, none for gusto_solve_trajopt
+     * (whose subproblems were validated with the unbounded rule); measured on the BASELINE batches: SubproblemFailed
+     * 23 -> 1 of 4096 (freeflyerSE2), 22 -> 0 of 8192 (astrobeeSE3), 10 -> 7 of 2048 (manifold), and 1-3 % fewer KKT solves. */
+    double sigma_max;
 } gusto_ipm_opts;
 
 typedef struct gusto_handle_s* gusto_handle;

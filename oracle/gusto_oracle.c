@@ -243,8 +243,9 @@ void go_default_params(int model, go_scp_params* sp, go_model_params* mp) {
     }
 }
 void go_default_ipm_opts(go_ipm_opts* o) {
-    o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = 1e-11; o->tr_tol = 1e-6; o->max_iter = 60; o->acc_iter = 0;
+    o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = -1.0 /* the model's */; o->tr_tol = 1e-6; o->max_iter = 60; o->acc_iter = 0;
     o->mu_warm = -1.0; o->mu_warm_gain = -1.0; o->mu_warm_max = -1.0; /* the model's warm-start triple */
+    o->sigma_max = -1.0; /* the algorithm's: 0.1 for GuSTO, none for TrajOpt */
 }
 int go_model_dims(int model, int* n, int* m) {
     switch (model) {
@@ -1008,7 +1009,12 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
                      go_sub_info* info) {
     const int n = p->n, m = p->m, N = p->N;
     const double kappa = 1.0 / fmax(1.0, omega);
-    const go_ipm_opts* io = &p->io;
+    go_ipm_opts io_resolved = p->io;
+    /* complementarity floor of the model (gusto_hip.h: mu_floor < 0; common.hpp: warm_defaults): the manifold model's solves sit
+     * at the noise floor of their dual residual for ten iterations when mu is driven to 1e-11 */
+    if (io_resolved.mu_floor < 0) io_resolved.mu_floor = (p->model == GO_ASTROBEE_SE3_MANIFOLD && !p->trajopt) ? 1e-10 : 1e-11;
+    if (io_resolved.sigma_max < 0) io_resolved.sigma_max = p->trajopt ? 0.0 : 0.1;
+    const go_ipm_opts* io = &io_resolved;
     int gidx[NX], ng = 0;
     double gval[NX];
     for (int i = 0; i < n; i++)
@@ -1251,6 +1257,7 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
                 }
                 double mu_aff = ncomp ? ca / ncomp : 0.0;
                 sigma = (mu > 0) ? pow(mu_aff / mu, 3.0) : 0.0;
+                if (io->sigma_max > 0) sigma = fmin(sigma, io->sigma_max); /* (gusto_hip.h: gusto_ipm_opts.sigma_max) */
                 mu_t = fmax(sigma * mu, io->mu_floor);
                 if (ncomp == 0) break; /* equality-constrained QP: the predictor is the Newton step */
             }

@@ -67,6 +67,7 @@ typedef struct {
     int acc_iter;        /* ALMOST once tol_acc has held for this many consecutive iterations (0: only at the cap) */
     double mu_warm_gain; /* start level = min(max(mu_warm, mu_warm_max), max(mu_warm, mu_warm_gain * conv[end]^2)): it follows */
     double mu_warm_max;  /* the size of the last trajectory change (gusto_hip.h: gusto_ipm_opts)                              */
+    double sigma_max;    /* upper bound of Mehrotra's centring parameter (<= 0: none)                                          */
 } go_ipm_opts;
 
 /* Study knob (tests/test_oracle_scp.py): alternative models of what the reference's external

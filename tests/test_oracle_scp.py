@@ -265,7 +265,7 @@ def test_warm_start_defaults_are_the_documented_triples():
     table in ipm_solve): a run with the documented triple spelled out must be bit for bit the run with the defaults, and both
     libraries hand out the sentinel."""
     d = g.default_ipm_opts()
-    assert d.mu_warm < 0 and d.mu_warm_gain < 0 and d.acc_iter == 0 and d.mu_floor == 1e-11 and d.tol == 1e-8
+    assert d.mu_warm < 0 and d.mu_warm_gain < 0 and d.acc_iter == 0 and d.tol == 1e-8 and d.sigma_max < 0 and d.mu_floor < 0
     boxes, spheres = P.iss_corner_env(True)
     cases = [(go.FREEFLYER_SE2, 50, P.freeflyer_env(), None, P.freeflyer_batch(3), (1e-4, 0.1, 1e-2)),
              (go.DUBINS_CAR, 30, None, None, P.dubins_batch(4), (1e-9, 0.0, 1e-9)),
@@ -273,8 +273,8 @@ def test_warm_start_defaults_are_the_documented_triples():
              (go.ASTROBEE_SE3_MANIFOLD, 50, boxes, spheres, P.astrobee_manifold_batch(2), (1e-4, 1.0, 1e-2))]
     for model, N, bx, sp, (x0, glo, ghi, tf), (lo, gain, hi) in cases:
         a = go.Oracle(model, N, boxes=bx, spheres=sp)
-        io = go.IpmOpts(tol=1e-8, tol_acc=1e-5, mu_floor=1e-11, tr_tol=1e-6, mu_warm=lo, max_iter=60, acc_iter=0, mu_warm_gain=gain,
-                        mu_warm_max=hi)
+        io = go.IpmOpts(tol=1e-8, tol_acc=1e-5, mu_floor=1e-10 if model == go.ASTROBEE_SE3_MANIFOLD else 1e-11, tr_tol=1e-6, mu_warm=lo, max_iter=60, acc_iter=0, mu_warm_gain=gain,
+                        mu_warm_max=hi, sigma_max=0.1)
         b = go.Oracle(model, N, boxes=bx, spheres=sp, ipm_opts=io)
         for k in range(len(x0)):
             a.set_problem(x0[k], glo[k], ghi[k], tf[k]); b.set_problem(x0[k], glo[k], ghi[k], tf[k])

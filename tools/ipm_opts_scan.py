@@ -23,6 +23,7 @@ for spec, fl, ac in [(a, b, c) for a in os.environ.get("MUW", "auto,1e-4").split
     io = g.default_ipm_opts()
     if fl > 0: io.mu_floor = fl
     if ac >= 0: io.acc_iter = ac
+    if os.environ.get("SIGMAX"): io.sigma_max = float(os.environ["SIGMAX"])
     mw = spec
     if spec != "auto":
         f = [float(x) for x in spec.split(":")]
@@ -31,6 +32,6 @@ for spec, fl, ac in [(a, b, c) for a in os.environ.get("MUW", "auto,1e-4").split
     for rep in range(2):
         s.set_problems(x0, glo, ghi, tf); s.solve(30)
     st = s.status()
-    print(f"model {model} mu_warm {mw} mu_floor {io.mu_floor:g} acc_iter {io.acc_iter}: kernel {s.last_solve_ms():.1f} ms conv {st['converged'].sum()} succ {st['successful'].sum()} "
+    print(f"model {model} mu_warm {mw} mu_floor {io.mu_floor:g} acc_iter {io.acc_iter} sigma_max {io.sigma_max:g}: kernel {s.last_solve_ms():.1f} ms conv {st['converged'].sum()} succ {st['successful'].sum()} "
           f"ipm {st['ipm_iters'].sum()} trips {st['iterations'].sum()} stops {np.bincount(st['stop_reason'], minlength=5)}", flush=True)
     del s
