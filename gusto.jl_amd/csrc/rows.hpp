@@ -12,6 +12,9 @@
 
 namespace gusto {
 
+#ifndef GUSTO_GOAL_BATCH
+#define GUSTO_GOAL_BATCH 1   // 0: BoxGoal rows one at a time (rounds 1-4)
+#endif
 #ifndef GUSTO_OBS_BATCH
 #define GUSTO_OBS_BATCH 4
 #endif
@@ -226,6 +229,37 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
     // first: without it the last knot's lane walked 2n dependent loads of the goal bounds in every row pass -- to find, for a
     // point goal, that there is no such row -- while the other 49 lanes waited (12 k of 200 k cycles per KKT solve)
     if (c.boxmask != 0 && c.k == c.N - 1) {
+#if GUSTO_GOAL_BATCH
+        // Only the last knot's lane has these rows and the other lanes wait for it, so what counts is its number of memory
+        // round trips: two coordinates (four rows) at a time, their bounds and the row state the Op needs (Op::obs_load, as
+        // for the obstacle rows) fetched in one batch; coordinates without a BoxGoal are skipped on the mask, without a load.
+        // Same rows in the same order as one at a time: bit-identical.  (The manifold model's default goal is a BoxGoal on
+        // the four quaternion coordinates: 8 round trips per pass -> 2, 13 k -> 4 k cycles of each of the three row passes.)
+        static_assert(OBS_BATCH >= 4, "a batch holds the four rows of two coordinates");
+        static_for<0, (n + 1) / 2>([&](auto G) {
+            constexpr int i0 = 2 * decltype(G)::value, i1 = (i0 + 1 < n) ? i0 + 1 : i0;
+            if ((c.boxmask >> i0) & 3u) {
+                const double lo0 = c.goal_lo[i0], hi0 = c.goal_hi[i0], lo1 = c.goal_lo[i1], hi1 = c.goal_hi[i1];
+                int oslot[OBS_BATCH];
+#pragma unroll
+                for (int q = 0; q < OBS_BATCH; q++) oslot[q] = slot_goal + 2 * ((q < 2) ? i0 : i1) + (q & 1);
+                op.obs_load(oslot);
+                const double p1 = 1.0, m1 = -1.0;
+                if (lo0 != hi0) {
+                    const double hw = (isfinite(hi0) && isfinite(lo0)) ? 0.5 * (hi0 - lo0) : 1.0;
+                    const double sc = 1.0 / fmax(1e-3, fmin(1.0, hw));
+                    if (isfinite(hi0)) lin_row<false, i0, 1, FX_OBS + 0>(op, oslot[0], ROW_HARD, xs, &p1, -hi0, sc, 0.0);
+                    if (isfinite(lo0)) lin_row<false, i0, 1, FX_OBS + 1>(op, oslot[1], ROW_HARD, xs, &m1, lo0, sc, 0.0);
+                }
+                if (i1 != i0 && lo1 != hi1) {
+                    const double hw = (isfinite(hi1) && isfinite(lo1)) ? 0.5 * (hi1 - lo1) : 1.0;
+                    const double sc = 1.0 / fmax(1e-3, fmin(1.0, hw));
+                    if (isfinite(hi1)) lin_row<false, i1, 1, FX_OBS + 2>(op, oslot[2], ROW_HARD, xs, &p1, -hi1, sc, 0.0);
+                    if (isfinite(lo1)) lin_row<false, i1, 1, FX_OBS + 3>(op, oslot[3], ROW_HARD, xs, &m1, lo1, sc, 0.0);
+                }
+            }
+        });
+#else
         static_for<0, n>([&](auto I) {
             constexpr int i = decltype(I)::value;
             const double lo = c.goal_lo[i], hi = c.goal_hi[i];
@@ -237,6 +271,7 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
                 if (isfinite(lo)) lin_row<false, i, 1>(op, slot_goal + 2 * i + 1, ROW_HARD, xs, &m1, lo, sc, 0.0);
             }
         });
+#endif
     }
 }
 
