@@ -1575,6 +1575,9 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
     (void)pf;
 }
 
+#ifndef GUSTO_GD_INV_REG
+#define GUSTO_GD_INV_REG 1     // 0: the goal system inverted in LDS by the whole workgroup (rounds 2-4)
+#endif
 #ifdef GUSTO_NO_COSTATE_PASS
 #define GUSTO_COSTATE_PASS 0
 #else
@@ -2179,6 +2182,61 @@ template <int MODEL, class BLK> GD void inv_spd_block(BLK& K, double* fail) {
     const int tid = K.tid, nt = K.nt();
     double* A = K.sGd;
     double* Li = K.sHh;   // (free between the factor sweep and the next one; NZ^2 >= n^2 doubles)
+#if GUSTO_GD_INV_REG
+    if constexpr (BLK::ONE) {
+        // One wave: the matrix lives in registers, lane r holds row r, and what a step needs from another lane comes by
+        // v_readlane -- no LDS round trip and no fence inside the factorisation (the LDS version below pays three per column
+        // and walks the forward substitution through dependent LDS reads: 28 k cycles per KKT solve for n = 12 / 13).  The
+        // same operations in the same order per entry (terms the LDS version skips enter as exact zeros): bit-identical.
+        const int r = tid < n ? tid : n - 1;   // (lanes >= n mirror the last row and are never read)
+        double a[n];
+#pragma unroll
+        for (int c = 0; c < n; c++) { a[c] = A[r * n + c]; if (c == r && !K.is_goal(r)) a[c] = 1.0; }
+        bool bad = false;
+        static_for<0, n>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const double ajj = readlane_f64(a[j], j);
+            if (!(ajj > 0.0)) bad = true;
+            const double d = rsqrt_nr(ajj);
+            a[j] = (r >= j) ? a[j] * d : a[j];                  // column j of L
+            static_for<j + 1, n>([&](auto C) {                  // trailing update of the lower triangle
+                constexpr int c = decltype(C)::value;
+                const double lcj = readlane_f64(a[j], c);
+                double t = a[c];
+                t -= a[j] * lcj;
+                a[c] = (r >= c) ? t : a[c];
+            });
+        });
+        if (bad) *fail = 1.0;
+        // column r of L^-1 by forward substitution; row i of L comes from lane i
+        double x[n];
+        static_for<0, n>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const double ri = rcp_nr(readlane_f64(a[i], i));
+            double acc = 0;
+            static_for<0, i>([&](auto L_) {
+                constexpr int l = decltype(L_)::value;
+                acc -= readlane_f64(a[l], i) * x[l];
+            });
+            x[i] = (i == r) ? ri : ((i > r) ? acc * ri : 0.0);
+        });
+        if (tid < n) {
+#pragma unroll
+            for (int i = 0; i < n; i++) Li[i * n + tid] = x[i];
+        }
+        K.sync();
+#pragma unroll
+        for (int t = 0; t < (n * n + 63) / 64; t++) {          // L^-T L^-1, an entry per lane: independent LDS reads
+            const int e = tid + 64 * t, ec = e < n * n ? e : n * n - 1;
+            const int i = ec / n, j = ec % n;
+            double acc = 0;
+#pragma unroll
+            for (int l = 0; l < n; l++) acc += Li[l * n + i] * Li[l * n + j];
+            if (e < n * n) K.sP[e] = acc;
+        }
+        return;
+    }
+#endif
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e % n;
         if (i == j && !K.is_goal(i)) A[e] = 1.0;
