@@ -2401,16 +2401,16 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
 #pragma unroll
     for (int j = 0; j < n; j++) th[j] = (K.goalmask != 0) ? block_reduce<BLK::ONE>(th[j], OpSum(), red) : 0.0;
     MT_(PF_M_RED);
-#if GUSTO_MUG_PAR
-    if (k < n) {   // mu_g = Gd^-1 theta, a lane per row (theta is wave-uniform after the reductions): as lane 0's loop it was n^2
-                   // LDS reads and FMAs that every other lane waited for, twice per interior point iteration.  Same sums: bit-identical.
-        double s = 0;
+    if constexpr (GUSTO_MUG_PAR && n > 4) {
+        if (k < n) {   // mu_g = Gd^-1 theta, a lane per row (theta is wave-uniform after the reductions): as lane 0's loop it was n^2
+                       // LDS reads and FMAs that every other lane waited for, twice per interior point iteration.  Same sums:
+                       // bit-identical.  (Not for the 3-state model, two waves per SIMD: measured 2 % slower there.)
+            double s = 0;
 #pragma unroll
-        for (int l = 0; l < n; l++) s += K.sP[k * n + l] * th[l];
-        mugn[k] = K.is_goal(k) ? s : 0.0;
-    }
-#else
-    if (k == 0) {
+            for (int l = 0; l < n; l++) s += K.sP[k * n + l] * th[l];
+            mugn[k] = K.is_goal(k) ? s : 0.0;
+        }
+    } else if (k == 0) {
 #pragma unroll
         for (int j = 0; j < n; j++) {
             double s = 0;
@@ -2419,7 +2419,6 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
             mugn[j] = K.is_goal(j) ? s : 0.0;
         }
     }
-#endif
     K.sync();
     MT_(PF_M_MU);
     if (act) {  // d_k = d0 + D_k mu_g ; ct_k = c_k - Gam_k d_k
@@ -3103,13 +3102,11 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             for (int i = 0; i < m; i++) { us[i] += alpha * K.dUs_(k, i); K.Uw[k * m + i] = us[i]; }
         }
         alpha_prev = alpha;   // the row state is advanced by the next residual pass
-#if GUSTO_MUG_PAR
-        if (k < n) mug[k] += alpha * (mugn[k] - mug[k]);
-#else
-        if (k == 0) {
+        if constexpr (GUSTO_MUG_PAR && n > 4) {
+            if (k < n) mug[k] += alpha * (mugn[k] - mug[k]);
+        } else if (k == 0) {
             for (int i = 0; i < n; i++) mug[i] += alpha * (mugn[i] - mug[i]);
         }
-#endif
         K.sync();
         pf.tick(PF_UPDATE);
     }
