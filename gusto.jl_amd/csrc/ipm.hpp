@@ -1604,10 +1604,17 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
     constexpr int n = T::n, m = T::m, NZ = n + m, NPG = n * NZ, NN = n * n;
     constexpr int KS = (n + 3) / 4, MS = (m + 3) / 4, RT = (NPG + 63) / 64, RN = (NN + 63) / 64;
     static_assert(!T::LTI && n <= 15 && m <= 8 && R::SNN > NN && R::SKD > 2 * m * n + m * m, "tile / record shape");
+    // -DGUSTO_PROFILE_COARSE: no stamp inside the stage, the sweep is one interval (PF_FACTOR).  The stamps of the fine profile
+    // wait for the values they follow and cost ~150 cycles each: with them the sweep reads as 55 % of a KKT solve, without 40 %.
+#ifdef GUSTO_PROFILE_COARSE
+#define FT_(id) do { } while (0)
+#else
+#define FT_(id) pf.tick(id)
+#endif
     const int tid = K.tid, N = K.N;
     const int mi = tid & 15, mq = tid >> 4;
-#ifdef GUSTO_PROFILE   // finer stamps of a stage (slots 40..47): the value is made a VGPR operand first, so the stamp waits for it
-#define FX_(id, val) do { asm volatile("" :: "v"(val)); pf.tick(40 + (id)); } while (0)
+#if defined(GUSTO_PROFILE) && !defined(GUSTO_PROFILE_COARSE)   // finer stamps of a stage (slots 40..47): the value is made a VGPR operand first, so the stamp waits for it
+#define FX_(id, val) do { asm volatile("" :: "v"(val)); FT_(40 + (id)); } while (0)
 #else
 #define FX_(id, val) do { } while (0)
 #endif
@@ -1672,7 +1679,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
         }
-        pf.tick(PF_FPRE);
+        FT_(PF_FPRE);
         double F[KS], G[KS], GA[MS];
 #pragma unroll
         for (int q = 0; q < KS; q++) {
@@ -1721,7 +1728,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
                 if (gg && row < m) zu[r] += 0.5 * PGs[mi * NZ + n + row];
             }
         }
-        pf.tick(PF_FAB);
+        FT_(PF_FAB);
         double S[m * m], Li[m * m];
 #pragma unroll
         for (int i = 0; i < m; i++)
@@ -1731,7 +1738,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
                 S[i * m + j] = readlane_f64(huu[a >> 2], ((a & 3) << 4) | b);
             }
         if (!chol_inv<m>(S, Li)) *fail = 1.0;
-        pf.tick(PF_F4);
+        FT_(PF_F4);
         // L^-1 is wave-uniform: one lane parks it in LDS, every lane takes its entries of the two operand layouts
         if (tid == 0) {
 #pragma unroll
@@ -1779,7 +1786,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 #pragma unroll
         for (int s = 0; s < MS; s++) Ph = __builtin_amdgcn_mfma_f64_16x16x4f64(GA[s], Kt[s], Ph, 0, 0, 0);   // Phi - Gam K
         FX_(6, Ph[0]);                 // Phicl done
-        pf.tick(PF_F6);
+        FT_(PF_F6);
         Pt = hyy; Pit = zy;
         // records (unconditional stores: lanes outside a matrix aim at the padding slot of the record)
         {
@@ -1796,9 +1803,9 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; if (e < NPG) K.sPG[((k - 1) & 1) * NPG + e] = pgn[r]; }
         }
-        pf.tick(PF_F7);
+        FT_(PF_F7);
         K.sync();
-        pf.tick(PF_FCD);
+        FT_(PF_FCD);
     }
     // Gd = sum V^T V for the goal system of the mid phase
 #pragma unroll

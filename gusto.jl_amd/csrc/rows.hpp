@@ -12,6 +12,9 @@
 
 namespace gusto {
 
+#ifndef GUSTO_FIX_BATCH
+#define GUSTO_FIX_BATCH 1    // 0: the fixed rows of the 12/13-state models one memory round trip each (rounds 1-4)
+#endif
 #ifndef GUSTO_GOAL_BATCH
 #define GUSTO_GOAL_BATCH 1   // 0: BoxGoal rows one at a time (rounds 1-4)
 #endif
@@ -151,8 +154,20 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
         constexpr bool is2 = MODEL == GUSTO_FREEFLYER_SE2, man = MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD;
         constexpr int nv = is2 ? 2 : 3, iw = is2 ? 5 : (man ? 10 : 9), nw = is2 ? 1 : 3;
         int slot = 0;
+        // Ops without a RowPre (the 12/13-state models: it does not fit their registers) borrow the obstacle batch buffer, idle
+        // until the obstacle loop, for the first four state rows and again for the two control rows: a pass pays two or three
+        // memory round trips for these rows instead of one per row (5 / 7).  Same rows, same order: bit-identical.
+        constexpr bool FB = GUSTO_FIX_BATCH && Op::FIX_BATCH;
+        constexpr int NB1 = T::NFIX < OBS_BATCH ? T::NFIX : OBS_BATCH;
+#define GUSTO_FXB(i, fx) ((FB && (i) < NB1) ? FX_OBS + (i) : (fx))
+        if constexpr (FB) {
+            int fs[OBS_BATCH];
+#pragma unroll
+            for (int q = 0; q < OBS_BATCH; q++) fs[q] = q < NB1 ? q : NB1 - 1;
+            op.obs_load(fs);
+        }
         if constexpr (!man) {  // stri_state_trust_region (freeflyer_se2.jl:323-326): w*||x-xp||^2 - Delta <= s
-            quad_row<false, 0, n, 0>(op, slot++, ROW_PEN_TR, xs, one, c.xp, 0.0, kw, c.kappa * c.Delta);
+            quad_row<false, 0, n, GUSTO_FXB(0, 0)>(op, slot++, ROW_PEN_TR, xs, one, c.xp, 0.0, kw, c.kappa * c.Delta);
         } else {
             // cse_quaternion_norm (manifold.jl:308-313), penalised as a +-eps pair (scp_gusto.jl:297-311)
             const double* qp = c.xp + 6;
@@ -160,14 +175,14 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
             double bp[4], bm[4], c0 = qn - 1.0;
 #pragma unroll
             for (int j = 0; j < 4; j++) { bp[j] = qp[j] / qn; bm[j] = -bp[j]; c0 -= qp[j] * qp[j] / qn; }
-            lin_row<false, 6, 4, 0>(op, slot++, ROW_HARD_EQ, xs, bm, -c0, kw, c.kappa * c.P->sp.eps);
-            lin_row<false, 6, 4, 1>(op, slot++, ROW_PEN_EQ, xs, bp, c0, kw, c.kappa * c.P->sp.eps);
+            lin_row<false, 6, 4, GUSTO_FXB(0, 0)>(op, slot++, ROW_HARD_EQ, xs, bm, -c0, kw, c.kappa * c.P->sp.eps);
+            lin_row<false, 6, 4, GUSTO_FXB(1, 1)>(op, slot++, ROW_PEN_EQ, xs, bp, c0, kw, c.kappa * c.P->sp.eps);
             const double m1 = -1.0;  // csi_orientation_sign (manifold.jl:316-319)
-            lin_row<false, 6, 1, 2>(op, slot++, ROW_PEN, xs, &m1, 0.0, kw, 0.0);
+            lin_row<false, 6, 1, GUSTO_FXB(2, 2)>(op, slot++, ROW_PEN, xs, &m1, 0.0, kw, 0.0);
         }
         // csi_translational_velocity_bound / csi_angular_velocity_bound (freeflyer_se2.jl:225-233)
-        quad_row<false, 3, nv, T::NFIX - 2>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
-        quad_row<false, iw, nw, T::NFIX - 1>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_omega * mp.hard_limit_omega, kw, 0.0);
+        quad_row<false, 3, nv, GUSTO_FXB(T::NFIX - 2, T::NFIX - 2)>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
+        quad_row<false, iw, nw, GUSTO_FXB(T::NFIX - 1, T::NFIX - 1)>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_omega * mp.hard_limit_omega, kw, 0.0);
         // ncsi_*_obstacle_avoidance_*_convexified (freeflyer_se2.jl:265-288): clearance - (d + nhat.(r - r0))
         // The rows of one knot are walked in batches of OBS_BATCH: every load of a batch (normal, offset AND the row state
         // the Op needs, Op::obs_load) is issued before the first row of the batch is processed.  One row at a time, each
@@ -207,11 +222,18 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
             for (int j = 0; j < nf; j++) af[j] = 1.0 / (mp.mass * mp.mass);
 #pragma unroll
             for (int j = 0; j < nm; j++) { const double ji = 1.0 / mp.Jdiag[is2 ? 2 : j]; am[j] = ji * ji; }
-            quad_row<true, 0, nf, T::NFIX>(op, slot_u, ROW_HARD, us, af, nullptr, -mp.hard_limit_accel * mp.hard_limit_accel,
+            if constexpr (FB) {
+                int fs[OBS_BATCH];
+#pragma unroll
+                for (int q = 0; q < OBS_BATCH; q++) fs[q] = slot_u + (q < 1 ? 0 : 1);
+                op.obs_load(fs);
+            }
+            quad_row<true, 0, nf, (FB ? FX_OBS + 0 : T::NFIX)>(op, slot_u, ROW_HARD, us, af, nullptr, -mp.hard_limit_accel * mp.hard_limit_accel,
                                   1.0 / (mp.hard_limit_accel * mp.hard_limit_accel), 0.0);
-            quad_row<true, im, nm, T::NFIX + 1>(op, slot_u + 1, ROW_HARD, us, am, nullptr, -mp.hard_limit_alpha * mp.hard_limit_alpha,
+            quad_row<true, im, nm, (FB ? FX_OBS + 1 : T::NFIX + 1)>(op, slot_u + 1, ROW_HARD, us, am, nullptr, -mp.hard_limit_alpha * mp.hard_limit_alpha,
                                    1.0 / (mp.hard_limit_alpha * mp.hard_limit_alpha), 0.0);
         }
+#undef GUSTO_FXB
     } else {  // DubinsCar: csi_max/min_bound_constraints, cci_max/min_bound_constraints (dynamics.jl:56-81)
         static_for<0, n>([&](auto I) {
             constexpr int i = decltype(I)::value;
@@ -319,6 +341,7 @@ struct ObsPre {
 // path at muw for its value g at the start point:  s - t = g, t lam_a = s lam_b = muw, lam_a + lam_b = 1
 //   <=>  {s, t} = muw + (sqrt(g^2 + 4 muw^2) +- g) / 2;   hard rows get lam = muw / t.
 template <class RST = RowState> struct OpInitT {
+    static constexpr bool FIX_BATCH = false;
     RST rs;
     double muw;
     int ncomp = 0;
@@ -355,6 +378,7 @@ using OpInit = OpInitT<>;
 // [var][slot][k] arrays, LaneRS for the lane-per-problem kernel, lane.hpp; ssum: the slacks of the penalised rows after the
 // update, for the kernels that take the objective from this pass)
 template <int n, int m, int NP, bool LRTR = false, class RST = RowState> struct OpResidHess {
+    static constexpr bool FIX_BATCH = NP == 0;   // (visit_rows: the fixed rows through the obstacle batch buffer)
     RST rs;
     double *Hx, *Hu, *rdx, *rdu, *gx0, *gu0;
     double alpha_prev;  // 0 on the first trip
@@ -449,6 +473,7 @@ struct StepFrac {
 // pass leaves gA = sum A grad and gB = sum B grad per knot and the corrector forms gA + mu_t gB once mu_t is known: one
 // row pass (6 row-state reads per row) less per interior point iteration.
 template <int NP, class RST = RowState> struct OpStep {
+    static constexpr bool FIX_BATCH = NP == 0;
     RST rs;
     const double *dxs, *dus;
     int pass;
@@ -520,6 +545,7 @@ template <int NP, class RST = RowState> struct OpStep {
 };
 
 template <class RST = RowState> struct OpSlackSumT {
+    static constexpr bool FIX_BATCH = false;
     RST rs;
     double sum = 0;
     GD void obs_load(const int*) {}
@@ -532,6 +558,7 @@ using OpSlackSum = OpSlackSumT<>;
 
 // convex_ineq_satisfied_gusto_jump (scp_gusto.jl:316-343): raw row values against eps
 struct OpCheck {
+    static constexpr bool FIX_BATCH = false;
     double eps;
     bool ok = true;
     GD void obs_load(const int*) {}
