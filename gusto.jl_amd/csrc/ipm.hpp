@@ -1820,6 +1820,9 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 //
 // backward: pt_{k-1} = Phicl_k^T pt_k + qq_k, k = N-1..1, pt := p + r (so qq_k = qt_k + r_{k-1}), pt_{N-1} = r_{N-1}.
 //           pv[k] holds qq_k on entry and pt_k on exit.
+#ifndef GUSTO_SWEEP_RDL_BATCH
+#define GUSTO_SWEEP_RDL_BATCH 1
+#endif
 #ifndef GUSTO_XL_MIN
 #define GUSTO_XL_MIN 8
 #endif
@@ -1948,8 +1951,21 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
 #pragma unroll
                     for (int l = 0; l < n; l++) acc[l % PS] += col[l] * pb[l];
                 } else {
+#if GUSTO_SWEEP_RDL_BATCH
+                    // the 2 n v_readlane of a step first, into n scalar pairs of their own, then the n dependent FMAs: left alone
+                    // hipcc reuses ONE scalar pair -- readlane, readlane, s_nop, fmac, n times over -- and every fmac waits for its
+                    // two readlanes, which wait for the fmac before them to have read the pair (24 cycles per element, 12 of them
+                    // avoidable).  Same FMAs in the same order.
+                    double pb[n];
+#pragma unroll
+                    for (int l = 0; l < n; l++) pb[l] = readlane_f64(pval, sg * n + l);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int l = 0; l < n; l++) acc[l % PS] += col[l] * pb[l];
+#else
 #pragma unroll
                     for (int l = 0; l < n; l++) acc[l % PS] += col[l] * readlane_f64(pval, sg * n + l);
+#endif
                 }
                 const double s = (PS == 4) ? (acc[0] + acc[1]) + (acc[2] + acc[PS - 1]) : acc[0];
                 pval = (g == gs) ? s : pval;
@@ -2070,8 +2086,17 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
 #pragma unroll
                     for (int l = 0; l < n; l++) acc[l % PS] += row[l] * pb[l];
                 } else {
+#if GUSTO_SWEEP_RDL_BATCH
+                    double pb[n];   // (see backward_sweep_1w)
+#pragma unroll
+                    for (int l = 0; l < n; l++) pb[l] = readlane_f64(yval, sg * n + l);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int l = 0; l < n; l++) acc[l % PS] += row[l] * pb[l];
+#else
 #pragma unroll
                     for (int l = 0; l < n; l++) acc[l % PS] += row[l] * readlane_f64(yval, sg * n + l);
+#endif
                 }
                 const double s = (PS == 4) ? (acc[0] + acc[1]) + (acc[2] + acc[PS - 1]) : acc[0];
                 yval = (g == gs) ? s : yval;
