@@ -415,7 +415,11 @@ struct Prof {
 #ifdef GUSTO_PROFILE
     long long t0, acc[PROF_N];
     GD Prof() { for (int i = 0; i < PROF_N; i++) acc[i] = 0; t0 = clock64(); }
+#ifdef GUSTO_PROFILE_COARSE   // no stamp inside a factor stage or a row pass: a stamp waits for what is in flight (~150 cycles each)
+    GD void tick(int id) { if ((id >= PF_FPRE && id <= PF_F8) || id >= PF_R0) return; const long long t = clock64(); acc[id] += t - t0; t0 = t; }
+#else
     GD void tick(int id) { const long long t = clock64(); acc[id] += t - t0; t0 = t; }
+#endif
     // (a problem runs in several time slices under the scheduler: the first one overwrites, the others accumulate)
     GD void flush(long long* out, int b, bool cont = false) {
         if (out && threadIdx.x == 0)
