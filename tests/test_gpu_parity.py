@@ -719,6 +719,59 @@ def test_partial_goal_and_box_goal_freeflyer():
             assert glo[b, 0] - 1e-7 <= sub["X"][b, -1, 0] <= ghi[b, 0] + 1e-7
 
 
+@pytest.mark.parametrize("name", ["freeflyer_se2", "astrobee_se3", "astrobee_se3_manifold"])
+def test_box_goal_rows_of_every_pairing_shape(name):
+    """BoxGoal rows are fetched two coordinates (four rows) at a time (rows.hpp): the first or the second coordinate of a pair
+    alone, both, the unpaired last coordinate of an odd state dimension, one-sided boxes (a single row), boxes next to free and
+    to point-goal coordinates -- one problem per shape, the convex subproblem and a short GuSTO run against the oracle, which
+    walks its goal rows one at a time (dynamics.jl:37-42, scp_gusto.jl:236-245)."""
+    g, go = _mods()
+    P = g.problems
+    if name == "freeflyer_se2":
+        model, env, sph, batch, N = g.FREEFLYER_SE2, P.freeflyer_env(), None, P.freeflyer_batch(8), 40
+    elif name == "astrobee_se3":
+        (env, sph), model, batch, N = P.iss_corner_env(True), g.ASTROBEE_SE3, P.astrobee_se3_batch(8), 50
+    else:
+        (env, sph), model, batch, N = P.iss_corner_env(True), g.ASTROBEE_SE3_MANIFOLD, P.astrobee_manifold_batch(8), 50
+    x0, glo, ghi, tf = [np.array(a, copy=True) for a in batch]
+    n = x0.shape[1]
+    c = 0.5 * (glo + ghi)                      # (the manifold generator already carries a box on its quaternion: start from points)
+    c[~np.isfinite(c)] = 0.0
+    glo, ghi = c.copy(), c.copy()
+    w = 0.02
+    shapes = [[0], [1], [2, 3], [n - 1], [0, 1, n - 2, n - 1], [4], list(range(n)), [1, 2]]
+    for b, cs in enumerate(shapes):
+        for i in cs:
+            glo[b, i] -= w; ghi[b, i] += w
+    ghi[5, 4] = np.inf                         # one-sided: only the lower bound's row exists
+    glo[3, n - 1] = -np.inf                    # one-sided on the unpaired / last coordinate
+    glo[7, 0] = -np.inf; ghi[7, 0] = np.inf    # a free coordinate next to a boxed one
+    man = name == "astrobee_se3_manifold"
+    atol = 3e-4 if man else SUB_ATOL
+    s = g.BatchSolver(model, N, 8, hist_cap=16, boxes=env, spheres=sph)
+    s.set_problems(x0, glo, ghi, tf)
+    X0, U0 = s.traj()
+    sub = s.subproblem(X0, U0, 3.0, 1.0, 3.0 / 8 + 0.05)
+    s.set_problems(x0, glo, ghi, tf)
+    s.solve(6)
+    X, U = s.traj(); st = s.status()
+    o = go.Oracle(model, N, boxes=env, spheres=sph)
+    for b in range(8):
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        Xi, Ui = o.init_straightline()
+        ro = o.subproblem(Xi, Ui, 3.0, 1.0, 3.0 / 8 + 0.05)
+        assert int(sub["status"][b]) == ro["status"], (b, int(sub["status"][b]), ro["status"])
+        if ro["status"] in (1, 2):
+            assert np.abs(sub["X"][b] - ro["X"]).max() < atol and np.abs(sub["U"][b] - ro["U"]).max() < SUB_ATOL, \
+                (b, np.abs(sub["X"][b] - ro["X"]).max(), np.abs(sub["U"][b] - ro["U"]).max())
+            for i in shapes[b]:
+                assert glo[b, i] - 1e-6 <= sub["X"][b, -1, i] <= ghi[b, i] + 1e-6, (b, i)
+        r = o.solve(6)
+        assert int(st["iterations"][b]) == r["iterations"] and bool(st["converged"][b]) == r["converged"], (b, st["iterations"][b], r["iterations"])
+        if r["iterations"] > 0:
+            assert np.abs(X[b] - r["X"]).max() < TRAJ_ATOL, (b, np.abs(X[b] - r["X"]).max())
+
+
 def test_history_capacity_contract():
     """gusto_get_history writes rows with the CALLER's pitch and refuses arrays smaller than the handle's capacity;
     a handle whose history fills up before iter_cap stops with GUSTO_STOP_HIST_FULL (never silently as MaxIter), and
