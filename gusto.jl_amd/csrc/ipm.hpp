@@ -1820,6 +1820,9 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 //
 // backward: pt_{k-1} = Phicl_k^T pt_k + qq_k, k = N-1..1, pt := p + r (so qq_k = qt_k + r_{k-1}), pt_{N-1} = r_{N-1}.
 //           pv[k] holds qq_k on entry and pt_k on exit.
+#ifndef GUSTO_XL_RDL
+#define GUSTO_XL_RDL 1           // 0: the 12/13-state sweeps pass the n-vector between knot groups through LDS (rounds 3-4)
+#endif
 #ifndef GUSTO_SWEEP_RDL_BATCH
 #define GUSTO_SWEEP_RDL_BATCH 1
 #endif
@@ -1912,13 +1915,23 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
 #pragma unroll
                             for (int q = 0; q < PS; q++) acc[q] = (q == 0) ? qb[d] : 0.0;
                             double pb[n];
+#if GUSTO_XL_RDL
+                            // (the n-vector by 2 n v_readlane into n scalar pairs of their own, all of them before the first
+                            // FMA -- see the small-model path below -- instead of a ds_write / broadcast ds_read round trip)
+#pragma unroll
+                            for (int l = 0; l < n; l++) pb[l] = readlane_f64(pval, sg * n + l);
+                            __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
                             for (int l = 0; l < n; l++) pb[l] = ex[sg * n + l];
+#endif
 #pragma unroll
                             for (int l = 0; l < n; l++) acc[l % PS] += cb[d][l] * pb[l];
                             const double s = (PS == 4) ? (acc[0] + acc[1]) + (acc[2] + acc[PS - 1]) : acc[0];
                             pval = (g == gs) ? s : pval;
+#if !GUSTO_XL_RDL
                             ex[tid] = pval;
+#endif
                         }
                     }
                     const int kk = k0 - g;
@@ -2050,13 +2063,21 @@ template <class BLK> GD void forward_sweep_1w(BLK K) {
 #pragma unroll
                             for (int q = 0; q < PS; q++) acc[q] = (q == 0) ? qb[d] : 0.0;
                             double pb[n];
+#if GUSTO_XL_RDL
+#pragma unroll
+                            for (int l = 0; l < n; l++) pb[l] = readlane_f64(yval, sg * n + l);
+                            __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
                             for (int l = 0; l < n; l++) pb[l] = ex[sg * n + l];
+#endif
 #pragma unroll
                             for (int l = 0; l < n; l++) acc[l % PS] += rb[d][l] * pb[l];
                             const double s = (PS == 4) ? (acc[0] + acc[1]) + (acc[2] + acc[PS - 1]) : acc[0];
                             yval = (g == gs) ? s : yval;
+#if !GUSTO_XL_RDL
                             ex[tid] = yval;
+#endif
                         }
                     }
                     const int kk = k0 + g;
