@@ -461,6 +461,24 @@ template <class Op> GD double wave_reduce(double v, Op op) {
     const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
     return op(op(r0, r1), op(r2, r3));
 }
+// n reductions at once, step by step across all of them: each DPP step of one value waits ~3 dependent instructions for the
+// one before it, and written one reduction after the other hipcc keeps that order (6-13 reductions back to back in the mid
+// phase); interleaved, a step of one value issues in the shadow of the others'.  Same operations per value.
+template <int NV, class Op> GD void wave_reduce_n(double* v, Op op) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) v[j] = op(v[j], row_ror_f64<1>(v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; j++) v[j] = op(v[j], row_ror_f64<2>(v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; j++) v[j] = op(v[j], row_ror_f64<4>(v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; j++) v[j] = op(v[j], row_ror_f64<8>(v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const double r0 = readlane_f64(v[j], 0), r1 = readlane_f64(v[j], 16), r2 = readlane_f64(v[j], 32), r3 = readlane_f64(v[j], 48);
+        v[j] = op(op(r0, r1), op(r2, r3));
+    }
+}
 // NaN-propagating max: used for residuals so that a NaN iterate is detected
 GD double nanmax(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
 struct OpNanMax { GD double operator()(double a, double b) const { return nanmax(a, b); } };

@@ -1820,6 +1820,9 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 //
 // backward: pt_{k-1} = Phicl_k^T pt_k + qq_k, k = N-1..1, pt := p + r (so qq_k = qt_k + r_{k-1}), pt_{N-1} = r_{N-1}.
 //           pv[k] holds qq_k on entry and pt_k on exit.
+#ifndef GUSTO_REDUCE_N
+#define GUSTO_REDUCE_N 1
+#endif
 #ifndef GUSTO_XL_RDL
 #define GUSTO_XL_RDL 1           // 0: the 12/13-state sweeps pass the n-vector between knot groups through LDS (rounds 3-4)
 #endif
@@ -2451,8 +2454,16 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         }
     }
     MT_(PF_M_TH);
+    if constexpr (BLK::ONE && GUSTO_REDUCE_N) {
+        if (K.goalmask != 0) wave_reduce_n<n>(th, OpSum());
+        else {
+#pragma unroll
+            for (int j = 0; j < n; j++) th[j] = 0.0;
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < n; j++) th[j] = (K.goalmask != 0) ? block_reduce<BLK::ONE>(th[j], OpSum(), red) : 0.0;
+    }
     MT_(PF_M_RED);
     if constexpr (GUSTO_MUG_PAR && n > 4) {
         if (k < n) {   // mu_g = Gd^-1 theta, a lane per row (theta is wave-uniform after the reductions): as lane 0's loop it was n^2
