@@ -1820,6 +1820,9 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 //
 // backward: pt_{k-1} = Phicl_k^T pt_k + qq_k, k = N-1..1, pt := p + r (so qq_k = qt_k + r_{k-1}), pt_{N-1} = r_{N-1}.
 //           pv[k] holds qq_k on entry and pt_k on exit.
+#ifndef GUSTO_MID_KEEP_D
+#define GUSTO_MID_KEEP_D 1
+#endif
 #ifndef GUSTO_REDUCE_N
 #define GUSTO_REDUCE_N 1
 #endif
@@ -2345,6 +2348,12 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
     const int N = K.N;
     // feed-forward d0 = S^-1 lu and the goal multiplier
     double th[n], d0[m];
+    // (12/13-state models: the D record of the knot, 78 entries from the slot workspace, is walked once and kept for d_k = d0 + D mu_g
+    // below -- this phase is a real call with registers of its own -- instead of walked again after the reductions)
+    constexpr bool KEEP_D = GUSTO_MID_KEEP_D && T::SWEEP_CALL && BLK::ONE && !BLK::C::KD_LDS;
+    double Dk[KEEP_D ? m * n : 1];
+#pragma unroll
+    for (int i = 0; i < (KEEP_D ? m * n : 1); i++) Dk[i] = 0;
 #pragma unroll
     for (int i = 0; i < n; i++) th[i] = 0;
 #pragma unroll
@@ -2437,7 +2446,11 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
 #pragma unroll
         for (int i = 0; i < m; i++)
 #pragma unroll
-            for (int j = 0; j < n; j++) thd[j] -= K.kd(k, R::oD + i * n + j) * lu[i];
+            for (int j = 0; j < n; j++) {
+                const double dij = K.kd(k, R::oD + i * n + j);
+                if constexpr (KEEP_D) Dk[i * n + j] = dij;
+                thd[j] -= dij * lu[i];
+            }
 #pragma unroll
         for (int j = 0; j < n; j++) {
             double s = thd[j];
@@ -2491,7 +2504,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         for (int i = 0; i < m; i++) {
             double s = d0[i];
 #pragma unroll
-            for (int j = 0; j < n; j++) s += K.kd(k, R::oD + i * n + j) * mugn[j];
+            for (int j = 0; j < n; j++) s += (KEEP_D ? Dk[i * n + j] : K.kd(k, R::oD + i * n + j)) * mugn[j];
             dk[i] = s;
             K.dv_(k, i) = s;
         }
