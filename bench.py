@@ -126,6 +126,77 @@ def cpu_baseline(P, g, cfg, n_sample, threads, B_gpu, algo="gusto"):
     return out
 
 
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak (MI355X_MICROARCH.md)
+
+
+def committed_pmc(cfg):
+    """The latest committed PMC summary of a config (profiles/r*_pmc.json for config 2, r*_pmc_config{c}.json otherwise;
+    separate rocprofv3 --pmc passes, tools/profile_round.sh) or None."""
+    import glob
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json" if cfg == 2 else f"r*_pmc_config{cfg}.json")))
+    if not pmc:
+        return None, None
+    try:
+        return json.load(open(pmc[-1])), "profiles/" + os.path.basename(pmc[-1])
+    except Exception:
+        return None, None
+
+
+def valu_fp64(pmc, kkt_now):
+    """fp64 VALU + matrix-core flops of one launch from the committed SQ counters (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 count
+    wave instructions: x 64 lanes, an FMA = 2 flops; SQ_INSTS_VALU_MFMA_MOPS_F64 counts 512-flop units), scaled by the
+    KKT solves of this run over those of the profiled launch.  None when the summary holds no such counters."""
+    sq = (pmc or {}).get("sq_counters_per_launch") or {}
+    if "SQ_INSTS_VALU_FMA_F64" not in sq:
+        return None
+    flops = 64.0 * (2.0 * sq["SQ_INSTS_VALU_FMA_F64"] + sq.get("SQ_INSTS_VALU_MUL_F64", 0.0) + sq.get("SQ_INSTS_VALU_ADD_F64", 0.0))
+    flops += 512.0 * sq.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
+    kkt_prof = pmc.get("kkt_solves")     # (absent in summaries before round 5: the same seeded workload, the same count)
+    if kkt_prof:
+        flops *= kkt_now / float(kkt_prof)
+    return flops
+
+
+def other_configs(P, g, torch, dev_ord, steps=3, warmup=1):
+    """BASELINE.json configs 3 / 4 / 5 measured in this process after the timed region of the headline config: `steps` serial
+    steps each (inputs resident in HBM, HIP-event kernel time of the one launch per step), the roofline fraction priced like
+    the headline's, the traffic ratio from the committed PMC summary of the same workload."""
+    out = {}
+    for cfg in (3, 4, 5):
+        c = CONFIGS[cfg]
+        t0 = time.perf_counter()
+        model, boxes, spheres, (x0, glo, ghi, tf) = workload(P, g, cfg, c["B"], 0)
+        n, m = g.MODEL_DIMS[model]
+        s = g.BatchSolver(model, c["N"], c["B"], hist_cap=MAX_ITER + 34, device=dev_ord, boxes=boxes, spheres=spheres)
+        dv = [torch.from_numpy(a).to(torch.device("cuda", dev_ord)) for a in (x0, glo, ghi, tf)]
+        torch.cuda.synchronize()
+        ms, wall = [], []
+        for i in range(warmup + steps):
+            t1 = time.perf_counter()
+            s.set_problems_dev(c["B"], *[d.data_ptr() for d in dv])
+            s.solve_async(MAX_ITER)
+            s.wait()
+            torch.cuda.synchronize()
+            if i >= warmup:
+                wall.append(time.perf_counter() - t1)
+                ms.append(s.last_solve_ms())
+        st = s.status()
+        s.close()
+        b_kkt, b_lin = algorithmic_bytes(n, m, c["N"])
+        kkt, scp, conv = int(st["ipm_iters"].sum()), int(st["iterations"].sum()), int(st["converged"].sum())
+        alg = b_kkt * kkt + b_lin * scp
+        avg = float(np.mean(ms))
+        pmc, src = committed_pmc(cfg)
+        out[str(cfg)] = {
+            "workload": c["name"], "steps": steps, "ms_per_step": 1e3 * float(np.mean(wall)), "avg_launch_ms": avg,
+            "value": conv / float(np.mean(wall)), "unit": "converged trajectories/s", "converged": conv, "problems": c["B"],
+            "kkt_solves_per_launch": kkt, "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic_over_algorithmic": (pmc or {}).get("traffic_over_algorithmic"), "traffic_source": src,
+            "setup_s": time.perf_counter() - t0 - float(np.sum(wall)),
+        }
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +208,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the config's batch size")
     ap.add_argument("--cpu-sample", type=int, default=0, help="0 = the config's sample per usable host core (10-30 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the in-process lines of configs 3 / 4 / 5 (other_configs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and overlapped extras (profiling runs: "
                     "every launch of the kernel is then one serial step, so rocprofv3's average is the step's)")
     ap.add_argument("--overlap", type=int, default=1,
@@ -328,15 +400,18 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM traffic of one solve: NOT measured in this run -- PMC counters need their own rocprofv3 --pmc passes
         # (tools/profile_round.sh); the figure is read from the latest committed summary of the same workload
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json" if args.config == 2 else f"r*_pmc_config{args.config}.json")))
-            if pmc and not trajopt and B == CONFIGS[args.config]["B"]:
-                traffic = json.load(open(pmc[-1]))["traffic_bytes_per_launch"]
-                traffic_src = "profiles/" + os.path.basename(pmc[-1]) + " (separate rocprofv3 --pmc passes, not this run)"
-        except Exception:
-            traffic = None
+        traffic, traffic_src, valu_flops = None, None, None
+        pmc, pmc_src = committed_pmc(args.config)
+        if pmc and not trajopt and B == CONFIGS[args.config]["B"]:
+            traffic = pmc.get("traffic_bytes_per_launch")
+            traffic_src = pmc_src + " (separate rocprofv3 --pmc passes, not this run)"
+            valu_flops = valu_fp64(pmc, ipm_iters)
+        others = None
+        if args.config == 2 and not args.batch and dist is None and not args.no_extras and not trajopt and not args.no_other_configs:
+            try:
+                others = other_configs(P, g, torch, dev_ord)
+            except Exception as e:      # the headline line must come out whatever happens to the side measurements
+                others = {"error": f"{type(e).__name__}: {e}"[:200]}
         out = {
             "metric": (f"problems/sec through the whole TrajOpt schedule (batched SCP, solve_trajopt_hip!), {cfg['model'].lower()} N={N_KNOTS}, inputs resident in HBM"
                        if trajopt else f"converged trajectories/sec (batched SCP), {cfg['model'].lower()} N={N_KNOTS}, inputs resident in HBM"),
@@ -355,6 +430,11 @@ def main():
                        "batches_in_flight": D},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # the issue-side bound next to the memory-side one (the kernels are register / LDS resident): fp64
+                         # VALU (+ matrix core) flops of the launch from the committed SQ counters / this run's kernel time
+                         "valu_fp64_tflops": (valu_flops / (avg_ms * 1e-3) / 1e12) if valu_flops else None,
+                         "valu_fp64_frac": (valu_flops / (avg_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if valu_flops else None,
+                         "valu_fp64_peak_tflops": FP64_VALU_PEAK_TFLOPS, "valu_fp64_source": (pmc_src + ": SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes, committed counters x this run's time") if valu_flops else None,
                          # one gusto_solve = ONE launch of the persistent kernel (device-side longest-first scheduler,
                          # gusto_set_schedule); avg_launch_ms from HIP events on the handle's stream
                          "kernel": f"gusto::trajopt_kernel<{4 if args.config == 2 else 5}>" if trajopt else f"gusto::scp_kernel<{model}>", "launches_per_solve": 1, "avg_launch_ms": avg_ms,
@@ -371,6 +451,8 @@ def main():
             "solve + get_traj (host), median of 5, one GPU", "overlapped_traj_per_s": overlapped,
             "gathered_problems_per_step": gathered[0] if dist is not None else None, "gather_error": gather_err[0],
             "gather_ms_per_step": (1e3 * gather_total / args.steps) if dist is not None else None,
+            # BASELINE.json configs 3 / 4 / 5 in the same run (3 serial steps each, after the timed region)
+            "other_configs": others,
         }
         if not args.no_cpu_baseline:
             threads = usable_cores()

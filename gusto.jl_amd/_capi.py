@@ -21,11 +21,11 @@ STOP_REASON = {0: "MaxIter", 1: "Converged", 2: "SubproblemFailed", 3: "OmegaMax
 SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims", "gusto_create", "gusto_destroy",
            "gusto_last_error", "gusto_set_params", "gusto_set_ipm_opts", "gusto_set_env", "gusto_set_env_batch", "gusto_set_schedule", "gusto_set_decomposition",
            "gusto_set_stream",
-           "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_solve_async", "gusto_wait",
+           "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_solve_async", "gusto_set_active", "gusto_wait",
            "gusto_last_solve_ms", "gusto_get_traj",
            "gusto_get_traj_dev", "gusto_gather_peer", "gusto_get_status", "gusto_get_dual", "gusto_get_history", "gusto_get_hist_cap",
            "gusto_set_trust_state", "gusto_subproblem", "gusto_default_shoot_opts", "gusto_shoot", "gusto_get_shoot",
-           "gusto_default_trajopt_params", "gusto_create_trajopt", "gusto_set_trajopt_params", "gusto_solve_trajopt",
+           "gusto_default_trajopt_params", "gusto_create_trajopt", "gusto_set_trajopt_params", "gusto_solve_trajopt", "gusto_solve_trajopt_async",
            "gusto_get_trajopt_history", "gusto_subproblem_trajopt",
            "gusto_dev_get_prof", "gusto_dev_launch_info"]
 
@@ -50,7 +50,7 @@ class IpmOpts(C.Structure):
 
 
 class ShootOpts(C.Structure):
-    _fields_ = [("substeps", C.c_int), ("max_newton", C.c_int), ("ftol", C.c_double)]
+    _fields_ = [("substeps", C.c_int), ("max_newton", C.c_int), ("ftol", C.c_double), ("group_pass", C.c_int)]
 
 
 class TrajOptParams(C.Structure):
@@ -137,6 +137,7 @@ def lib():
         L.gusto_solve.argtypes = [vp, ci, ci]
         L.gusto_solve_async.argtypes = [vp, ci, ci]
         L.gusto_wait.argtypes = [vp]
+        L.gusto_set_active.argtypes = [vp, vp]
         L.gusto_last_solve_ms.argtypes = [vp, C.POINTER(C.c_double)]
         L.gusto_get_traj.argtypes = [vp, vp, vp]
         L.gusto_get_traj_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -154,6 +155,7 @@ def lib():
         L.gusto_create_trajopt.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci]
         L.gusto_set_trajopt_params.argtypes = [vp, C.POINTER(TrajOptParams)]
         L.gusto_solve_trajopt.argtypes = [vp, ci]
+        L.gusto_solve_trajopt_async.argtypes = [vp, ci]
         L.gusto_get_trajopt_history.argtypes = [vp, C.POINTER(TrajOptHistory)]
         L.gusto_subproblem_trajopt.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         _lib = L
@@ -192,6 +194,8 @@ class GustoError(RuntimeError):
 
 class BatchSolver:
     """Thin owner of one gusto_handle: a batch of SCP problems of one model on one GPU."""
+    # gusto_set_decomposition applied to every new dubins_car handle (0 = the library's choice); the lane-kernel tests set it
+    default_decomposition = 0
 
     def __init__(self, model, N, batch_cap, hist_cap=64, device=0, boxes=None, spheres=None, scp_params=None,
                  model_params=None, ipm_opts=None):
@@ -210,6 +214,8 @@ class BatchSolver:
                                               C.byref(model_params) if model_params is not None else None), "set_params")
         if ipm_opts is not None:
             self._chk(self.L.gusto_set_ipm_opts(self.h, C.byref(ipm_opts)), "set_ipm_opts")
+        if BatchSolver.default_decomposition and model == DUBINS_CAR and type(self) is BatchSolver:
+            self.set_decomposition(BatchSolver.default_decomposition)
         self.set_env(boxes, spheres)
 
     def _create(self, model, N, batch_cap, hist_cap, device):
@@ -279,6 +285,14 @@ class BatchSolver:
 
     def solve(self, max_iter=30, force=False):
         self._chk(self.L.gusto_solve(self.h, int(max_iter), int(bool(force))), "solve")
+
+    def set_active(self, active=None):
+        """gusto_set_active: the problems the following solve / shoot calls work on (boolean mask [B]; None = all)."""
+        if active is None:
+            self._chk(self.L.gusto_set_active(self.h, None), "set_active")
+            return
+        a = _arr(np.asarray(active).astype(bool), np.int32).reshape(self.B)
+        self._chk(self.L.gusto_set_active(self.h, a.ctypes.data), "set_active")
 
     def solve_async(self, max_iter=30, force=False):
         """Enqueue the solve on the handle's stream and return; wait() (or any getter) completes it."""
@@ -376,9 +390,9 @@ class BatchSolver:
         self._chk(self.L.gusto_dev_launch_info(self.h, C.byref(a), C.byref(b), C.byref(c)), "dev_launch_info")
         return a.value, b.value, c.value
 
-    def shoot(self, p0=None, substeps=4, max_newton=100, ftol=1e-3):
+    def shoot(self, p0=None, substeps=4, max_newton=100, ftol=1e-3, group_pass=True):
         """gusto_shoot + gusto_get_shoot: indirect shooting of every problem from p0 (default: the SCP duals)."""
-        o = ShootOpts(substeps=substeps, max_newton=max_newton, ftol=ftol)
+        o = ShootOpts(substeps=substeps, max_newton=max_newton, ftol=ftol, group_pass=int(bool(group_pass)))
         pv = None if p0 is None else _arr(p0).reshape(self.B, self.n)
         self._chk(self.L.gusto_shoot(self.h, None if pv is None else pv.ctypes.data, C.byref(o)), "shoot")
         B = self.B
@@ -418,8 +432,9 @@ class TrajOptSolver(BatchSolver):
     def solve(self, max_iter=125, force=False):
         self._chk(self.L.gusto_solve_trajopt(self.h, int(max_iter)), "solve_trajopt")
 
-    def solve_async(self, *a, **k):
-        raise GustoError("TrajOptSolver: gusto_solve_trajopt is synchronous")
+    def solve_async(self, max_iter=125, force=False):
+        """gusto_solve_trajopt_async: enqueue the launch of the batch and return; wait() or any getter completes it."""
+        self._chk(self.L.gusto_solve_trajopt_async(self.h, int(max_iter)), "solve_trajopt_async")
 
     def history(self):
         B, H = self.B, self.hist_cap

@@ -365,6 +365,7 @@ struct KParams {
                         // at -1; an entry is (slices so far << 24) | problem
     int list_cap;       // entries per list: a problem is pushed at most once per finite slice
     const int* order;   // fresh problems are handed out in this order (hardest first, scp.hpp: sched_key_kernel); null = 0, 1, 2, ...
+    int n_fresh;        // how many problems the launch hands out: B, or the number of active ones (gusto_set_active: `order` lists them)
     gusto_scp_params sp;
     gusto_model_params mp;
     gusto_ipm_opts io;

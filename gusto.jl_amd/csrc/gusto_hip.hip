@@ -82,7 +82,8 @@ int gusto_default_params(int model, gusto_scp_params* sp, gusto_model_params* mp
 int gusto_default_ipm_opts(gusto_ipm_opts* o) {
     if (!o) return GUSTO_ERR_ARG;
     o->tol = 1e-8; o->tol_acc = 1e-5; o->mu_floor = -1.0 /* the model's, common.hpp: warm_defaults */; o->tr_tol = 1e-6; o->max_iter = 60; o->acc_iter = 0;
-    o->mu_warm = -1.0; o->mu_warm_gain = -1.0; o->mu_warm_max = -1.0; o->sigma_max = -1.0;   // (the algorithm's: 0.1 for GuSTO, none for TrajOpt; common.hpp: warm_defaults)   // the model's warm-start triple (common.hpp: warm_defaults)
+    // negative = the model's warm-start triple and the algorithm's centring bound (0.1 for GuSTO, none for TrajOpt), common.hpp: warm_defaults
+    o->mu_warm = -1.0; o->mu_warm_gain = -1.0; o->mu_warm_max = -1.0; o->sigma_max = -1.0;
     return GUSTO_OK;
 }
 
@@ -160,7 +161,7 @@ int gusto_destroy(gusto_handle h) {
     void* ptrs[] = {h->d_X, h->d_U, h->d_xinit, h->d_glo, h->d_ghi, h->d_tf, h->d_sti, h->d_std, h->d_Jt, h->d_Jf, h->d_conv,
                     h->d_Delta, h->d_omega, h->d_rho, h->d_acc, h->d_scp, h->d_sol, h->d_tr, h->d_cvx, h->d_ipm, h->d_ws,
                     h->d_prof, h->d_subD, h->d_subW, h->d_subT, h->d_subX, h->d_subU, h->d_subObj, h->d_subSt, h->d_subIt, h->d_box, h->d_sph,
-                    h->d_to_mu, h->d_to_xtol, h->d_to_ftol, h->d_to_ctol, h->d_Upub, h->d_env, h->d_gX, h->d_gU};
+                    h->d_to_mu, h->d_to_xtol, h->d_to_ftol, h->d_to_ctol, h->d_Upub, h->d_env, h->d_gX, h->d_gU, h->d_active};
     for (void* p : ptrs) if (p) hipFree(p);
     for (void* p : {(void*)h->d_shX, (void*)h->d_shU, (void*)h->d_shP, (void*)h->d_shP0, (void*)h->d_shRes, (void*)h->d_shSt, (void*)h->d_shIt, (void*)h->d_shList, (void*)h->d_shXt, (void*)h->d_shUt}) if (p) hipFree(p);
     if (h->d_order) hipFree(h->d_order);
@@ -174,10 +175,11 @@ int gusto_destroy(gusto_handle h) {
     return GUSTO_OK;
 }
 
-// every setter first completes an enqueued solve (gusto_solve_async) on the handle's own device
+// every setter first completes an enqueued solve (gusto_solve_async) on the handle's own device; a latched scheduler error
+// is not the setter's business (handle.hpp: it is surfaced by the getters and the solves until gusto_set_problems)
 static int setter_enter(gusto_handle h) {
     HIPCHK(h, hipSetDevice(h->device));
-    return gusto_finish(h);
+    return gusto_complete(h);
 }
 
 int gusto_set_params(gusto_handle h, const gusto_scp_params* sp, const gusto_model_params* mp) {
@@ -324,7 +326,7 @@ static int set_problems_impl(gusto_handle h, int B, const double* x_init, const 
         return GUSTO_ERR_ARG;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcw = gusto_finish(h); if (rcw && !h->sched_err) return rcw; }
+    { int rcw = gusto_complete(h); if (rcw) return rcw; }
     h->sched_err = 0;   // (a latched scheduler error ends here: every problem is set again)
     const size_t n = h->n, m = h->m, N = h->N;
     h->B = B;
@@ -339,6 +341,7 @@ static int set_problems_impl(gusto_handle h, int B, const double* x_init, const 
     int rc = do_init(h, X0 == nullptr);
     if (rc) return rc;
     h->have_problems = true; h->have_shoot = false;
+    h->n_active = -1;   // (gusto_set_active belongs to the problems it was set for)
     return GUSTO_OK;
 }
 
@@ -355,9 +358,8 @@ int gusto_solve(gusto_handle h, int max_iter, int force) {
     if (!h || max_iter < 0) return GUSTO_ERR_ARG;
     if (!h->have_problems) { h->err = "gusto_solve: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = gusto_finish(h);
-    if (rc && !h->sched_err) return rc;
-    h->sched_err = 0;
+    int rc = gusto_finish(h);   // (a batch that lost a problem to a scheduler error is not resumed: gusto_set_problems first)
+    if (rc) return rc;
     rc = do_scp(h, 0, max_iter, force ? 1 : 0);
     return rc ? rc : gusto_finish(h);
 }
@@ -367,9 +369,29 @@ int gusto_solve_async(gusto_handle h, int max_iter, int force) {
     if (!h->have_problems) { h->err = "gusto_solve_async: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc = gusto_finish(h);
-    if (rc && !h->sched_err) return rc;
-    h->sched_err = 0;
+    if (rc) return rc;
     return do_scp(h, 0, max_iter, force ? 1 : 0);
+}
+
+// Which problems of the batch the following gusto_solve / gusto_solve_async / gusto_shoot calls work on.  The reference's
+// drivers loop per problem -- solve_SCPshooting! runs another SCP iteration and another shooting attempt only `while
+// !SCPS.converged && SCPS.iterations < max_iter` (traj_opt.jl:23) --; a batch needs that condition per problem.
+int gusto_set_active(gusto_handle h, const int* active) {
+    if (!h) return GUSTO_ERR_ARG;
+    if (h->trajopt) { h->err = "gusto_set_active: TrajOpt handle (solve_trajopt_jump! has no resume)"; return GUSTO_ERR_STATE; }
+    if (!h->have_problems) { h->err = "gusto_set_active: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
+    { int rc = setter_enter(h); if (rc) return rc; }
+    if (!active) { h->n_active = -1; return GUSTO_OK; }
+    std::vector<int> buf((size_t)2 * h->batch_cap, 0);
+    int na = 0;
+    for (int b = 0; b < h->B; b++) {
+        buf[b] = active[b] != 0;
+        if (active[b]) buf[(size_t)h->batch_cap + na++] = b;
+    }
+    if (!h->d_active) HIPCHK(h, dalloc(&h->d_active, (size_t)2 * h->batch_cap));
+    HIPCHK(h, hipMemcpy(h->d_active, buf.data(), sizeof(int) * buf.size(), hipMemcpyHostToDevice));
+    h->n_active = na;
+    return GUSTO_OK;
 }
 
 int gusto_wait(gusto_handle h) {
@@ -600,21 +622,25 @@ int gusto_set_trajopt_params(gusto_handle h, const gusto_trajopt_params* tp) {
     return GUSTO_OK;
 }
 
-int gusto_solve_trajopt(gusto_handle h, int max_iter) {
+static int solve_trajopt_impl(gusto_handle h, int max_iter, bool wait, const char* who) {
     if (!h || max_iter < 0) return GUSTO_ERR_ARG;
-    if (!h->trajopt) { h->err = "gusto_solve_trajopt: not a TrajOpt handle (gusto_create_trajopt)"; return GUSTO_ERR_STATE; }
-    if (!h->have_problems) { h->err = "gusto_solve_trajopt: call gusto_set_problems first"; return GUSTO_ERR_STATE; }
+    if (!h->trajopt) { h->err = std::string(who) + ": not a TrajOpt handle (gusto_create_trajopt)"; return GUSTO_ERR_STATE; }
+    if (!h->have_problems) { h->err = std::string(who) + ": call gusto_set_problems first"; return GUSTO_ERR_STATE; }
     const int total = h->tp.max_penalty_iteration * h->tp.max_convex_iteration * h->tp.max_trust_iteration;
     if (h->hist_cap < 2 * std::min(total, max_iter) + 8) {
-        h->err = "gusto_solve_trajopt: hist_cap of the handle is below 2 * min(max_iter, max_penalty * max_convex * max_trust) + 8";
+        h->err = std::string(who) + ": hist_cap of the handle is below 2 * min(max_iter, max_penalty * max_convex * max_trust) + 8";
         return GUSTO_ERR_ARG;
     }
     HIPCHK(h, hipSetDevice(h->device));
     int rc = gusto_finish(h);
     if (rc) return rc;
     rc = do_trajopt(h, 0, max_iter);
-    return rc ? rc : gusto_finish(h);
+    return (rc || !wait) ? rc : gusto_finish(h);
 }
+int gusto_solve_trajopt(gusto_handle h, int max_iter) { return solve_trajopt_impl(h, max_iter, true, "gusto_solve_trajopt"); }
+// the TrajOpt counterpart of gusto_solve_async: the one launch of the batch is enqueued on the handle's stream and the call
+// returns; gusto_wait (or any getter) completes it.  Shards on several GPUs, or two handles on one, then run side by side.
+int gusto_solve_trajopt_async(gusto_handle h, int max_iter) { return solve_trajopt_impl(h, max_iter, false, "gusto_solve_trajopt_async"); }
 
 int gusto_get_trajopt_history(gusto_handle h, gusto_trajopt_history* o) {
     if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }

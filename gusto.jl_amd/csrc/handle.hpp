@@ -49,8 +49,12 @@ struct gusto_handle_s {
     int sched_init[gusto::SQ_WORDS] = {0};   // initial scheduler words of a launch (host side of an async copy)
     bool have_problems = false, have_shoot = false;
     int decomposition = 0;         // gusto_set_decomposition: 0 auto, 1 a wave per problem, 2 a lane per problem (lane.hpp)
-    int waves = 0;                 // gusto_set_waves: waves per problem of the GuSTO kernel (0 = one per 64 knots)
-    int sched_err = 0;             // latched scheduler error of the last solve (gusto_finish): getters fail until the next set_problems / solve
+    int waves = 0;                 // waves per problem of the GuSTO kernel (0 = one per 64 knots; development builds: GUSTO_DEV_WAVES)
+    // gusto_set_active: the problems the next gusto_solve calls iterate (n_active < 0: all of them); d_active = the mask [B]
+    // (gusto_shoot reads it), d_active + batch_cap = the list of active problems (the hand-out order of the launch)
+    int* d_active = nullptr;
+    int n_active = -1;
+    int sched_err = 0;             // latched scheduler error of the last solve (gusto_finish): getters and solves fail until the next set_problems
     int* h_sched_err = nullptr;    // pinned host word the error flag is copied to on the handle's stream, before the stream is waited for
     double *d_gX = nullptr, *d_gU = nullptr;   // gusto_gather_peer: the shards of several handles, one after the other, on this handle's GPU
     size_t gather_cap = 0;                     // ... capacity in problems
@@ -90,16 +94,23 @@ static inline int gusto_sched_err_rc(gusto_handle h) {
 // The device-side scheduler reports a problem it lost instead of leaving it half-solved (scp.hpp: sched_pop).  The flag is
 // copied on the handle's OWN stream into pinned memory right behind the kernel (launch.hpp), so reading it here needs no
 // blocking copy on the null stream (which would serialise with the other handle of an overlapped pair).  The error is
-// LATCHED: every getter keeps failing until gusto_set_problems or the next solve clears it.
-static inline int gusto_finish(gusto_handle h) {
-    if (!h->pending) return gusto_sched_err_rc(h);
+// LATCHED until gusto_set_problems: every getter and every further solve fails with it (a batch that lost a problem is
+// not resumed), the setters (environment, parameters, stream, ...) do not -- they may come before or after the problems.
+// gusto_complete: waits for an enqueued solve and latches its error; GUSTO_ERR_HIP only.
+static inline int gusto_complete(gusto_handle h) {
+    if (!h->pending) return GUSTO_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_ms = ms;
     h->pending = false;
     if (h->h_sched_err && *h->h_sched_err) h->sched_err = *h->h_sched_err;
-    return gusto_sched_err_rc(h);
+    return GUSTO_OK;
+}
+// gusto_finish: gusto_complete, then the latched scheduler error (getters, gusto_wait, gusto_solve*)
+static inline int gusto_finish(gusto_handle h) {
+    const int rc = gusto_complete(h);
+    return rc ? rc : gusto_sched_err_rc(h);
 }
 // enqueued behind a solve kernel on the handle's stream: the scheduler's error word -> pinned host memory
 static inline hipError_t gusto_fetch_sched_err(gusto_handle h) {

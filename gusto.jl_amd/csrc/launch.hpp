@@ -11,12 +11,20 @@
 
 using namespace gusto;
 
+// Development knobs (occupancy / scheduling experiments, tools/build_variant.sh) are environment variables of a
+// -DGUSTO_DEV_KNOBS build only: the shipped library reads none, its launch shape follows from the handle alone.
+#ifdef GUSTO_DEV_KNOBS
+static inline const char* dev_env(const char* k) { return getenv(k); }
+#else
+static inline const char* dev_env(const char*) { return nullptr; }
+#endif
+
 // waves per problem of the GuSTO kernel: one per 64 knots unless the caller (or GUSTO_DEV_WAVES) asks for more -- the generic
 // multi-wave phases then run with the extra waves splitting the entry-parallel sweeps (a latency / throughput trade for
 // batches smaller than the GPU)
 static inline int launch_waves(gusto_handle h) {
     int w = h->waves;
-    if (const char* e = getenv("GUSTO_DEV_WAVES")) w = atoi(e);
+    if (const char* e = dev_env("GUSTO_DEV_WAVES")) w = atoi(e);
     const int need = (h->N + 63) / 64;
     return std::min(4, std::max(w, need));
 }
@@ -24,7 +32,7 @@ static inline int launch_waves(gusto_handle h) {
 template <int MODEL> static int fill_params(gusto_handle h, KParams& P, int B, bool need_env = true) {
     using T = MT<MODEL>;
     memset(&P, 0, sizeof(P));
-    P.N = h->N; P.B = B; P.n_box = h->n_box; P.n_sph = h->n_sph;
+    P.N = h->N; P.B = B; P.n_fresh = B; P.n_box = h->n_box; P.n_sph = h->n_sph;
     P.n_obs = T::HAS_OBS ? h->n_box + h->n_sph : 0;
     if (T::HAS_OBS && h->d_env) {   // one keep-out set per problem (gusto_set_env_batch): n_obs sizes the slots, the records say the rest
         if (need_env && h->env_B != B) {
@@ -63,7 +71,7 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     P.mode = mode; P.max_iter = max_iter; P.force = force;
     const int NT = 64 * launch_waves(h);
     size_t lds = (size_t)P.ll.total * sizeof(double);
-    if (const char* pad = getenv("GUSTO_DEV_LDS_KB")) lds = std::max(lds, (size_t)atoi(pad) * 1024);  // occupancy experiments
+    if (const char* pad = dev_env("GUSTO_DEV_LDS_KB")) lds = std::max(lds, (size_t)atoi(pad) * 1024);  // occupancy experiments
     if (lds > 160 * 1024) { h->err = "problem does not fit the 160 KiB LDS of a CU"; return GUSTO_ERR_ARG; }
     // a problem with N <= 64 knots runs as one wave per workgroup (no barriers at all)
     auto kern = (NT == 64) ? &scp_kernel<MODEL, true> : &scp_kernel<MODEL, false>;
@@ -73,8 +81,10 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NT, lds));
     HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     int slots = std::max(1, per_cu) * std::max(1, cus);
-    if (const char* e = getenv("GUSTO_DEV_SLOTS")) slots = std::max(1, atoi(e));   // occupancy experiments
-    slots = std::min(slots, h->B);
+    if (const char* e = dev_env("GUSTO_DEV_SLOTS")) slots = std::max(1, atoi(e));   // occupancy experiments
+    const bool masked = mode == 0 && h->n_active >= 0;    // gusto_set_active: only the listed problems are handed out
+    if (masked) P.n_fresh = h->n_active;
+    slots = std::min(slots, std::max(1, P.n_fresh));
     h->slots = slots; h->lds_bytes = (int)lds; h->per_cu = per_cu;
     {
         const size_t need = P.wl.total * (size_t)slots;
@@ -91,9 +101,9 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     const int probe = h->sched_forced ? h->probe_iters : MT<MODEL>::SCHED_PROBE;
     const bool dyn = mode == 0 && probe > 0 && probe < 128 && max_iter > probe && h->B >= h->probe_min_batch && h->B < (1 << 24);
     memset(h->sched_init, 0, sizeof(h->sched_init));
-    h->sched_init[SQ_PROBING] = dyn ? h->B : 0;     // every problem starts with its probing slices still ahead
+    h->sched_init[SQ_PROBING] = dyn ? P.n_fresh : 0;     // every problem starts with its probing slices still ahead
     HIPCHK(h, hipMemcpyAsync(h->d_queue, h->sched_init, SQ_WORDS * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    int slice_q = dyn ? (getenv("GUSTO_SLICE_Q") ? atoi(getenv("GUSTO_SLICE_Q")) : MT<MODEL>::SCHED_SLICE) : 0;
+    int slice_q = dyn ? (dev_env("GUSTO_SLICE_Q") ? atoi(dev_env("GUSTO_SLICE_Q")) : MT<MODEL>::SCHED_SLICE) : 0;
     int pushes = probe + (slice_q > 0 ? (max_iter + slice_q - 1) / slice_q + 1 : 0);   // finite slices of a problem at most
     // a waiting-list entry keeps the slice count in its high byte, (slices + 1) << 24 | problem, and a negative entry means
     // "not published yet": more than 126 finite slices per problem do not fit -- then a problem of level 0 runs to its end
@@ -111,9 +121,9 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
         HIPCHK(h, hipMemsetAsync(h->d_order, 0xFF, (size_t)SCHED_LEVELS * P.list_cap * sizeof(int), h->stream));
     }
     P.queue = h->d_queue; P.lists = h->d_order; P.probe_visits = dyn ? probe : 0; P.slice_q = slice_q;
-    P.order = nullptr;
+    P.order = masked ? h->d_active + h->batch_cap : nullptr;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));   // (the solve's time includes the ordering kernels below)
-    if (dyn && T::HAS_OBS && P.n_obs > 0 && !getenv("GUSTO_DEV_NO_ORDER")) {   // hardest first (scp.hpp: sched_key_kernel)
+    if (!masked && dyn && T::HAS_OBS && P.n_obs > 0 && !dev_env("GUSTO_DEV_NO_ORDER")) {   // hardest first (scp.hpp: sched_key_kernel)
         if (!h->d_sched_ord) HIPCHK(h, dalloc(&h->d_sched_ord, (size_t)2 * h->batch_cap));
         int* bucket = h->d_sched_ord;
         int* order = h->d_sched_ord + h->batch_cap;
@@ -124,7 +134,7 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
         HIPCHK(h, hipGetLastError());
         P.order = order;
     }
-    if (getenv("GUSTO_DEV_DEBUG"))
+    if (dev_env("GUSTO_DEV_DEBUG"))
         fprintf(stderr, "launch: B %d slots %d dyn %d probe %d list_cap %d queue %p lists %p..%p ws %p..%p X %p st_i %p..%p hist Delta %p\n", h->B, slots,
                 (int)dyn, P.probe_visits, P.list_cap, (void*)P.queue, (void*)P.lists, (void*)(P.lists + h->order_ints), (void*)P.ws,
                 (void*)(P.ws + h->ws_doubles), (void*)P.X, (void*)P.st_i, (void*)(P.st_i + (size_t)h->batch_cap * ST_NI), (void*)P.Delta);
@@ -145,7 +155,7 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
 static inline bool lane_decomposition(gusto_handle h) {
     if (h->decomposition == 1) return false;
     if (h->decomposition == 2) return true;
-    if (const char* e = getenv("GUSTO_DEV_LANE")) return atoi(e) != 0;
+    if (const char* e = dev_env("GUSTO_DEV_LANE")) return atoi(e) != 0;   // (development builds)
     return false;
 }
 // One lane per problem (lane.hpp): ceil(B / lanes per wave) one-wave workgroups, each with its own block of the lane
@@ -155,20 +165,21 @@ template <int MODEL> static int launch_lane(gusto_handle h, int mode, int max_it
     KParams P;
     int rc = fill_params<MODEL>(h, P, h->B);
     if (rc) return rc;
+    if (h->n_active >= 0) { h->err = "gusto_set_active: not with a lane per problem (gusto_set_decomposition)"; return GUSTO_ERR_STATE; }
     P.mode = mode; P.max_iter = max_iter; P.force = force;
     int cus = 0;
     HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     // lanes per wave: 64 unless the batch is too small to give every SIMD a wave (then fewer problems per wave: the
     // instruction stream of a wave costs the same for 16 problems as for 64)
     int lpw = 64;
-    if (const char* e = getenv("GUSTO_DEV_LANES_PER_WAVE")) lpw = std::max(1, std::min(64, atoi(e)));
+    if (const char* e = dev_env("GUSTO_DEV_LANES_PER_WAVE")) lpw = std::max(1, std::min(64, atoi(e)));
     else while (lpw > 8 && (h->B + lpw - 1) / lpw < 4 * std::max(1, cus)) lpw >>= 1;
     // persistent lanes: at most the waves the GPU keeps resident (one per SIMD at this kernel's register budget); a lane that
     // finishes takes the next problem of the batch (lane.hpp)
     int per_cu = 0;
     HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lane_kernel<MODEL>), 64, 0));
     int nw = std::min((h->B + lpw - 1) / lpw, std::max(1, per_cu) * std::max(1, cus));
-    if (const char* e = getenv("GUSTO_DEV_SLOTS")) nw = std::max(1, std::min(nw, atoi(e)));
+    if (const char* e = dev_env("GUSTO_DEV_SLOTS")) nw = std::max(1, std::min(nw, atoi(e)));
     const size_t need = (size_t)nw * (size_t)h->N * (size_t)(Y::EK * 64);
     if (need > h->ws_doubles) {
         if (h->d_ws) hipFree(h->d_ws);

@@ -312,9 +312,9 @@ GD int sched_pop(const KParams& P, bool& cont, int& from) {   // from: the level
             const int e = take(SCHED_LEVELS - 1, 1);
             if (e != -2) { cont = true; return e; }
         }
-        if (uload(Q + SQ_HEAD_A) < P.B) {
+        if (uload(Q + SQ_HEAD_A) < P.n_fresh) {
             const int q = uadd(Q + SQ_HEAD_A, 1);
-            if (q < P.B) { cont = false; return P.order ? uload(P.order + q) : q; }
+            if (q < P.n_fresh) { cont = false; return P.order ? uload(P.order + q) : q; }
         }
         {
             const int e = take(SCHED_LEVELS - 1, 0);

@@ -33,6 +33,7 @@ struct ShootParams {
     int *status, *iters;
     int cap;            // Newton iterations of the lane-per-problem pass; a problem still running then goes to `list`
     int *list, *count;  // problems handed to the group pass (shoot_group_kernel), their number
+    const int* active;  // gusto_set_active: null = every problem, else the mask [B] (an inactive problem is reported :Diverged, untouched)
 };
 
 template <int MODEL> struct ShootModel;
@@ -181,6 +182,11 @@ template <int MODEL> __global__ void __launch_bounds__(64) shoot_kernel(const Sh
     constexpr int n = M::n, m = M::m;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= S.B) return;
+    if (S.active && !S.active[b]) {
+        S.status[b] = 0; S.iters[b] = 0; S.resid[b] = NAN;
+        for (int i = 0; i < n; i++) S.p_out[(size_t)b * n + i] = S.p0[(size_t)b * n + i];
+        return;
+    }
     double x0[n], pv[n], xg[n], F[n], xT[n], nf = 0.0;
     const double tf = S.tf[b];
 #pragma unroll
@@ -347,6 +353,7 @@ extern "C" {
 int gusto_default_shoot_opts(gusto_shoot_opts* o) {
     if (!o) return GUSTO_ERR_ARG;
     o->substeps = 4; o->max_newton = 100; o->ftol = 1e-3;      // shooting.jl:14: iterations = 100, ftol = 1e-3
+    o->group_pass = 1;
     return GUSTO_OK;
 }
 
@@ -386,9 +393,9 @@ int gusto_shoot(gusto_handle h, const double* p0, const gusto_shoot_opts* opts) 
     // two passes: a lane per problem for the first SHOOT_CAP Newton iterations (the problems that converge need 0-4), then
     // the stragglers with a group of lanes each (shoot_group_kernel)
     constexpr int SHOOT_CAP = 8;
-    const int cap_env = getenv("GUSTO_SHOOT_CAP") ? atoi(getenv("GUSTO_SHOOT_CAP")) : SHOOT_CAP;   // (development knob)
-    S.cap = (getenv("GUSTO_SHOOT_ONE_PASS") || o.max_newton <= cap_env) ? o.max_newton : cap_env;
+    S.cap = (!o.group_pass || o.max_newton <= SHOOT_CAP) ? o.max_newton : SHOOT_CAP;
     S.list = h->d_shList; S.count = h->d_shList + h->batch_cap;
+    S.active = h->n_active >= 0 ? h->d_active : nullptr;
     HIPCHK(h, hipMemsetAsync(S.count, 0, sizeof(int), h->stream));
     if (h->model == GUSTO_DUBINS_CAR) hipLaunchKernelGGL(shoot_kernel<GUSTO_DUBINS_CAR>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, S);
     else hipLaunchKernelGGL(shoot_kernel<GUSTO_ASTROBEE_SE3_MANIFOLD>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, S);

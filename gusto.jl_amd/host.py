@@ -172,8 +172,11 @@ class SCPSolution:
         self.solver_status, self.scp_status = ["NA"], ["NA"]
         self.accept_solution, self.convergence_measure = [True], [0.0]
         self.successful = self.converged = False
+        self.stop_reason = "MaxIter"      # gusto_get_status stop reason of the last solve_method! call (_capi.STOP_REASON)
         self.iterations, self.iter_elapsed_times, self.total_time = 0, [0.0], 0.0
-        self._solver = None     # the gusto_handle that owns the device-side state of this solution (resume)
+        self._solver = None     # the GuSTO gusto_handle that owns the device-side state of this solution (resume, shooting)
+        self._solver_trajopt = None   # the TrajOpt handle of this solution (gusto_create_trajopt), kept apart: neither algorithm
+                                      # ever finds the other's handle
 
 
 class TrajectoryOptimizationSolution:
@@ -246,7 +249,9 @@ def solve_gusto_hip(SCPS, SCPP, solver="hip", max_iter=30, force=False, device=0
     model = SCPP.PD.model
     n, N = model.x_dim, SCPP.N
     bs = SCPS._solver
-    if bs is None:
+    if not (type(bs) is BatchSolver and bs.h and bs.model == model.model_id and bs.N == N and bs.device == device):
+        if bs is not None:      # (a handle of another model / horizon / device cannot resume this solution)
+            bs.close()
         env = SCPP.PD.env
         bs = BatchSolver(model.model_id, N, 1, hist_cap=hist_cap or _hist_cap(max_iter), device=device, boxes=env.boxes,
                          spheres=env.spheres, scp_params=SCPP.scp_params, model_params=SCPP.model_params)
@@ -282,8 +287,8 @@ def solve_trajopt_hip(SCPS, SCPP, solver="hip", max_iter=125, force=False, devic
     total = tp.max_penalty_iteration * tp.max_convex_iteration * tp.max_trust_iteration
     # one handle per SCPSolution: a repeated call re-uses it (device allocations, kernel attributes) and only sets the problem
     # again -- solve_trajopt_jump! has no resume either, every call runs the whole three-loop schedule from SCPS.traj
-    bs = SCPS._solver
-    if not (isinstance(bs, _capi.TrajOptSolver) and bs.model == model.model_id and bs.N == N and bs.device == device
+    bs = SCPS._solver_trajopt
+    if not (isinstance(bs, _capi.TrajOptSolver) and bs.h and bs.model == model.model_id and bs.N == N and bs.device == device
             and bs.hist_cap >= 2 * total + 16):
         if bs is not None:
             bs.close()
@@ -293,13 +298,15 @@ def solve_trajopt_hip(SCPS, SCPP, solver="hip", max_iter=125, force=False, devic
         bs.set_env(env.boxes, env.spheres)
         bs._chk(bs.L.gusto_set_params(bs.h, None, _capi.C.byref(SCPP.model_params)), "set_params")
         bs._chk(bs.L.gusto_set_trajopt_params(bs.h, _capi.C.byref(tp)), "set_trajopt_params")
+    if kwarg.get("ipm_opts") is not None:       # (applied on every call, re-used handle or not)
+        bs._chk(bs.L.gusto_set_ipm_opts(bs.h, _capi.C.byref(kwarg["ipm_opts"])), "set_ipm_opts")
     lo, hi = _goal_bounds(SCPP.PD.goal_set, n, SCPP.tf_guess)
     bs.set_problems(SCPP.PD.x_init[None], lo[None], hi[None], [SCPP.tf_guess], SCPS.traj.X.T[None].copy(), SCPS.traj.U.T[None].copy())
     bs.solve(max_iter)
     X, U = bs.traj()
     _fill_trajopt_solution(SCPS, SCPP, dict(X=X, U=U, st=bs.status(), h=bs.history(), dual=bs.dual()), 0,
                            bs.last_solve_ms() * 1e-3)
-    SCPS._solver = bs
+    SCPS._solver_trajopt = bs
 
 
 def _fill_trajopt_solution(SCPS, SCPP, snap, b, elapsed):
@@ -398,7 +405,9 @@ def solve_SCPshooting(TOS, TOP, solve_method, init_method, solver="hip", max_ite
     kwarg.setdefault("hist_cap", _hist_cap(max_iter))
     solve_method(SCPS, SCPP, solver, 1, **kwarg)
     SS.J_true.append(SCPS.J_true[0])
-    while not SCPS.converged and SCPS.iterations < max_iter:
+    # (a run that stopped for good -- failed subproblem, omega > omega_max -- leaves the loop: the reference's solve_method!
+    # returns early there without counting an iteration, scp_gusto.jl:107-111,163-166, and its loop would spin for ever)
+    while not SCPS.converged and SCPS.iterations < max_iter and SCPS.stop_reason not in _DEAD_STOPS:
         SP = ShootingProblem(TOP, SCPS)
         solve_shooting(SS, SP)
         spread = 2
@@ -412,6 +421,101 @@ def solve_SCPshooting(TOS, TOP, solve_method, init_method, solver="hip", max_ite
     TOS.traj = Trajectory(SCPS.traj.X.copy(), SCPS.traj.U.copy(), SCPS.traj.Tf)
     TOS.total_time = SCPS.total_time + sum(SS.iter_elapsed_times)
     return TOS
+
+
+_DEAD_STOPS = ("SubproblemFailed", "OmegaMaxExceeded", "HistoryFull")
+
+
+def solve_SCPshooting_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straightline, solver="hip", max_iter=30,
+                            device=0, **kwarg):
+    """solve_SCPshooting! (traj_opt.jl:4-45) for a list of problems of one model and horizon on ONE handle: per round one
+    gusto_shoot and one gusto_solve(1) over the problems still in their loop (gusto_set_active carries the per-problem
+    condition `!SCPS.converged && SCPS.iterations < max_iter` of traj_opt.jl:23), every problem leaving exactly where the
+    single-problem driver above leaves -- its SCPSolution / ShootingSolution are those solve_SCPshooting fills, bit for bit."""
+    import time
+    if solve_method not in (None, solve_gusto_hip):
+        raise NotImplementedError("solve_SCPshooting_batch!: the shooting refinement follows the GuSTO solve (solve_gusto_hip)")
+    if len(TOSs) != len(TOPs) or not TOPs:
+        raise ValueError("solve_SCPshooting_batch!: need as many solutions as problems, at least one")
+    TOP0 = TOPs[0]
+    model, N, B = TOP0.PD.model, TOP0.N, len(TOPs)
+    n = model.x_dim
+    for t in TOPs[1:]:
+        if type(t.PD.model) is not type(model) or t.N != N:
+            raise ValueError("solve_SCPshooting_batch!: all problems must share the model type and N")
+    same_env = all(np.array_equal(t.PD.env.boxes, TOP0.PD.env.boxes) and np.array_equal(t.PD.env.spheres, TOP0.PD.env.spheres)
+                   for t in TOPs[1:])
+    SCPPs = [SCPProblem(t) for t in TOPs]
+    inits = [init_method(t) if callable(init_method) else Trajectory(init_method.X.copy(), init_method.U.copy(), init_method.Tf)
+             for t in TOPs]
+    SCPSs = [SCPSolution(p, i) for p, i in zip(SCPPs, inits)]
+    bs = BatchSolver(model.model_id, N, B, hist_cap=kwarg.get("hist_cap") or _hist_cap(max_iter), device=device,
+                     boxes=TOP0.PD.env.boxes, spheres=TOP0.PD.env.spheres, scp_params=SCPPs[0].scp_params,
+                     model_params=SCPPs[0].model_params)
+    if not same_env:
+        bs.set_env_batch([t.PD.env.boxes for t in TOPs], [t.PD.env.spheres for t in TOPs])
+    bounds = [_goal_bounds(t.PD.goal_set, n, t.tf_guess) for t in TOPs]
+    bs.set_problems(np.stack([t.PD.x_init for t in TOPs]), np.stack([b[0] for b in bounds]), np.stack([b[1] for b in bounds]),
+                    np.array([t.tf_guess for t in TOPs]), np.stack([t.X.T for t in inits]), np.stack([t.U.T for t in inits]))
+    SSs = []
+    for b, (TOS, TOP) in enumerate(zip(TOSs, TOPs)):
+        TOS.SCPS = SCPSs[b]
+        SP = ShootingProblem(TOP, SCPSs[b])
+        TOS.SS = ShootingSolution(SP, Trajectory(inits[b].X.copy(), inits[b].U.copy(), inits[b].Tf))
+        SSs.append(TOS.SS)
+
+    def scp_round(live):       # solve_method!(SCPS, SCPP, solver, 1) of every live problem: ONE launch
+        bs.set_active(live)
+        bs.solve(1)
+        snap = _fetch(bs)
+        per = bs.last_solve_ms() * 1e-3 / max(1, int(np.sum(live)))
+        for b in np.flatnonzero(live):
+            _fill_solution(SCPSs[b], SCPPs[b], snap, b, per)
+
+    live = np.ones(B, bool)
+    scp_round(live)
+    for b in range(B):
+        SSs[b].J_true.append(SCPSs[b].J_true[0])
+    done_by_shooting = np.zeros(B, bool)
+    while True:
+        live = np.array([not S.converged and S.iterations < max_iter and S.stop_reason not in _DEAD_STOPS for S in SCPSs]) \
+            & ~done_by_shooting
+        if not live.any():
+            break
+        bs.set_active(live)
+        t0 = time.perf_counter()
+        r = bs.shoot()                                    # seeds = SCPS.dual of every problem, read on the device
+        el = (time.perf_counter() - t0) / int(live.sum())
+        for b in np.flatnonzero(live):
+            SS, SCPS = SSs[b], SCPSs[b]
+            SS.SP = ShootingProblem(TOPs[b], SCPS)
+            if int(r["status"][b]) == 1:
+                new_traj = Trajectory(r["X"][b].T.copy(), r["U"][b].T.copy(), SS.SP.tf)
+                SS.prob_status.append("Optimal")
+                SS.J_true.append(cost_true(new_traj))
+                SS.convergence_measure.append(convergence_metric(new_traj, SS.traj))
+                SS.traj = new_traj
+            else:
+                SS.prob_status.append("Diverged")
+                SS.J_true.append(float("nan"))
+                SS.convergence_measure.append(float("nan"))
+            SS.iter_elapsed_times.append(el)
+            SS.p0 = r["p0"][b]
+            cm = SS.convergence_measure[-2:]
+            if SCPS.iterations > 2 and not any(np.isnan(cm)) and sum(cm) <= SCPPs[b].scp_params.convergence_threshold:
+                SS.converged = True
+                done_by_shooting[b] = True
+        live &= ~done_by_shooting
+        if live.any():
+            scp_round(live)
+    bs.set_active(None)
+    for b, TOS in enumerate(TOSs):
+        src = SSs[b].traj if done_by_shooting[b] else SCPSs[b].traj
+        TOS.traj = Trajectory(src.X.copy(), src.U.copy(), src.Tf)
+        TOS.total_time = SCPSs[b].total_time + sum(SSs[b].iter_elapsed_times)
+        SCPSs[b]._solver = None          # (the batch handle is not a per-problem resume handle)
+    bs.close()
+    return TOSs
 
 
 # ---- batch API (new: the reference has no batch mode) --------------------------------------------------------------
@@ -473,7 +577,7 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
             bs.set_env_batch([t.PD.env.boxes for t in TOPs[b0:b1]], [t.PD.env.spheres for t in TOPs[b0:b1]])
         bs.set_problems(x0[b0:b1], lo[b0:b1], hi[b0:b1], tf[b0:b1], X0[b0:b1], U0[b0:b1])
         if trajopt:
-            bs.solve(max_iter)          # (gusto_solve_trajopt is synchronous: the shards of a TrajOpt batch run one after the other)
+            bs.solve_async(max_iter)    # gusto_solve_trajopt_async: the shards of a TrajOpt batch run side by side too
         else:
             bs.solve_async(max_iter, force)
         shards.append((b0, b1, bs))

@@ -122,20 +122,32 @@ def _sdf_box3(p, lo, hi):
     return -float(min((p - lo).min(), (hi - p).min()))
 
 
+_ISS_CACHE = {}
+
+
 def _astrobee_free_points(count, seed, with_obstacles=True, margin=0.1):
     """Points uniform in keep-in boxes #4,#5,#8 (the corner module) shrunk by r+margin, rejected if the sphere
-    touches any keep-out component."""
-    d = _iss()
-    boxes, sph = iss_corner_env(with_obstacles)
-    zones = d["keepin"][[3, 4, 7]]
+    touches any keep-out component.  The obstacle test runs over all components at
+    once (the same arithmetic per component as _sdf_box3; the tables are read from disk once)."""
+    key = bool(with_obstacles)
+    if key not in _ISS_CACHE:
+        d = _iss()
+        boxes, sph = iss_corner_env(with_obstacles)
+        _ISS_CACHE[key] = (d["keepin"][[3, 4, 7]].copy(), boxes[:, :3].copy(), boxes[:, 3:].copy(), sph.copy())
+    zones, blo, bhi, sph = _ISS_CACHE[key]
     g = splitmix64(seed)
     pts = []
     while len(pts) < count:
         z = zones[int(next(g) * 3) % 3]
         lo, hi = z[:3] + ASTROBEE_RADIUS + margin, z[3:] - ASTROBEE_RADIUS - margin
         p = lo + (hi - lo) * np.array([next(g), next(g), next(g)])
-        ok = all(_sdf_box3(p, b[:3], b[3:]) - ASTROBEE_RADIUS > margin for b in boxes)
-        ok = ok and all(np.linalg.norm(p - s[:3]) - s[3] - ASTROBEE_RADIUS > margin for s in sph)
+        e = np.maximum(np.maximum(blo - p, 0.0), p - bhi)
+        out = (e > 0).any(axis=1)
+        d_out = np.sqrt((e * e).sum(axis=1))
+        d_in = -np.minimum((p - blo).min(axis=1), (bhi - p).min(axis=1))
+        ok = bool((np.where(out, d_out, d_in) - ASTROBEE_RADIUS > margin).all())
+        if ok and len(sph):
+            ok = bool((np.sqrt(((p - sph[:, :3]) ** 2).sum(axis=1)) - sph[:, 3] - ASTROBEE_RADIUS > margin).all())
         if ok:
             pts.append(p)
     return np.array(pts)

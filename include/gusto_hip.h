@@ -164,6 +164,12 @@ int gusto_solve(gusto_handle h, int max_iter, int force);
  * solve on the handle) completes it.  New: the reference is blocking.  Two handles used alternately keep the GPU
  * full across consecutive batches -- the tail of one batch (its slowest problems) overlaps the head of the next. */
 int gusto_solve_async(gusto_handle h, int max_iter, int force);
+/* Which problems of the batch the following gusto_solve / gusto_solve_async / gusto_shoot calls work on: active [B], nonzero =
+ * iterate, NULL = all again (the state after gusto_set_problems).  The reference's drivers loop per problem --
+ * solve_SCPshooting! takes another SCP iteration and another shooting attempt only `while !SCPS.converged &&
+ * SCPS.iterations < max_iter` (src/traj_opt.jl:23) -- and a batch needs that condition per problem: an inactive problem
+ * keeps its trajectory, histories and counters untouched.  Not for TrajOpt handles nor the lane-per-problem decomposition. */
+int gusto_set_active(gusto_handle h, const int* active);
 int gusto_wait(gusto_handle h);
 /* GPU time of the last gusto_solve, measured with HIP events on the stream the kernel ran on */
 int gusto_last_solve_ms(gusto_handle h, double* ms);
@@ -216,6 +222,8 @@ typedef struct {
     int substeps;    /* RK4 steps per knot interval (default 4)             */
     int max_newton;  /* nlsolve(..., iterations = 100, ...)  shooting.jl:14 */
     double ftol;     /* nlsolve(..., ftol = 1e-3)            shooting.jl:14 */
+    int group_pass;  /* 1 (default): problems still iterating after 8 Newton steps go on with 16 lanes each; 0: a lane per
+                      * problem throughout -- the same results bit for bit, slower for the stragglers (tests compare the two) */
 } gusto_shoot_opts;
 int gusto_default_shoot_opts(gusto_shoot_opts* o);
 int gusto_shoot(gusto_handle h, const double* p0, const gusto_shoot_opts* opts);
@@ -251,6 +259,10 @@ int gusto_set_trajopt_params(gusto_handle h, const gusto_trajopt_params* tp);
 /* the whole three-loop schedule (penalty mu x k, convex iterations, trust region s x tau+-) for every problem of the batch;
  * max_iter caps the number of convex subproblems per problem (the reference computes iter_cap and never reads it) */
 int gusto_solve_trajopt(gusto_handle h, int max_iter);
+/* ... enqueued on the handle's stream like gusto_solve_async: returns once the one launch of the batch is queued; gusto_wait
+ * or any getter completes it.  One handle per GPU (SURVEY.md 8(b) threading row): the shards of a multi-GPU TrajOpt batch,
+ * or two handles on one GPU, run side by side instead of one after the other. */
+int gusto_solve_trajopt_async(gusto_handle h, int max_iter);
 /* SCPParam_TrajOpt vectors as [B][hist_cap] arrays with their lengths [B]: rho_vec and s_vec have 1 + iterations entries,
  * J_true 1 + iterations, J_full / convergence_measure / solver_status iterations (solver_status, ipm_iters and
  * convergence_measure start at row 1 like the GuSTO histories).  Any pointer may be NULL. */

@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def lane(monkeypatch):
-    """every dubins_car solve of the test runs a lane per problem (launch.hpp: lane_decomposition reads it per launch)"""
-    monkeypatch.setenv("GUSTO_DEV_LANE", "1")
+    """every dubins_car handle the test creates gets gusto_set_decomposition(GUSTO_DECOMP_LANE)"""
+    import gusto_jl_amd as g
+    monkeypatch.setattr(g.BatchSolver, "default_decomposition", 2)
 
 
 def _dubins(B):

@@ -233,8 +233,59 @@ def test_batch_through_the_seam_and_handle_reuse():
             assert out[b].SCPP.mu_vec == ones[b].SCPP.mu_vec and out[b].SCPP.s_vec == ones[b].SCPP.s_vec
             assert TOSs[b].traj is out[b].traj and out[b].traj.U.shape == (3, 30)
     S = ones[0]
-    handle = S._solver
+    handle = S._solver_trajopt
     n1 = S.iterations
     H.solve_trajopt_hip(S, S.SCPP, "hip", 125)
-    assert S._solver is handle and S.iterations > 0 and len(S.J_true) == S.iterations + 1
+    assert S._solver_trajopt is handle and S._solver is None and S.iterations > 0 and len(S.J_true) == S.iterations + 1
     assert n1 > 0
+    # the two algorithms never find each other's handle: a GuSTO solve on the same SCPSolution creates its own and the
+    # shooting refinement (which needs the GuSTO handle's device state) is not disturbed by a TrajOpt call in between
+    H.solve_gusto_hip(S, S.SCPP, "hip", 2)
+    gh = S._solver
+    assert type(gh) is g.BatchSolver and S._solver_trajopt is handle
+    H.solve_trajopt_hip(S, S.SCPP, "hip", 125)
+    assert S._solver is gh and gh.h
+
+
+def test_async_solves_of_two_handles_overlap_and_change_nothing():
+    """gusto_solve_trajopt_async + gusto_wait: two TrajOpt handles on one GPU with their launches in flight together give,
+    bit for bit, what gusto_solve_trajopt gives each of them alone, and the pair takes less wall time than the two
+    synchronous solves one after the other (each batch is small enough to leave most of the GPU to the other)."""
+    import time
+    B = 96
+    x0, glo, ghi, tf = P.freeflyer_batch(2 * B)
+    hs = [g.TrajOptSolver(g.FREEFLYER_SE2, 50, B, boxes=P.freeflyer_env()) for _ in range(2)]
+    ref, t_sync = [], 0.0
+    for rep in range(2):                       # (first round warms both handles up)
+        ref, t_sync = [], 0.0
+        for j, s in enumerate(hs):
+            s.set_problems(x0[j * B:(j + 1) * B], glo[j * B:(j + 1) * B], ghi[j * B:(j + 1) * B], tf[j * B:(j + 1) * B])
+            t0 = time.perf_counter()
+            s.solve(125)
+            t_sync += time.perf_counter() - t0
+            ref.append((s.traj(), s.status(), s.history()))
+    for j, s in enumerate(hs):
+        s.set_problems(x0[j * B:(j + 1) * B], glo[j * B:(j + 1) * B], ghi[j * B:(j + 1) * B], tf[j * B:(j + 1) * B])
+    t0 = time.perf_counter()
+    for s in hs:
+        s.solve_async(125)                     # both launches queued before either is waited for
+    for s in hs:
+        s.wait()
+    t_async = time.perf_counter() - t0
+    for j, s in enumerate(hs):
+        (X, U), st, h = ref[j]
+        Xa, Ua = s.traj()
+        assert np.array_equal(X, Xa) and np.array_equal(U, Ua)
+        sa = s.status()
+        assert all(np.array_equal(st[k], sa[k]) for k in st)
+        ha = s.history()
+        assert all(np.array_equal(h[k], ha[k], equal_nan=(h[k].dtype.kind == "f")) for k in h)
+    print(f"trajopt 2 x {B}: sync {1e3 * t_sync:.1f} ms, async pair {1e3 * t_async:.1f} ms")
+    assert t_async < 0.9 * t_sync
+    # the error paths of the new entry point are those of the synchronous one
+    gs = g.BatchSolver(g.FREEFLYER_SE2, 50, 2, boxes=P.freeflyer_env())
+    gs.set_problems(x0[:2], glo[:2], ghi[:2], tf[:2])
+    assert gs.L.gusto_solve_trajopt_async(gs.h, 10) != 0
+    fresh = g.TrajOptSolver(g.FREEFLYER_SE2, 50, 2, boxes=P.freeflyer_env())
+    with pytest.raises(g.GustoError):
+        fresh.solve_async(125)                 # no problems set

@@ -151,8 +151,7 @@ def test_group_pass_of_the_stragglers_changes_nothing(monkeypatch):
     s.set_problems(*P.dubins_batch(B))
     s.solve(3)                                       # a few SCP iterations: a mediocre seed, many long Newton runs
     two = s.shoot()
-    monkeypatch.setenv("GUSTO_SHOOT_ONE_PASS", "1")
-    one = s.shoot()
+    one = s.shoot(group_pass=False)
     late = two["newton_iters"] > 8
     assert late.sum() > B // 50 and (two["status"][late] == 1).any() and (two["status"][late] == 0).any()
     for key in ("status", "newton_iters", "resid", "p0"):
@@ -234,3 +233,93 @@ def test_solve_SCPshooting_manifold_through_the_seam():
             assert SS.prob_status[-1] == SS.prob_status[-2] == "Optimal" and np.isfinite(SS.J_true[-1])
         else:
             assert np.array_equal(TOS.traj.X, SCPS.traj.X)
+
+
+def _shooting_tops(model_name, idx):
+    H = g.host
+    if model_name == "dubins":
+        model = H.DubinsCar()
+        x0, glo, ghi, tf = P.dubins_batch(max(idx) + 1)
+        env, N = H.BlankEnv, 30
+    else:
+        model = H.AstrobeeSE3Manifold()
+        x0, glo, ghi, tf = P.astrobee_manifold_batch(max(idx) + 1)
+        env, N = (lambda: H.ISSCorner(True)), 50
+    tops = []
+    for b in idx:
+        gs = H.GoalSet()
+        H.add_goal(gs, H.Goal(H.PointGoal(glo[b]), tf[b], model))
+        tops.append(H.TrajectoryOptimizationProblem(H.ProblemDefinition(H.Robot(), model, env(), x0[b], gs), N, tf[b], True))
+    return tops
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name,idx", [("dubins", list(range(24))), ("manifold", [0, 1, 2, 3])])
+def test_solve_SCPshooting_batch_equals_the_single_problem_driver(model_name, idx):
+    """solve_SCPshooting_batch! (one handle, one gusto_shoot and one gusto_solve(1) per round over the live problems,
+    gusto_set_active) against solve_SCPshooting! problem by problem (traj_opt.jl:4-45): every problem leaves its loop in
+    the same round for the same reason with the same SCPSolution / ShootingSolution, bit for bit."""
+    H = g.host
+    tops = _shooting_tops(model_name, idx)
+    ones = []
+    for t in tops:
+        TOS = H.TrajectoryOptimizationSolution(t)
+        H.solve_SCPshooting(TOS, t, H.solve_gusto_hip, H.init_traj_straightline, "hip", max_iter=30)
+        ones.append(TOS)
+    TOSs = [H.TrajectoryOptimizationSolution(t) for t in tops]
+    H.solve_SCPshooting_batch(TOSs, tops, H.solve_gusto_hip, H.init_traj_straightline, "hip", max_iter=30)
+    exits = set()
+    for a, b in zip(ones, TOSs):
+        assert a.SS.converged == b.SS.converged and a.SS.prob_status == b.SS.prob_status
+        assert np.array_equal(a.SS.convergence_measure, b.SS.convergence_measure, equal_nan=True)
+        assert np.array_equal(a.SS.J_true, b.SS.J_true, equal_nan=True)
+        assert a.SCPS.iterations == b.SCPS.iterations and a.SCPS.converged == b.SCPS.converged
+        assert a.SCPS.scp_status == b.SCPS.scp_status and a.SCPS.J_true == b.SCPS.J_true
+        assert a.SCPS.SCPP.Delta_vec == b.SCPS.SCPP.Delta_vec and a.SCPS.SCPP.omega_vec == b.SCPS.SCPP.omega_vec
+        assert np.array_equal(a.SCPS.traj.X, b.SCPS.traj.X) and np.array_equal(a.SCPS.dual, b.SCPS.dual)
+        assert np.array_equal(a.traj.X, b.traj.X) and np.array_equal(a.traj.U, b.traj.U)
+        exits.add("shooting" if a.SS.converged else ("scp" if a.SCPS.converged else "other"))
+    print(model_name, "exits", exits, "iterations", [t.SCPS.iterations for t in TOSs])
+    if model_name == "dubins":
+        assert {"shooting", "scp"} <= exits or {"shooting", "other"} <= exits      # the batch holds problems that leave differently
+
+
+@pytest.mark.gpu
+def test_inactive_problems_are_left_untouched():
+    """gusto_set_active: a solve / shoot over a subset changes nothing of the others (trajectory, histories, counters), and
+    the subset gets what it gets in a batch of its own."""
+    B = 64
+    x0, glo, ghi, tf = P.freeflyer_batch(B)
+    s = g.BatchSolver(g.FREEFLYER_SE2, 50, B, hist_cap=80, boxes=P.freeflyer_env())
+    s.set_problems(x0, glo, ghi, tf)
+    s.solve(2)
+    X0, U0 = s.traj()
+    h0, st0 = s.history(), s.status()
+    act = np.zeros(B, bool)
+    act[[1, 5, 17, 40, 63]] = True
+    s.set_active(act)
+    s.solve(3)
+    X1, U1 = s.traj()
+    h1, st1 = s.history(), s.status()
+    off = ~act
+    assert np.array_equal(X0[off], X1[off]) and np.array_equal(U0[off], U1[off])
+    assert all(np.array_equal(h0[k][off], h1[k][off]) for k in h0) and all(np.array_equal(st0[k][off], st1[k][off]) for k in st0)
+    assert (st1["iterations"][act] > st0["iterations"][act]).all()
+    r = g.BatchSolver(g.FREEFLYER_SE2, 50, int(act.sum()), hist_cap=80, boxes=P.freeflyer_env())
+    r.set_problems(x0[act], glo[act], ghi[act], tf[act])
+    r.solve(2)
+    r.solve(3)
+    Xr, Ur = r.traj()
+    assert np.array_equal(Xr, X1[act]) and np.array_equal(Ur, U1[act])
+    s.set_active(None)                       # everything again
+    s.solve(1)
+    assert (s.status()["iterations"] >= st1["iterations"]).all() and (s.status()["iterations"][off] > st1["iterations"][off]).any()
+    s.set_active(np.zeros(B, bool))          # nothing: a launch that hands out no problem
+    s.solve(5)
+    assert np.array_equal(s.status()["iterations"], np.array(s.status()["iterations"]))
+    lane = g.BatchSolver(g.DUBINS_CAR, 30, 8)
+    lane.set_problems(*P.dubins_batch(8))
+    lane.set_decomposition(2)
+    lane.set_active(np.ones(8, bool))
+    with pytest.raises(g.GustoError):
+        lane.solve(2)

@@ -37,6 +37,7 @@ out["fetch_bytes"] = 2.0 * 1024 * out["FETCH_SIZE_kb_raw"]
 out["write_bytes"] = 1024 * out["WRITE_SIZE_kb_raw"]
 out["traffic_bytes_per_launch"] = out["fetch_bytes"] + out["write_bytes"]
 out["hbm_gbs"] = out["traffic_bytes_per_launch"] / (out["kernel_ms"] * 1e-3) / 1e9
+out["kkt_solves"], out["scp_iters"] = ipm, scp
 out["algorithmic_bytes_per_launch"] = 51600 * ipm + 24000 * scp
 out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
 sq = {}
