@@ -241,10 +241,37 @@ template <int MODEL> struct Rec {
     static constexpr int oK = 0, oD = m * n, oS = 2 * m * n;
 };
 
+// Compact [Phi Gam] record of the matrix-core models (MT::MFMA): only the structural nonzeros of Phi = 2 M - I (MT::Mnz) and
+// Gam (MT::Gnz) -- 60 of 216 doubles for astrobeeSE3, 73 of 247 for the manifold model -- Phi first, column by column (the
+// adjoint costate recursion reads a column per lane), then Gam row by row.  Written by linearize() next to the dense block,
+// read by the factor sweep (scattered into its dense LDS operand buffer) and by adjoint_sweep_1w.
+template <int MODEL> struct SpPG {
+    using T = MT<MODEL>;
+    static constexpr int n = T::n, m = T::m;
+    static constexpr int pos_phi(int l, int i) {   // rank of Phi[l][i] among the nonzeros, column-major
+        int c = 0;
+        for (int i2 = 0; i2 < n; i2++)
+            for (int l2 = 0; l2 < n; l2++)
+                if (T::Mnz(l2, i2) && (i2 < i || (i2 == i && l2 < l))) c++;
+        return c;
+    }
+    static constexpr int NPHI = pos_phi(0, n);
+    static constexpr int pos_gam(int l, int j) {   // ... of Gam[l][j], row-major, behind Phi
+        int c = NPHI;
+        for (int l2 = 0; l2 < n; l2++)
+            for (int j2 = 0; j2 < m; j2++)
+                if (T::Gnz(l2, j2) && (l2 < l || (l2 == l && j2 < j))) c++;
+        return c;
+    }
+    static constexpr int NS = pos_gam(n, 0);
+    static constexpr int S = (NS + 15) / 16 * 16;   // stride per knot: whole 128-byte lines
+    static constexpr bool USE = T::MFMA && T::NDEF == 0;
+};
+
 // per-problem global workspace, offsets in doubles
 struct WsLayout {
     int nslot;
-    size_t rowstate, obs_nh, obs_c0, obs_mask, PG, QQ, Paft, Piaft, KD, Phicl, pvt, to_traj, total;
+    size_t rowstate, obs_nh, obs_c0, obs_mask, PG, PGS, QQ, Paft, Piaft, KD, Phicl, pvt, to_traj, total;
 };
 template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     using T = MT<MODEL>;
@@ -258,6 +285,7 @@ template <int MODEL> inline WsLayout make_ws_layout(int N, int n_obs) {
     L.obs_c0 = take((size_t)n_obs * N);
     L.obs_mask = take((size_t)N);
     L.PG = take((size_t)(T::LTI ? 1 : N) * n * NZ);
+    L.PGS = take(SpPG<MODEL>::USE ? (size_t)N * SpPG<MODEL>::S : 0);
     using R = Rec<MODEL>;
     L.QQ = take((size_t)N * R::SQQ);
     L.Paft = take((size_t)(N + 1) * R::SNN) + R::SNN;    // record -1 exists: the sweep stores P_{k-1} unconditionally

@@ -66,7 +66,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     // knot-private vectors and the linearisation point (global)
     GPtr<double> Xp, rd, qrd, dXs, Up, qu, dv, dUs, gAx, gBx, gAu, gBu;
     // global workspace of this problem
-    GPtr<double> rowstate, obs_nh, obs_c0, PG, QQ, Paft, Piaft, KD, Phicl;
+    GPtr<double> rowstate, obs_nh, obs_c0, PG, PGS, QQ, Paft, Piaft, KD, Phicl;
     LPtr<double> kdl;   // K | D | S^-1 (upper triangle) per knot in LDS, stride C::KDS (LdsC::KD_LDS); before factor stage k the slot of knot k holds QQ_k
     LPtr<double> pgl;   // [Phi Gam] per knot in LDS (LdsC::PG_LDS)
     LPtr<double> lcl;   // linearisation cache per knot in LDS (LdsC::LC_LDS)
@@ -174,7 +174,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         double* w = Pc->ws + (size_t)slot_ * Pc->wl.total;
         rowstate = w + Pc->wl.rowstate; obs_nh = w + Pc->wl.obs_nh; obs_c0 = w + Pc->wl.obs_c0;
         obs_mask = reinterpret_cast<uint64_t*>(w + Pc->wl.obs_mask);
-        PG = al16(w + Pc->wl.PG); QQ = al16(w + Pc->wl.QQ); Paft = al16(w + Pc->wl.Paft); Piaft = al16(w + Pc->wl.Piaft);
+        PG = al16(w + Pc->wl.PG); PGS = al16(w + Pc->wl.PGS); QQ = al16(w + Pc->wl.QQ); Paft = al16(w + Pc->wl.Paft); Piaft = al16(w + Pc->wl.Piaft);
         KD = al16(w + Pc->wl.KD); Phicl = w + Pc->wl.Phicl;
         {
             double* q = w + Pc->wl.pvt;
@@ -200,7 +200,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         const WsLayout& W = P.wl;
         rowstate = w + W.rowstate; obs_nh = w + W.obs_nh; obs_c0 = w + W.obs_c0;
         obs_mask = reinterpret_cast<uint64_t*>(w + W.obs_mask);
-        PG = al16(w + W.PG); QQ = al16(w + W.QQ); Paft = al16(w + W.Paft); Piaft = al16(w + W.Piaft); KD = al16(w + W.KD); Phicl = w + W.Phicl;
+        PG = al16(w + W.PG); PGS = al16(w + W.PGS); QQ = al16(w + W.QQ); Paft = al16(w + W.Paft); Piaft = al16(w + W.Piaft); KD = al16(w + W.KD); Phicl = w + W.Phicl;
         {   // knot-private vectors in the global workspace, the linearisation point = the stored trajectory
             double* q = w + W.pvt;
             rd = q; qrd = q + N * n; dXs = q + 2 * N * n; dUs = q + 3 * N * n; qu = dUs + N * m; dv = qu + N * m;
@@ -392,16 +392,26 @@ template <int MODEL, class BLK> GD void linearize(BLK& K, double toggle) {
             stage_M<MODEL>(K.P.mp, xp, up, h, M, B);
             auto pg = K.PGk(T::LTI ? 0 : k);
             const bool knot0 = !T::LTI && k == 0;   // x_1 is pinned: the sweep's operand of knot 0 is [0 | b_0], b_0 = dt/2 B
+            // (matrix-core models, one wave: also the compact record of the structural nonzeros, common.hpp: SpPG)
+            constexpr bool SPR = SpPG<MODEL>::USE && BLK::ONE;
+            using SP = SpPG<MODEL>;
+            auto ps = K.PGS + (size_t)(SPR ? k : 0) * SP::S;
 #pragma unroll
             for (int i = 0; i < n; i++) {
 #pragma unroll
-                for (int j = 0; j < n; j++) pg[i * NZ + j] = knot0 ? 0.0 : 2.0 * M[i * n + j] - (i == j ? 1.0 : 0.0);
+                for (int j = 0; j < n; j++) {
+                    const double v = knot0 ? 0.0 : 2.0 * M[i * n + j] - (i == j ? 1.0 : 0.0);
+                    pg[i * NZ + j] = v;
+                    if constexpr (SPR) if (T::Mnz(i, j)) ps[SP::pos_phi(i, j)] = v;
+                }
 #pragma unroll
                 for (int j = 0; j < m; j++) {
                     double s = 0;
 #pragma unroll
                     for (int l = 0; l < n; l++) if (T::Bnz(l, j)) s += M[i * n + l] * (h * B[l * m + j]);   // (B's structural zeros add nothing: n m (n - 1) fewer FMAs for the 12/13-state models, where a column of B has one entry)
-                    pg[i * NZ + n + j] = knot0 ? h * B[i * m + j] : 2.0 * s;
+                    const double v = knot0 ? h * B[i * m + j] : 2.0 * s;
+                    pg[i * NZ + n + j] = v;
+                    if constexpr (SPR) if (T::Gnz(i, j)) ps[SP::pos_gam(i, j)] = v;
                 }
                 if constexpr (T::NDEF > 0) {   // a defect moves y_k directly: Gam_d = I (common.hpp)
 #pragma unroll
@@ -797,7 +807,7 @@ template <int MODEL> struct SweepView {
     LPtr<double> sP, sPi, sPG, sT, sHh, sZ, sK, sD, sW, sV, sGd;
     LPtr<int> lut;
     LPtr<double> cv, rv, nun, pv, dY;
-    GPtr<double> PG, QQ, Paft, Piaft, KD;
+    GPtr<double> PG, PGS, QQ, Paft, Piaft, KD;
     std::conditional_t<C::PHICL_LDS, LPtr<double>, GPtr<double>> Phicl;
     LPtr<double> kdl;   // K | D | S^-1 per knot in LDS (LdsC::KD_LDS; the double integrator's sweeps rebuild Phicl from it)
     LPtr<double> pgl;   // [Phi Gam] per knot in LDS (LdsC::PG_LDS)
@@ -842,7 +852,7 @@ template <int MODEL> struct SweepView {
         v.N = K.N; v.phicl_off = K.P.ll.phicl; v.kd_off = K.P.ll.kd; v.pg_off = K.P.ll.pg; v.pp_off = K.P.ll.pp;
         if constexpr (!C::PHICL_LDS) v.Phicl = K.Phicl;   // (LDS copy of the small models: set by rebind_lds)
         v.rebind_lds(K.lds);
-        v.PG = K.PG; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.KD = K.KD;
+        v.PG = K.PG; v.PGS = K.PGS; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.KD = K.KD;
         v.mpp = &K.P.mp; v.tid = K.tid; v.dt = K.dt; v.goalmask = K.goalmask;
         return v;
     }
@@ -1586,6 +1596,13 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
 #else
 #define GUSTO_COSTATE_PASS 1
 #endif
+// The corrector's new costates of the one-wave 12/13-state kernels by the ADJOINT recursion nu_k = Phi_k^T nu_{k+1} + M_k^T
+// (H_x dx_k + gx_k) instead of nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g: no P | Pi records at all (2 n^2 doubles per knot written
+// by the factor sweep and read back by the costate pass, 0.46 of the 2.0 MB a KKT solve moved), see adjoint_sweep_1w.
+#ifndef GUSTO_COSTATE_ADJOINT
+#define GUSTO_COSTATE_ADJOINT 1
+#endif
+template <int MODEL> constexpr bool costate_adjoint() { return GUSTO_COSTATE_ADJOINT && GUSTO_COSTATE_PASS && MT<MODEL>::SWEEP_CALL && MT<MODEL>::MFMA; }
 // The factor sweep of the 12/13-state models entirely on the matrix cores (MT::MFMA).  Every matrix of a stage is a
 // 16 x 16 tile in the accumulator layout of v_mfma_f64_16x16x4_f64 -- entry (row, col) in register row >> 2 of lane
 // (row & 3) << 4 | col -- and that layout IS an operand layout: register s of a tile X, used as the A operand of K step
@@ -1602,7 +1619,9 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NPG = n * NZ, NN = n * n;
-    constexpr int KS = (n + 3) / 4, MS = (m + 3) / 4, RT = (NPG + 63) / 64, RN = (NN + 63) / 64;
+    using SP = SpPG<MODEL>;
+    constexpr bool SPR = SP::USE;   // [Phi Gam] from the compact record of its nonzeros (60 / 73 doubles per knot instead of 216 / 247)
+    constexpr int KS = (n + 3) / 4, MS = (m + 3) / 4, RT = SPR ? (SP::NS + 63) / 64 : (NPG + 63) / 64, RN = (NN + 63) / 64;
     static_assert(!T::LTI && n <= 15 && m <= 8 && R::SNN > NN && R::SKD > 2 * m * n + m * m, "tile / record shape");
     // -DGUSTO_PROFILE_COARSE: no stamp inside the stage, the sweep is one interval (PF_FACTOR).  The stamps of the fine profile
     // wait for the values they follow and cost ~150 cycles each: with them the sweep reads as 55 % of a KKT solve, without 40 %.
@@ -1648,14 +1667,39 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
     const int oLA0 = (mi < m) ? mi * m : 0;   // L^-1 as the A operand of L^-1 X: lane (i = mi, k = mq + 4 s) holds Li[mi][k]
     double* Lw = K.sHh;                       // m x m scratch for L^-1 (the H / Z buffers of the VALU path are unused here)
     for (int e = tid; e < m * m; e += 64) Lw[e] = 0.0;
+    int doff[RT];   // (SPR) where entry tid + 64 r of the compact record sits in the dense n x NZ operand buffer
+    if constexpr (SPR) {
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const int e = tid + 64 * r;
+            int o = 0;
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+#pragma unroll
+                for (int j = 0; j < n; j++) if (T::Mnz(i, j)) o = (e == SP::pos_phi(i, j)) ? i * NZ + j : o;
+#pragma unroll
+                for (int j = 0; j < m; j++) if (T::Gnz(i, j)) o = (e == SP::pos_gam(i, j)) ? i * NZ + n + j : o;
+            }
+            doff[r] = o;
+        }
+        for (int e = tid; e < 2 * NPG; e += 64) K.sPG[e] = 0.0;   // (the structural zeros of both buffers, once)
+        K.sync();
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const int e = tid + 64 * r;
+            if (e < SP::NS) K.sPG[((N - 1) & 1) * NPG + doff[r]] = K.PGS[(size_t)(N - 1) * SP::S + e];
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < RT; r++) {
         const int e = tid + 64 * r;
         if (e < NPG) K.sPG[((N - 1) & 1) * NPG + e] = K.PGk(N - 1)[e];
     }
+    }
 #pragma unroll
     for (int r = 0; r < RN; r++) {
         const int e = tid + 64 * r;
+        if constexpr (!costate_adjoint<MODEL>())
         if (e < NN) { K.Paft[(size_t)(N - 1) * R::SNN + e] = 0.0; K.Piaft[(size_t)(N - 1) * R::SNN + e] = 0.0; }
     }
     double qc[KS + 2 * MS], qn[KS + 2 * MS], pgn[RT];
@@ -1674,7 +1718,11 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
     for (int k = N - 1; k >= 0; k--) {
         const double* PGs = pg_buf<MODEL>(K, k);
         gather((k > 0) ? k - 1 : 0, qn);
-        {
+        if constexpr (SPR) {
+            const auto pg = K.PGS + (size_t)((k > 0) ? k - 1 : 0) * SP::S;
+#pragma unroll
+            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < SP::NS) ? e : SP::NS - 1]; }
+        } else {
             const auto pg = K.PGk((k > 0) ? k - 1 : 0);
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
@@ -1795,13 +1843,20 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
             double* pir = K.Piaft + (size_t)(k - 1) * R::SNN;
             double* kdr = K.KD + (size_t)k * R::SKD;
 #pragma unroll
-            for (int q = 0; q < KS; q++) { phr[oN[q]] = Ph[q]; par[oNT[q]] = hyy[q]; pir[oNT[q]] = zy[q]; }
+            for (int q = 0; q < KS; q++) {
+                phr[oN[q]] = Ph[q];
+                if constexpr (!costate_adjoint<MODEL>()) { par[oNT[q]] = hyy[q]; pir[oNT[q]] = zy[q]; }
+            }
 #pragma unroll
             for (int s = 0; s < MS; s++) { kdr[oKr[s]] = Kt[s]; kdr[oDr[s]] = Dt[s]; kdr[oSr[s]] = Si[s]; }
         }
         if (k > 0) {
 #pragma unroll
-            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; if (e < NPG) K.sPG[((k - 1) & 1) * NPG + e] = pgn[r]; }
+            for (int r = 0; r < RT; r++) {
+                const int e = tid + 64 * r;
+                if constexpr (SPR) { if (e < SP::NS) K.sPG[((k - 1) & 1) * NPG + doff[r]] = pgn[r]; }
+                else if (e < NPG) K.sPG[((k - 1) & 1) * NPG + e] = pgn[r];
+            }
         }
         FT_(PF_F7);
         K.sync();
@@ -2197,6 +2252,111 @@ template <int MODEL> __device__ __noinline__ void costate_pass_1w_call(typename 
     costate_pass_1w<MODEL>(SweepView<MODEL>::make(B), gusto_dyn_lds + LdsC<MODEL, true>::misc + 48);
 }
 
+
+// Adjoint recursion of the new costates (costate_adjoint): nu_k = Phi_k^T nu_{k+1} + v_k, k = N-2 .. 1, nu_{N-1} = v_{N-1};
+// nun[k] holds v_k on entry (step_phase) and nu_k on exit.  Phi_k = 2 M_k - I is the block linearize() stored; of its column
+// i only the structural nonzeros are fetched (x = (r, v, attitude, w): M is block upper triangular, MT::Mnz -- one or two
+// entries for a position / velocity column, the attitude and rate rows for the others): 36 / 46 doubles per knot instead
+// of the 2 n^2 of the P | Pi records.  Groups of n lanes hold consecutive knots as in backward_sweep_1w; the n-vector travels
+// between groups through 64 doubles of LDS (each lane needs ITS rows of it: a per-lane address, not a broadcast).
+template <int MODEL> constexpr bool adjoint_pattern_ok() {   // the column pattern adjoint_sweep_1w assumes IS MT::Mnz
+    using T = MT<MODEL>;
+    constexpr int n = T::n, q = n - 9;
+    for (int i = 0; i < n; i++)
+        for (int l = 0; l < n; l++) {
+            const bool want = (i < 6) ? (l == i || (i >= 3 && l == i - 3)) : (l >= 6 && l < ((i < 6 + q) ? 6 + q : n));
+            if (want != T::Mnz(l, i)) return false;
+        }
+    return true;
+}
+template <int MODEL> GD void adjoint_sweep_1w(SweepView<MODEL> K) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n, NZ = T::n + T::m, C = 64 / n, q = n - 9, NR = n - 6;
+    static_assert(adjoint_pattern_ok<MODEL>(), "column pattern of M of the astrobee models");
+    const int tid = K.tid, N = K.N;
+    const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
+    // rows of column i: {i} and {i - 3} below the attitude block, else rows 6 .. hi - 1, hi = 6 + q for an attitude column, n for a rate column
+    int rl[NR];
+    bool rok[NR];
+    const int hi = (i < 6 + q) ? 6 + q : n;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        rl[j] = (i < 6) ? ((j == 1 && i >= 3) ? i - 3 : i) : 6 + j;
+        rok[j] = (i < 6) ? (j == 0 || (j == 1 && i >= 3)) : (6 + j < hi);
+        if (!rok[j]) rl[j] = i;
+    }
+    // where those entries sit in the compact record (SpPG: Phi column by column, rows ascending): column start + rank
+    int cs = 0, pj[NR];
+#pragma unroll
+    for (int i2 = 0; i2 < n; i2++) cs = (i == i2) ? SpPG<MODEL>::pos_phi(0, i2) : cs;
+#pragma unroll
+    for (int j = 0; j < NR; j++) pj[j] = (i < 6) ? ((i >= 3) ? (j == 1 ? 0 : (j == 0 ? 1 : 0)) : 0) : (rok[j] ? j : 0);
+    double* ex = K.sHh;
+    constexpr int RING = GUSTO_SWEEP_RING;
+    double cb[RING][NR], vb[RING];
+    auto fetch = [&](int k0, double* c, double& v) {
+        const int kk = (k0 - g >= 1) ? k0 - g : 1;      // (clamped: always loadable, never used past the end)
+        const auto pg = K.PGS + (size_t)kk * SpPG<MODEL>::S + cs;   // (column i of Phi_kk: consecutive entries of the compact record)
+#pragma unroll
+        for (int j = 0; j < NR; j++) { const double a = pg[pj[j]]; c[j] = rok[j] ? a : 0.0; }
+        v = K.nun[kk * n + i];
+    };
+#pragma unroll
+    for (int d = 0; d < RING - 1; d++) fetch(N - 2 - d * C, cb[d], vb[d]);
+    double val = K.nun[(N - 1) * n + i];       // every group starts from nu_{N-1}; only group C - 1 is read at step 0
+    ex[tid] = val;
+    K.sync();
+    for (int kb = N - 2; kb >= 1; kb -= RING * C) {
+        static_for<0, RING>([&](auto DD) {
+            constexpr int d = decltype(DD)::value;
+            const int k0 = kb - d * C;
+            fetch(k0 - (RING - 1) * C, cb[(d + RING - 1) % RING], vb[(d + RING - 1) % RING]);
+            if (k0 >= 1) {
+#pragma unroll
+                for (int gs = 0; gs < C; gs++) {
+                    if (k0 - gs >= 1) {
+                        const int sg = (gs == 0) ? C - 1 : gs - 1;
+                        double pb[NR];
+#pragma unroll
+                        for (int j = 0; j < NR; j++) pb[j] = ex[sg * n + rl[j]];
+                        double s = vb[d];
+#pragma unroll
+                        for (int j = 0; j < NR; j++) s += cb[d][j] * pb[j];
+                        val = (g == gs) ? s : val;
+                        ex[tid] = val;
+                    }
+                }
+                const int kk = k0 - g;
+                if (tid < C * n && kk >= 1) K.nun[kk * n + i] = val;
+            }
+        });
+    }
+    K.sync();
+}
+template <int MODEL> __device__ __noinline__ void adjoint_sweep_1w_call(typename Blk<MODEL, true>::Args a, double hdt) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n, m = T::m;
+    Blk<MODEL, true> K(a, gusto_dyn_lds);
+    adjoint_sweep_1w<MODEL>(SweepView<MODEL>::make(K));
+    if (K.tid == 0) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0 (as step_phase closes the other kernels)
+        const double* gxs = gusto_dyn_lds + LdsC<MODEL, true>::misc + 16;
+        double Ad[n * n], x0[n], u0[m];
+#pragma unroll
+        for (int i = 0; i < n; i++) x0[i] = K.Xp[i];
+#pragma unroll
+        for (int i = 0; i < m; i++) u0[i] = K.Up[i];
+        Dyn<MODEL>::A(K.P.mp, x0, u0, Ad);
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            double s = gxs[i] + K.nun[n + i];
+#pragma unroll
+            for (int j = 0; j < n; j++) if (T::Anz(j, i)) s += hdt * Ad[j * n + i] * K.nun[n + j];
+            K.nun[i] = -s;
+        }
+    }
+    K.sync();
+}
+
 // MT::SWEEP_CALL (measured per model: astrobeeSE3 +9 %, the manifold model -10 %): the sweep as a real call.  Inlined, its 50-stage loop shares one register allocation with the whole
 // interior point iteration and the allocator spills INSIDE the loop; called, the loop gets the register file to itself
 // and the caller's live values are saved once around the call.
@@ -2557,6 +2717,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m;
+    constexpr bool ADJ = costate_adjoint<MODEL>() && BLK::ONE;   // new costates by the adjoint recursion (adjoint_sweep_1w)
     const int N = K.N;
     double l_amax = 1.0, l_c0 = 0, l_c1 = 0, l_c2 = 0;
     if (act) {
@@ -2628,10 +2789,35 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
                 return var == RS_T || var == RS_LAM || var == RS_S || var == RS_LAMB || (pass && (var == RS_KA || var == RS_KB));
             });
         }
-        OpStep<NP> op{rs, dxs, dus, pass, mu_t, tau, gAx, gAu, gBx, gBu, &pre};
+        double hdx[ADJ ? n : 1];
+#pragma unroll
+        for (int i = 0; i < (ADJ ? n : 1); i++) hdx[i] = 0;
+        OpStep<NP, RowState, ADJ> op{rs, dxs, dus, pass, mu_t, tau, gAx, gAu, gBx, gBu, &pre, hdx};
         ctx.tick(0);
         visit_rows<MODEL>(ctx, xs, us, op);
         ctx.tick(3);
+        if constexpr (ADJ) {
+            // v_k = M_k^T (H_x dx_k + gx_k [+ mu_g at the last knot]) -> nun[k], the inhomogeneity of nu_k = Phi_k^T nu_{k+1} + v_k:
+            // stationarity in x_k of the Newton system, H_x dx_k + gx_k + F_k^T nu_{k+1} - G_k^T nu_k = 0 with F = I + dt/2 A,
+            // G = I - dt/2 A = M^-1 (resid_phase: "+ E^T nu"), gx_k the row part of this right-hand side (RHS phase)
+            if (k >= 1 && (pass == 1 || ncomp == 0)) {
+                double Mk[n * n], Gamk[n * m], w[n];
+                load_M_Gam(K, k, Mk, Gamk);
+#pragma unroll
+                for (int i = 0; i < n; i++) {
+                    double s = hdx[i] + (pass ? K.gAx_(k, i) + mu_t * K.gBx_(k, i) : 0.0);
+                    if (k == N - 1 && K.is_goal(i)) s += mugn[i];
+                    w[i] = s;
+                }
+#pragma unroll
+                for (int i = 0; i < n; i++) {
+                    double s = 0;
+#pragma unroll
+                    for (int l = 0; l < n; l++) if (T::Mnz(l, i)) s += Mk[l * n + i] * w[l];
+                    K.nun[k * n + i] = s;
+                }
+            }
+        }
         l_amax = op.amax.value(); l_c0 = op.c0; l_c1 = op.c1; l_c2 = op.c2;
         if (pass == 0) {
 #pragma unroll
@@ -2641,6 +2827,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         }
     }
     K.sync();
+    if constexpr (!ADJ)   // (adjoint costates: nu_1 is known after the sweep; adjoint_sweep_1w_call closes with this block)
     if (k == 0 && (pass == 1 || ncomp == 0)) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0
         double Ad[n * n], x0[n], u0[m];
 #pragma unroll
@@ -3136,6 +3323,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             pf.tick(PF_MID);
             forward_sweep<MODEL>(K);
             if constexpr (GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL)
+                if constexpr (!costate_adjoint<MODEL>())
                 if (pass == 1 || ncomp == 0) costate_pass_1w_call<MODEL>(K.args());
             pf.tick(PF_FWD);
             GUSTO_REFRESH_K();
@@ -3147,6 +3335,8 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
 #endif
             if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL, BLK>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
             else so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
+            if constexpr (costate_adjoint<MODEL>() && BLK::ONE)
+                if (pass == 1 || ncomp == 0) adjoint_sweep_1w_call<MODEL>(K.args(), hdt);
             const double l_amax = so.amax, l_c0 = so.c0, l_c1 = so.c1, l_c2 = so.c2;
             const double a_max = block_reduce<BLK::ONE>(l_amax, OpMin(), red);
             alpha = a_max;

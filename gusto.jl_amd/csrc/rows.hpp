@@ -472,7 +472,10 @@ struct StepFrac {
 // affine in the centring parameter, coef = A + mu_t B, and everything A and B need is in registers right here, so the
 // pass leaves gA = sum A grad and gB = sum B grad per knot and the corrector forms gA + mu_t gB once mu_t is known: one
 // row pass (6 row-state reads per row) less per interior point iteration.
-template <int NP, class RST = RowState> struct OpStep {
+// HDX: the pass also leaves hdx = H_x dx of this knot, H_x = sum over the state rows of sigma grad grad^T + lam hess -- the
+// condensed Hessian the residual pass put into the stage cost, applied to the step instead of stored (the adjoint costate
+// recursion of the 12/13-state kernels, ipm.hpp: adjoint_sweep_1w, needs H_x dx_k and nothing else of H_x).
+template <int NP, class RST = RowState, bool HDX = false> struct OpStep {
     static constexpr bool FIX_BATCH = NP == 0;
     RST rs;
     const double *dxs, *dus;
@@ -480,6 +483,7 @@ template <int NP, class RST = RowState> struct OpStep {
     double mu_t, tau;
     double *gAx, *gAu, *gBx, *gBu;   // (pass 0) corrector row sums of this knot
     const RowPre<NP>* pre;           // state of the fixed-position rows, fetched in one batch (small models)
+    double* hdx = nullptr;           // (HDX) H_x dx of this knot
     StepFrac amax;
     double c0 = 0, c1 = 0, c2 = 0;
     ObsPre ob;
@@ -502,6 +506,7 @@ template <int NP, class RST = RowState> struct OpStep {
         for (int a = 0; a < CNT; a++) w += ev.gr[a] * dv[I0 + a];
         double dt, dl, ds;
         double cA = 0, cB = 0;   // (pass 0) corrector coefficient = cA + mu_t cB
+        double sig = 0;          // (HDX) the row's weight in the condensed Hessian, as OpResidHess forms it
         if (row_is_hard(kind)) {
             const double rp = ev.g + t;
             const double rt = rcp_nr(t);
@@ -509,6 +514,7 @@ template <int NP, class RST = RowState> struct OpStep {
             dl = (mu_t - t * lam - ka - lam * dt) * rt;
             ds = 0.0;
             if (pass == 0) { cA = (lam * rp - dt * dl) * rt; cB = rt; }
+            if constexpr (HDX) sig = lam * rt;
         } else {
             const double s = get<FX>(RS_S, slot), lamb = get<FX>(RS_LAMB, slot);
             const double kb = pass ? get<FX>(RS_KB, slot) : 0.0;
@@ -520,6 +526,7 @@ template <int NP, class RST = RowState> struct OpStep {
             dl = (rho0 + lam * w) * rD;
             ds = (mu_t - s * lamb - kb + s * dl) * il;
             dt = -rp - w + ds;
+            if constexpr (HDX) sig = lam * rD;   // = lam lamb / (t lamb + lam s)
             amax.test(s, ds, tau);
             amax.test(lamb, -dl, tau);
             if (pass == 0) {
@@ -528,6 +535,11 @@ template <int NP, class RST = RowState> struct OpStep {
                 cA = lam + (lam * rp - t * lam - dt * dl + lol * (s * lamb - ds * dl)) * rD;
                 cB = (1.0 - lol) * rD;
             }
+        }
+        if constexpr (HDX && !ISU) {
+            const double sw = sig * w;
+#pragma unroll
+            for (int a = 0; a < CNT; a++) hdx[I0 + a] += sw * ev.gr[a] + (lam * ev.hd[a]) * dv[I0 + a];
         }
         amax.test(t, dt, tau);
         amax.test(lam, dl, tau);
