@@ -508,6 +508,51 @@ template <int NV, class Op> GD void wave_reduce_n(double* v, Op op) {
         v[j] = op(op(r0, r1), op(r2, r3));
     }
 }
+// lane i <- lane i + N of its row of 16 lanes, 0 past the row's end (DPP row_shl, bound_ctrl): the step of a suffix scan
+template <int N> GD double row_shl0_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = (int)(u & 0xffffffffu), hi = (int)(u >> 32);
+    const unsigned rl = (unsigned)__builtin_amdgcn_update_dpp(0, lo, 0x100 + N, 0xf, 0xf, true);
+    const unsigned rh = (unsigned)__builtin_amdgcn_update_dpp(0, hi, 0x100 + N, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)rh << 32) | rl);
+}
+// NV inclusive SUFFIX sums over the 64 lanes at once, v[j] of lane i <- sum of v[j] over the lanes >= i: four DPP steps inside each
+// row of 16 lanes (interleaved across the values, see wave_reduce_n), then the totals of the rows behind through v_readlane
+template <int NV> GD void wave_suffix_sum_n(double* v) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) v[j] += row_shl0_f64<1>(v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; j++) v[j] += row_shl0_f64<2>(v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; j++) v[j] += row_shl0_f64<4>(v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; j++) v[j] += row_shl0_f64<8>(v[j]);
+    const int row = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const double t1 = readlane_f64(v[j], 16), t2 = readlane_f64(v[j], 32), t3 = readlane_f64(v[j], 48);
+        const double behind = (row == 0) ? (t1 + t2) + t3 : ((row == 1) ? t2 + t3 : ((row == 2) ? t3 : 0.0));
+        v[j] += behind;
+    }
+}
+// the value of the next lane (lane 63: 0): inside a row by DPP, across a row boundary through v_readlane
+GD double wave_next_f64(double v) {
+    const double in_row = row_shl0_f64<1>(v);
+    const double t1 = readlane_f64(v, 16), t2 = readlane_f64(v, 32), t3 = readlane_f64(v, 48);
+    const int l = threadIdx.x & 63;
+    return (l == 15) ? t1 : ((l == 31) ? t2 : ((l == 47) ? t3 : in_row));
+}
+// the value of the previous lane (lane 0: 0)
+GD double wave_prev_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = (int)(u & 0xffffffffu), hi = (int)(u >> 32);
+    const unsigned rl = (unsigned)__builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true);   // row_shr:1
+    const unsigned rh = (unsigned)__builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true);
+    const double in_row = __builtin_bit_cast(double, ((unsigned long long)rh << 32) | rl);
+    const double t0 = readlane_f64(v, 15), t1 = readlane_f64(v, 31), t2 = readlane_f64(v, 47);
+    const int l = threadIdx.x & 63;
+    return (l == 16) ? t0 : ((l == 32) ? t1 : ((l == 48) ? t2 : in_row));
+}
 // NaN-propagating max: used for residuals so that a NaN iterate is detected
 GD double nanmax(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
 struct OpNanMax { GD double operator()(double a, double b) const { return nanmax(a, b); } };

@@ -28,6 +28,9 @@ namespace gusto {
 // the dynamic LDS of the workgroup (the same memory as the `extern __shared__` array of scp_kernel)
 extern __shared__ __attribute__((aligned(16))) double gusto_dyn_lds[];
 
+template <int MODEL> constexpr bool costate_adjoint();
+template <int MODEL> constexpr bool costate_scan();
+
 struct IpmOut {
     int status, iters;
     double obj, res_p, res_d, mu;
@@ -1409,7 +1412,7 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
     // ---- start: P = Pi = Gd = 0 after the last knot, Z = 0 (the tail of "stage N" then leaves Pi_{N-1} = 0) ----
     L[wP] = 0.0; L[wPi] = 0.0; L[wZ] = 0.0;
     double gdR = 0.0, zR = 0.0;   // this lane's entry of Gd (accumulated over the sweep) and of Z (the Pi' term of the next tail)
-    if (tid < R::SNN) K.Paft[(size_t)(N - 1) * R::SNN + tid] = 0.0;
+    if constexpr (!costate_scan<MODEL>()) if (tid < R::SNN) K.Paft[(size_t)(N - 1) * R::SNN + tid] = 0.0;
     double qq = K.kdl[(N - 1) * C::KDS + (tid < NQ ? tid : 0)];
     double LiP[m * m], wiP[m];   // L^-1 and this lane's column i of W of the stage before (tail operands)
 #pragma unroll
@@ -1440,7 +1443,7 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
 #pragma unroll
         for (int l = 0; l < m; l++) { pin -= wiP[l] * vj[l]; gd += vi[l] * vj[l]; }
         L[wPi] = pin; gdR = gd;
-        K.Paft[(size_t)(kt - 1) * R::SNN + eq] = pin;
+        if constexpr (!costate_scan<MODEL>()) K.Paft[(size_t)(kt - 1) * R::SNN + eq] = pin;
 #pragma unroll
         for (int a = 0; a < m; a++) L[wKD + kt * sKD + (m + a) * n] = dj[a];
     };
@@ -1545,7 +1548,7 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
 #pragma unroll
         for (int l = 0; l < m; l++) pn -= wi[l] * wj[l];
         L[wP] = pn;
-        K.Paft[(size_t)(k - 1) * R::SNN + ep] = pn;     // (record -1 exists for k == 0)
+        if constexpr (!costate_scan<MODEL>()) K.Paft[(size_t)(k - 1) * R::SNN + ep] = pn;     // (record -1 exists for k == 0)
 #pragma unroll
         for (int a = 0; a < m; a++) L[wKD + k * sKD + a * n] = kj[a];
         {   // S^-1 = L^-T L^-1, upper triangle (wave-uniform values)
@@ -1603,6 +1606,37 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
 #define GUSTO_COSTATE_ADJOINT 1
 #endif
 template <int MODEL> constexpr bool costate_adjoint() { return GUSTO_COSTATE_ADJOINT && GUSTO_COSTATE_PASS && MT<MODEL>::SWEEP_CALL && MT<MODEL>::MFMA; }
+// Run-time part of the choice.  The recursion multiplies by Phi_k^T = the Cayley transform of dt/2 A_k, and for MRP kinematics
+// (astrobeeSE3: A_pp = d(B(p) w)/dp is not skew) that transform has a pole at dt/2 |A_pp| = 1: on coarse horizons the stage
+// errors of the Riccati solution are amplified into a noise floor of the dual residual above the 1e-8 stopping test (measured,
+// tf = 70: identical interior point iterations to the P | Pi costates for N >= 45, +8 % at N = 40, +60 % and ALMOST statuses at
+// N = 28).  There the kernel keeps the P | Pi records (their stores aim at the records only then).  Quaternion kinematics are
+// skew (orthogonal Cayley transform): the manifold model showed no such effect down to N = 5.
+template <int MODEL> GD bool costate_adjoint_rt(const gusto_model_params& mp, double dt) {
+#ifdef GUSTO_ADJ_ALWAYS   // (A/B builds: what the run-time test costs)
+    return true;
+#else
+    if constexpr (MODEL == GUSTO_ASTROBEE_SE3) return 0.5 * dt * mp.hard_limit_omega <= 0.65;
+    else return true;
+#endif
+}
+// ... and for the double integrator (constant Phi = I + dt [0 I; 0 0]) the same recursion is two SUFFIX SUMS over the knots,
+//   nu_k[a] = sum_{j >= k} v_j[a],   nu_k[n/2 + a] = sum_{j >= k} (v_j[n/2 + a] + dt nu_{j+1}[a]),   a < n/2,
+// i.e. a dozen DPP steps over the lanes of the wave (lane = knot) inside the step phase: no P | Pi record (a third of the
+// memory traffic of a freeflyer KKT solve), no sequential pass at all.
+// OFF by default: it halves the memory traffic of a freeflyer KKT solve (133 -> 64 KB, 2.4 -> 1.2 x the algorithmic bytes) for
+// the same time (29.0 vs 29.4 ms per config-2 batch: the kernel is not bound by its traffic), but these costates are not
+// backward stable the way the P | Pi ones are -- whatever the Riccati solution is off by lands in them instead of in a small
+// stage residual: with the velocity costates taken locally from the u-stationarity (the variant below) every BASELINE-sized case
+// runs the iterations of the P | Pi kernel (343 331 vs 343 323 KKT solves per config-2 batch, omega up to 1e6), while on the
+// coarsest horizon of the edge-case tests (N = 5, dt = 50 s) two of six subproblems no longer reach the 1e-8 test.  A build
+// switch (-DGUSTO_COSTATE_SCAN=1) for the measurements in profiles/r05_costate_scan.txt.
+#ifndef GUSTO_COSTATE_SCAN
+#define GUSTO_COSTATE_SCAN 0
+#endif
+template <int MODEL> constexpr bool costate_scan() {
+    return GUSTO_COSTATE_SCAN && MT<MODEL>::PG2 && MT<MODEL>::LTI && MT<MODEL>::NDEF == 0 && LdsC<MODEL, true>::KD_LDS;
+}
 // The factor sweep of the 12/13-state models entirely on the matrix cores (MT::MFMA).  Every matrix of a stage is a
 // 16 x 16 tile in the accumulator layout of v_mfma_f64_16x16x4_f64 -- entry (row, col) in register row >> 2 of lane
 // (row & 3) << 4 | col -- and that layout IS an operand layout: register s of a tile X, used as the A operand of K step
@@ -1615,7 +1649,9 @@ template <int MODEL> constexpr bool costate_adjoint() { return GUSTO_COSTATE_ADJ
 // Pi_k^T c_k is row 15 of Phi^T Pi: the two matrix-vector products of the stage come with the tiles.  Rows / columns
 // beyond n (m) of a tile are finite don't-cares that never meet a nonzero operand; stores aim them at the padding slot
 // of their record.
-template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail, Prof& pf) {
+// (NOPP: no P | Pi records -- the costates come from the adjoint recursion; a template parameter, chosen at run time by the
+// caller, so that the stage loop holds no branch around its stores)
+template <int MODEL, bool NOPP> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail, Prof& pf) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NPG = n * NZ, NN = n * n;
@@ -1632,6 +1668,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 #endif
     const int tid = K.tid, N = K.N;
     const int mi = tid & 15, mq = tid >> 4;
+    constexpr bool adj_rt = NOPP;
 #if defined(GUSTO_PROFILE) && !defined(GUSTO_PROFILE_COARSE)   // finer stamps of a stage (slots 40..47): the value is made a VGPR operand first, so the stamp waits for it
 #define FX_(id, val) do { asm volatile("" :: "v"(val)); FT_(40 + (id)); } while (0)
 #else
@@ -1699,7 +1736,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 #pragma unroll
     for (int r = 0; r < RN; r++) {
         const int e = tid + 64 * r;
-        if constexpr (!costate_adjoint<MODEL>())
+        if (!adj_rt)
         if (e < NN) { K.Paft[(size_t)(N - 1) * R::SNN + e] = 0.0; K.Piaft[(size_t)(N - 1) * R::SNN + e] = 0.0; }
     }
     double qc[KS + 2 * MS], qn[KS + 2 * MS], pgn[RT];
@@ -1845,7 +1882,7 @@ template <int MODEL> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail,
 #pragma unroll
             for (int q = 0; q < KS; q++) {
                 phr[oN[q]] = Ph[q];
-                if constexpr (!costate_adjoint<MODEL>()) { par[oNT[q]] = hyy[q]; pir[oNT[q]] = zy[q]; }
+                if constexpr (!NOPP) { par[oNT[q]] = hyy[q]; pir[oNT[q]] = zy[q]; }
             }
 #pragma unroll
             for (int s = 0; s < MS; s++) { kdr[oKr[s]] = Kt[s]; kdr[oDr[s]] = Dt[s]; kdr[oSr[s]] = Si[s]; }
@@ -2363,7 +2400,12 @@ template <int MODEL> __device__ __noinline__ void adjoint_sweep_1w_call(typename
 template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(typename Blk<MODEL, true>::Args a, Prof* pf) {
     Blk<MODEL, true> B(a, gusto_dyn_lds);
     SweepView<MODEL> K = SweepView<MODEL>::make(B);
-    if constexpr (MT<MODEL>::MFMA) factor_sweep_mfma<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
+    if constexpr (MT<MODEL>::MFMA) {
+        if constexpr (!costate_adjoint<MODEL>()) factor_sweep_mfma<MODEL, false>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
+        else if constexpr (MODEL != GUSTO_ASTROBEE_SE3) factor_sweep_mfma<MODEL, true>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
+        else if (costate_adjoint_rt<MODEL>(*K.mpp, K.dt)) factor_sweep_mfma<MODEL, true>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
+        else factor_sweep_mfma<MODEL, false>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
+    }
     else factor_sweep_1w<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
 }
 template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof& pf) {
@@ -2371,7 +2413,7 @@ template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof&
 #ifndef GUSTO_SWEEP_INLINE
     else if constexpr (MT<MODEL>::SWEEP_CALL) factor_sweep_1w_call<MODEL>(K.args(), &pf);
 #endif
-    else if constexpr (MT<MODEL>::MFMA) factor_sweep_mfma<MODEL>(SweepView<MODEL>::make(K), fail, pf);
+    else if constexpr (MT<MODEL>::MFMA) factor_sweep_mfma<MODEL, false>(SweepView<MODEL>::make(K), fail, pf);   // (inlined builds, -DGUSTO_SWEEP_INLINE: P | Pi costates)
 #ifndef GUSTO_NO_FACTOR_PIPE
     else if constexpr (MT<MODEL>::PG2 && LdsC<MODEL, true>::KD_LDS) factor_sweep_pg2<MODEL>(SweepView<MODEL>::make(K), fail, pf);
 #endif
@@ -2718,8 +2760,16 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m;
     constexpr bool ADJ = costate_adjoint<MODEL>() && BLK::ONE;   // new costates by the adjoint recursion (adjoint_sweep_1w)
+    const bool adj_rt = ADJ && costate_adjoint_rt<MODEL>(K.P.mp, K.dt);   // ... unless the horizon is too coarse for it (P | Pi records then)
+    constexpr bool SCAN = costate_scan<MODEL>() && BLK::ONE;      // ... by two suffix sums over the lanes (double integrator)
     const int N = K.N;
     double l_amax = 1.0, l_c0 = 0, l_c1 = 0, l_c2 = 0;
+    double vk[SCAN ? n : 1];   // (SCAN) v_k = M^T (H_x dx_k + gx_k [+ mu_g]) of this lane's knot, 0 for knot 0 and the idle lanes
+    double sk[SCAN ? n / 2 : 1];   // (SCAN) s_k = (nu_k + nu_{k+1})[velocity part] from the u-stationarity of the knot
+#pragma unroll
+    for (int i = 0; i < (SCAN ? n : 1); i++) vk[i] = 0;
+#pragma unroll
+    for (int i = 0; i < (SCAN ? n / 2 : 1); i++) sk[i] = 0;
     if (act) {
         double dxs[n], dus[m], dyp[n];
 #pragma unroll
@@ -2754,7 +2804,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
 #pragma unroll
         for (int i = 0; i < n; i++) K.dXs_(k, i) = dxs[i];
         // nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g  (one-wave 12/13-state models: costate_pass_1w has done it)
-        if constexpr (!(GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL))
+        if constexpr (!(GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL) && !SCAN)
         if (k + 1 < N && (pass == 1 || ncomp == 0)) {
 #pragma unroll
             for (int i = 0; i < n; i++) {
@@ -2789,10 +2839,12 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
                 return var == RS_T || var == RS_LAM || var == RS_S || var == RS_LAMB || (pass && (var == RS_KA || var == RS_KB));
             });
         }
-        double hdx[ADJ ? n : 1];
+        double hdx[(ADJ || SCAN) ? n : 1], hdu[SCAN ? m : 1];
 #pragma unroll
-        for (int i = 0; i < (ADJ ? n : 1); i++) hdx[i] = 0;
-        OpStep<NP, RowState, ADJ> op{rs, dxs, dus, pass, mu_t, tau, gAx, gAu, gBx, gBu, &pre, hdx};
+        for (int i = 0; i < ((ADJ || SCAN) ? n : 1); i++) hdx[i] = 0;
+#pragma unroll
+        for (int i = 0; i < (SCAN ? m : 1); i++) hdu[i] = 0;
+        OpStep<NP, RowState, ADJ || SCAN> op{rs, dxs, dus, pass, mu_t, tau, gAx, gAu, gBx, gBu, &pre, hdx, SCAN ? hdu : nullptr};
         ctx.tick(0);
         visit_rows<MODEL>(ctx, xs, us, op);
         ctx.tick(3);
@@ -2800,7 +2852,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
             // v_k = M_k^T (H_x dx_k + gx_k [+ mu_g at the last knot]) -> nun[k], the inhomogeneity of nu_k = Phi_k^T nu_{k+1} + v_k:
             // stationarity in x_k of the Newton system, H_x dx_k + gx_k + F_k^T nu_{k+1} - G_k^T nu_k = 0 with F = I + dt/2 A,
             // G = I - dt/2 A = M^-1 (resid_phase: "+ E^T nu"), gx_k the row part of this right-hand side (RHS phase)
-            if (k >= 1 && (pass == 1 || ncomp == 0)) {
+            if (adj_rt && k >= 1 && (pass == 1 || ncomp == 0)) {
                 double Mk[n * n], Gamk[n * m], w[n];
                 load_M_Gam(K, k, Mk, Gamk);
 #pragma unroll
@@ -2818,6 +2870,38 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
                 }
             }
         }
+        if constexpr (SCAN) {
+            // The double integrator has as many controls as velocity states (B = [0; diag(beta)]), so the u-stationarity of knot k,
+            //   (H_u du_k + gu_k)_a + dt/2 beta_a (nu_{k+1} + nu_k)[h3 + a] = 0,
+            // gives the SUM s_k of two consecutive velocity costates LOCALLY: sk[a] below.  (The adjoint recursion proper,
+            // nu_k = Phi^T nu_{k+1} + v_k, is two nested suffix sums over the knots and amplifies the stage errors of the
+            // Riccati solution by ~N^2 dt / 2: measured +13 % interior point iterations at omega = 1e4.)
+            if (k >= 1 && (pass == 1 || ncomp == 0)) {
+                constexpr int h3 = n / 2;
+                double Mk[n * n], Gamk[n * m], w[n], Bd[n * m];
+                load_M_Gam(K, k, Mk, Gamk);
+                Dyn<MODEL>::B(K.P.mp, Bd);
+                const double wk_ = ctx.kappa * ((k == N - 1) ? 0.5 * K.dt : K.dt);
+#pragma unroll
+                for (int i = 0; i < n; i++) {
+                    double s = hdx[i] + (pass ? K.gAx_(k, i) + mu_t * K.gBx_(k, i) : 0.0);
+                    if (k == N - 1 && K.is_goal(i)) s += mugn[i];
+                    w[i] = s;
+                }
+#pragma unroll
+                for (int i = 0; i < n; i++) {   // v_k = M^T (H_x dx_k + gx_k [+ mu_g])
+                    double s = 0;
+#pragma unroll
+                    for (int l = 0; l < n; l++) if (T::Mnz(l, i)) s += Mk[l * n + i] * w[l];
+                    vk[i] = s;
+                }
+#pragma unroll
+                for (int a = 0; a < h3; a++) {
+                    const double gu = 2 * wk_ * (us[a] + dus[a]) + hdu[a] + (pass ? K.gAu_(k, a) + mu_t * K.gBu_(k, a) : 0.0);
+                    sk[a] = -gu / (hdt * Bd[(a + h3) * m + a]);
+                }
+            }
+        }
         l_amax = op.amax.value(); l_c0 = op.c0; l_c1 = op.c1; l_c2 = op.c2;
         if (pass == 0) {
 #pragma unroll
@@ -2826,9 +2910,36 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
             for (int i = 0; i < m; i++) { K.gAu_(k, i) = gAu[i]; K.gBu_(k, i) = gBu[i]; }
         }
     }
+    if constexpr (SCAN) {
+        if (pass == 1 || ncomp == 0) {   // (wave-uniform: every lane takes part in the scan)
+            constexpr int h3 = n / 2;
+            // velocity costates: nu_k = s_k - nu_{k+1}, nu_N = 0  <=>  nu_k = (-1)^k sum_{j >= k} (-1)^j s_j : ONE suffix sum over the lanes
+            const double sgn = (k & 1) ? -1.0 : 1.0;
+            double V[h3], q[h3];
+#pragma unroll
+            for (int a = 0; a < h3; a++) V[a] = sgn * sk[a];
+            wave_suffix_sum_n<h3>(V);
+#pragma unroll
+            for (int a = 0; a < h3; a++) V[a] *= sgn;
+            // position costates from the x-stationarity of the velocity rows, nu_k[h3 + a] = nu_{k+1}[h3 + a] + dt nu_{k+1}[a] + v_k[h3 + a]:
+            // q_k = nu_{k+1}[a], handed to the next lane; knot 1 closes with its position rows, nu_1[a] = nu_2[a] + v_1[a]
+#pragma unroll
+            for (int a = 0; a < h3; a++) q[a] = ((V[a] - wave_next_f64(V[a])) - vk[h3 + a]) / K.dt;
+            double qp[h3];
+#pragma unroll
+            for (int a = 0; a < h3; a++) qp[a] = wave_prev_f64(q[a]);   // (every lane: the exchange is wave-wide)
+            if (act && k >= 1) {
+#pragma unroll
+                for (int a = 0; a < h3; a++) {
+                    K.nun[k * n + a] = (k == 1) ? q[a] + vk[a] : qp[a];
+                    K.nun[k * n + h3 + a] = V[a];
+                }
+            }
+        }
+    }
     K.sync();
-    if constexpr (!ADJ)   // (adjoint costates: nu_1 is known after the sweep; adjoint_sweep_1w_call closes with this block)
-    if (k == 0 && (pass == 1 || ncomp == 0)) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0
+    // (adjoint costates: nu_1 is known after the sweep; adjoint_sweep_1w_call closes with this block)
+    if (!adj_rt && k == 0 && (pass == 1 || ncomp == 0)) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0
         double Ad[n * n], x0[n], u0[m];
 #pragma unroll
         for (int i = 0; i < n; i++) x0[i] = K.Xp[i];
@@ -3323,7 +3434,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             pf.tick(PF_MID);
             forward_sweep<MODEL>(K);
             if constexpr (GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL)
-                if constexpr (!costate_adjoint<MODEL>())
+                if (!(costate_adjoint<MODEL>() && costate_adjoint_rt<MODEL>(K.P.mp, K.dt)))
                 if (pass == 1 || ncomp == 0) costate_pass_1w_call<MODEL>(K.args());
             pf.tick(PF_FWD);
             GUSTO_REFRESH_K();
@@ -3336,7 +3447,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL, BLK>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
             else so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
             if constexpr (costate_adjoint<MODEL>() && BLK::ONE)
-                if (pass == 1 || ncomp == 0) adjoint_sweep_1w_call<MODEL>(K.args(), hdt);
+                if (costate_adjoint_rt<MODEL>(K.P.mp, K.dt) && (pass == 1 || ncomp == 0)) adjoint_sweep_1w_call<MODEL>(K.args(), hdt);
             const double l_amax = so.amax, l_c0 = so.c0, l_c1 = so.c1, l_c2 = so.c2;
             const double a_max = block_reduce<BLK::ONE>(l_amax, OpMin(), red);
             alpha = a_max;

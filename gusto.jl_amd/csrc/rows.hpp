@@ -484,6 +484,7 @@ template <int NP, class RST = RowState, bool HDX = false> struct OpStep {
     double *gAx, *gAu, *gBx, *gBu;   // (pass 0) corrector row sums of this knot
     const RowPre<NP>* pre;           // state of the fixed-position rows, fetched in one batch (small models)
     double* hdx = nullptr;           // (HDX) H_x dx of this knot
+    double* hdu = nullptr;           // (HDX, optional) the same for the control rows: sum sigma grad grad^T du + lam hess du
     StepFrac amax;
     double c0 = 0, c1 = 0, c2 = 0;
     ObsPre ob;
@@ -536,10 +537,13 @@ template <int NP, class RST = RowState, bool HDX = false> struct OpStep {
                 cB = (1.0 - lol) * rD;
             }
         }
-        if constexpr (HDX && !ISU) {
-            const double sw = sig * w;
+        if constexpr (HDX) {
+            double* hd_ = ISU ? hdu : hdx;
+            if (!ISU || hdu) {
+                const double sw = sig * w;
 #pragma unroll
-            for (int a = 0; a < CNT; a++) hdx[I0 + a] += sw * ev.gr[a] + (lam * ev.hd[a]) * dv[I0 + a];
+                for (int a = 0; a < CNT; a++) hd_[I0 + a] += sw * ev.gr[a] + (lam * ev.hd[a]) * dv[I0 + a];
+            }
         }
         amax.test(t, dt, tau);
         amax.test(lam, dl, tau);
