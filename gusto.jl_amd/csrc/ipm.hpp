@@ -1354,7 +1354,7 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
 // ds_read_b128) and read by ROWS for r_k = P c (P is exactly symmetric), Pi is kept transposed (the column for Pi^T c is a
 // row), only the upper triangle of H is written, and what a lane reads back from itself (its entry of Gd, its entry of Z)
 // stays in a register.
-template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, Prof& pf) {
+template <int MODEL, bool NOPP = false> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, Prof& pf) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     using C = LdsC<MODEL, true>;
@@ -1412,7 +1412,7 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
     // ---- start: P = Pi = Gd = 0 after the last knot, Z = 0 (the tail of "stage N" then leaves Pi_{N-1} = 0) ----
     L[wP] = 0.0; L[wPi] = 0.0; L[wZ] = 0.0;
     double gdR = 0.0, zR = 0.0;   // this lane's entry of Gd (accumulated over the sweep) and of Z (the Pi' term of the next tail)
-    if constexpr (!costate_scan<MODEL>()) if (tid < R::SNN) K.Paft[(size_t)(N - 1) * R::SNN + tid] = 0.0;
+    if constexpr (!NOPP) if (tid < R::SNN) K.Paft[(size_t)(N - 1) * R::SNN + tid] = 0.0;
     double qq = K.kdl[(N - 1) * C::KDS + (tid < NQ ? tid : 0)];
     double LiP[m * m], wiP[m];   // L^-1 and this lane's column i of W of the stage before (tail operands)
 #pragma unroll
@@ -1443,7 +1443,7 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
 #pragma unroll
         for (int l = 0; l < m; l++) { pin -= wiP[l] * vj[l]; gd += vi[l] * vj[l]; }
         L[wPi] = pin; gdR = gd;
-        if constexpr (!costate_scan<MODEL>()) K.Paft[(size_t)(kt - 1) * R::SNN + eq] = pin;
+        if constexpr (!NOPP) K.Paft[(size_t)(kt - 1) * R::SNN + eq] = pin;
 #pragma unroll
         for (int a = 0; a < m; a++) L[wKD + kt * sKD + (m + a) * n] = dj[a];
     };
@@ -1548,7 +1548,7 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
 #pragma unroll
         for (int l = 0; l < m; l++) pn -= wi[l] * wj[l];
         L[wP] = pn;
-        if constexpr (!costate_scan<MODEL>()) K.Paft[(size_t)(k - 1) * R::SNN + ep] = pn;     // (record -1 exists for k == 0)
+        if constexpr (!NOPP) K.Paft[(size_t)(k - 1) * R::SNN + ep] = pn;     // (record -1 exists for k == 0)
 #pragma unroll
         for (int a = 0; a < m; a++) L[wKD + k * sKD + a * n] = kj[a];
         {   // S^-1 = L^-T L^-1, upper triangle (wave-uniform values)
@@ -1612,6 +1612,21 @@ template <int MODEL> constexpr bool costate_adjoint() { return GUSTO_COSTATE_ADJ
 // tf = 70: identical interior point iterations to the P | Pi costates for N >= 45, +8 % at N = 40, +60 % and ALMOST statuses at
 // N = 28).  There the kernel keeps the P | Pi records (their stores aim at the records only then).  Quaternion kinematics are
 // skew (orthogonal Cayley transform): the manifold model showed no such effect down to N = 5.
+// ... and per interior point iteration: these costates are not backward stable the way the P | Pi ones are (whatever the Riccati
+// solution is off by lands in them instead of in a small stage residual), and once in a few thousand solves that noise keeps
+// the dual residual above the 1e-8 test -- the solve then idles at the acceptable level until the iteration cap (measured:
+// astrobeeSE3, 2 of 4044 solves of a B = 1024 batch, 60 iterations each, and the batch waits for them: 31.6 -> 48.5 ms).  A solve
+// that has sat at the acceptable level for GUSTO_ADJ_ACC iterations without passing the test, or is still running after
+// GUSTO_ADJ_MAX_IT (99 % have stopped by then), therefore goes on with the P | Pi records -- and passes the test an iteration later.
+// ipm_solve decides and leaves the answer in LDS (misc[9]) for the phases that are real calls.
+#ifndef GUSTO_ADJ_MAX_IT
+#define GUSTO_ADJ_MAX_IT 20
+#endif
+#ifndef GUSTO_ADJ_ACC
+#define GUSTO_ADJ_ACC 3
+#endif
+constexpr int ADJ_FLAG = 9;   // slot of the per-iteration choice in the misc block of the workgroup's LDS
+template <int MODEL> GD bool costate_adjoint_now() { return gusto_dyn_lds[LdsC<MODEL, true>::misc + ADJ_FLAG] != 0.0; }
 template <int MODEL> GD bool costate_adjoint_rt(const gusto_model_params& mp, double dt) {
 #ifdef GUSTO_ADJ_ALWAYS   // (A/B builds: what the run-time test costs)
     return true;
@@ -2402,8 +2417,7 @@ template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(typename 
     SweepView<MODEL> K = SweepView<MODEL>::make(B);
     if constexpr (MT<MODEL>::MFMA) {
         if constexpr (!costate_adjoint<MODEL>()) factor_sweep_mfma<MODEL, false>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
-        else if constexpr (MODEL != GUSTO_ASTROBEE_SE3) factor_sweep_mfma<MODEL, true>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
-        else if (costate_adjoint_rt<MODEL>(*K.mpp, K.dt)) factor_sweep_mfma<MODEL, true>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
+        else if (costate_adjoint_now<MODEL>()) factor_sweep_mfma<MODEL, true>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
         else factor_sweep_mfma<MODEL, false>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
     }
     else factor_sweep_1w<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
@@ -2415,7 +2429,12 @@ template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof&
 #endif
     else if constexpr (MT<MODEL>::MFMA) factor_sweep_mfma<MODEL, false>(SweepView<MODEL>::make(K), fail, pf);   // (inlined builds, -DGUSTO_SWEEP_INLINE: P | Pi costates)
 #ifndef GUSTO_NO_FACTOR_PIPE
-    else if constexpr (MT<MODEL>::PG2 && LdsC<MODEL, true>::KD_LDS) factor_sweep_pg2<MODEL>(SweepView<MODEL>::make(K), fail, pf);
+    else if constexpr (MT<MODEL>::PG2 && LdsC<MODEL, true>::KD_LDS) {
+        if constexpr (costate_scan<MODEL>()) {   // (no P | Pi records while the costates come from the scans: two instances of the sweep)
+            if (costate_adjoint_now<MODEL>()) factor_sweep_pg2<MODEL, true>(SweepView<MODEL>::make(K), fail, pf);
+            else factor_sweep_pg2<MODEL, false>(SweepView<MODEL>::make(K), fail, pf);
+        } else factor_sweep_pg2<MODEL, false>(SweepView<MODEL>::make(K), fail, pf);
+    }
 #endif
     else factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail, pf);
 }
@@ -2760,8 +2779,9 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m;
     constexpr bool ADJ = costate_adjoint<MODEL>() && BLK::ONE;   // new costates by the adjoint recursion (adjoint_sweep_1w)
-    const bool adj_rt = ADJ && costate_adjoint_rt<MODEL>(K.P.mp, K.dt);   // ... unless the horizon is too coarse for it (P | Pi records then)
     constexpr bool SCAN = costate_scan<MODEL>() && BLK::ONE;      // ... by two suffix sums over the lanes (double integrator)
+    bool adj_rt = false;   // ... unless the horizon is too coarse for it or the solve has run long (P | Pi records then)
+    if constexpr (ADJ || SCAN) adj_rt = costate_adjoint_now<MODEL>();
     const int N = K.N;
     double l_amax = 1.0, l_c0 = 0, l_c1 = 0, l_c2 = 0;
     double vk[SCAN ? n : 1];   // (SCAN) v_k = M^T (H_x dx_k + gx_k [+ mu_g]) of this lane's knot, 0 for knot 0 and the idle lanes
@@ -2804,8 +2824,8 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
 #pragma unroll
         for (int i = 0; i < n; i++) K.dXs_(k, i) = dxs[i];
         // nu_{k+1} = P_k dy_k + p_k + Pi_k mu_g  (one-wave 12/13-state models: costate_pass_1w has done it)
-        if constexpr (!(GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL) && !SCAN)
-        if (k + 1 < N && (pass == 1 || ncomp == 0)) {
+        if constexpr (!(GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL))
+        if (!(SCAN && adj_rt) && k + 1 < N && (pass == 1 || ncomp == 0)) {
 #pragma unroll
             for (int i = 0; i < n; i++) {
                 double s = K.pv[k * n + i] - K.rv[k * n + i];
@@ -2876,7 +2896,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
             // gives the SUM s_k of two consecutive velocity costates LOCALLY: sk[a] below.  (The adjoint recursion proper,
             // nu_k = Phi^T nu_{k+1} + v_k, is two nested suffix sums over the knots and amplifies the stage errors of the
             // Riccati solution by ~N^2 dt / 2: measured +13 % interior point iterations at omega = 1e4.)
-            if (k >= 1 && (pass == 1 || ncomp == 0)) {
+            if (adj_rt && k >= 1 && (pass == 1 || ncomp == 0)) {
                 constexpr int h3 = n / 2;
                 double Mk[n * n], Gamk[n * m], w[n], Bd[n * m];
                 load_M_Gam(K, k, Mk, Gamk);
@@ -2911,7 +2931,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         }
     }
     if constexpr (SCAN) {
-        if (pass == 1 || ncomp == 0) {   // (wave-uniform: every lane takes part in the scan)
+        if (adj_rt && (pass == 1 || ncomp == 0)) {   // (wave-uniform: every lane takes part in the scan)
             constexpr int h3 = n / 2;
             // velocity costates: nu_k = s_k - nu_{k+1}, nu_N = 0  <=>  nu_k = (-1)^k sum_{j >= k} (-1)^j s_j : ONE suffix sum over the lanes
             const double sgn = (k & 1) ? -1.0 : 1.0;
@@ -2939,7 +2959,7 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
     }
     K.sync();
     // (adjoint costates: nu_1 is known after the sweep; adjoint_sweep_1w_call closes with this block)
-    if (!adj_rt && k == 0 && (pass == 1 || ncomp == 0)) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0
+    if (!(ADJ && adj_rt) && k == 0 && (pass == 1 || ncomp == 0)) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0
         double Ad[n * n], x0[n], u0[m];
 #pragma unroll
         for (int i = 0; i < n; i++) x0[i] = K.Xp[i];
@@ -3335,6 +3355,13 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         if (it == 0) mu_start = mu;
         if (mu > IPM_DIVERGED * fmax(1.0, mu_start)) break;   // (diverging: an infeasible subproblem, common.hpp)
         pf.tick(PF_BUILD);
+        // (the costates of this iteration: adjoint recursion or P | Pi records, see costate_adjoint_rt)
+        bool adj_now = false;
+        if constexpr ((costate_adjoint<MODEL>() || costate_scan<MODEL>()) && BLK::ONE) {
+            adj_now = it < GUSTO_ADJ_MAX_IT && n_acc < GUSTO_ADJ_ACC && costate_adjoint_rt<MODEL>(K.P.mp, K.dt);
+            if (k == 0) K.misc[ADJ_FLAG] = adj_now ? 1.0 : 0.0;
+            K.sync();
+        }
         // (4) factorise
         factor_sweep<MODEL>(K, fail, pf);
         pf.tick(PF_FACTOR);
@@ -3434,7 +3461,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             pf.tick(PF_MID);
             forward_sweep<MODEL>(K);
             if constexpr (GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL)
-                if (!(costate_adjoint<MODEL>() && costate_adjoint_rt<MODEL>(K.P.mp, K.dt)))
+                if (!adj_now)
                 if (pass == 1 || ncomp == 0) costate_pass_1w_call<MODEL>(K.args());
             pf.tick(PF_FWD);
             GUSTO_REFRESH_K();
@@ -3447,7 +3474,8 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL, BLK>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
             else so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
             if constexpr (costate_adjoint<MODEL>() && BLK::ONE)
-                if (costate_adjoint_rt<MODEL>(K.P.mp, K.dt) && (pass == 1 || ncomp == 0)) adjoint_sweep_1w_call<MODEL>(K.args(), hdt);
+                if (adj_now && (pass == 1 || ncomp == 0)) adjoint_sweep_1w_call<MODEL>(K.args(), hdt);
+            (void)adj_now;
             const double l_amax = so.amax, l_c0 = so.c0, l_c1 = so.c1, l_c2 = so.c2;
             const double a_max = block_reduce<BLK::ONE>(l_amax, OpMin(), red);
             alpha = a_max;
