@@ -262,7 +262,9 @@ def _scp_parity(model, N, env, spheres, x0, glo, ghi, tf, max_iter=30, max_diver
         # within 1e-2 relative (problem 38 of this batch wanders with convergence measures of 0.5 .. 6.7 for twelve trips: its
         # thirteenth differs by 3 % between the lane kernel and the oracle, every verdict still the same).
         wh, ch = w, 10 ** 6       # (ch: history entries compared)
-        if not r["converged"] and r["stop_reason"] == 0:
+        # (only where it was measured -- dubins_car, whose heading wraps and whose runs wander: the other models' MaxIter runs
+        # keep the tolerances of the converged ones)
+        if model == g.DUBINS_CAR and not r["converged"] and r["stop_reason"] == 0:
             w, wh, ch = 10.0 * w, 100.0 * w, 9        # ... and the first eight trips of their histories
         assert np.abs(X[b] - r["X"]).max() < TRAJ_ATOL * w and np.abs(U[b] - r["U"]).max() < TRAJ_ATOL * w, b
         np.testing.assert_array_equal(h["accept_solution"][b, :nh], r["accept"])
@@ -969,3 +971,239 @@ def test_warm_start_defaults_on_device_are_the_documented_triples():
             out.append((s.traj()[0], s.status()["ipm_iters"].copy()))
         np.testing.assert_array_equal(out[0][0], out[1][0])
         np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
+# ---- known divergences, out-of-sample robustness, row values (round 5) ---------------------------------------------------------
+# dubins_car problems (generator index first = 20000 + i) whose SCP iteration counts differ between the HIP path and the oracle in
+# the 8192-problem sweep of profiles/r04_parity_sweep.txt -- among them one trip against thirty
+DUBINS_KNOWN = [351, 662, 1659, 2304, 3155, 3252, 3780, 3792, 5064, 6056, 6158, 6745]
+
+
+def _dubins_hard_rows_lp(Xp, Up, x_init, goal, tf):
+    """Feasibility of the HARD rows of a dubins_car subproblem linearised at (Xp, Up) -- x_1 = x_init, x_N = goal, the trapezoid
+    rows (dubins_car.jl:134-146; f and its Jacobians from tests/np_models.py, no oracle code) and |u_k| <= 10 for k < N
+    (dynamics.jl:73-81) -- as a linear program for HiGHS: 0 = feasible, 2 = infeasible.  The penalised rows cannot make a
+    subproblem infeasible."""
+    from scipy.optimize import linprog
+    import np_models as nm
+    N, n, m = Xp.shape[0], 3, 1
+    dt, nz = tf / (N - 1), 4
+    Aeq, beq = [], []
+    for i in range(n):
+        r = np.zeros(N * nz); r[i] = 1; Aeq.append(r); beq.append(x_init[i])
+        r = np.zeros(N * nz); r[(N - 1) * nz + i] = 1; Aeq.append(r); beq.append(goal[i])
+    lin = []
+    for k in range(N):
+        A, Bm = nm.jac(nm.Dubins, Xp[k], Up[k])
+        lin.append((nm.Dubins.f(Xp[k], Up[k]) - A @ Xp[k] - Bm @ Up[k], A, Bm))
+    for k in range(1, N):
+        (c0, A0, B0), (c1, A1, B1) = lin[k - 1], lin[k]
+        for i in range(n):
+            r = np.zeros(N * nz)
+            r[(k - 1) * nz + i] += 1; r[k * nz + i] -= 1
+            r[(k - 1) * nz:(k - 1) * nz + n] += 0.5 * dt * A0[i]; r[(k - 1) * nz + n] += 0.5 * dt * B0[i, 0]
+            r[k * nz:k * nz + n] += 0.5 * dt * A1[i]; r[k * nz + n] += 0.5 * dt * B1[i, 0]
+            Aeq.append(r); beq.append(-0.5 * dt * (c0[i] + c1[i]))
+    bounds = []
+    for k in range(N):
+        bounds += [(None, None)] * n + [(-10.0, 10.0) if k < N - 1 else (None, None)]
+    return linprog(np.zeros(N * nz), A_eq=np.array(Aeq), b_eq=np.array(beq), bounds=bounds, method="highs").status
+
+
+def _first_difference(h, j, r):
+    """first history entry (>= 1) of device problem j that differs from the oracle run r; min length if none"""
+    nh, no = int(h["n_hist"][j]), len(r["scp_status"])
+    for t in range(1, min(nh, no)):
+        if not (h["scp_status"][j, t] == r["scp_status"][t] and h["accept_solution"][j, t] == r["accept"][t] and
+                h["solver_status"][j, t] == r["solver_status"][t] and h["Delta"][j, t] == r["Delta"][t] and
+                h["omega"][j, t] == r["omega"][t]):
+            return t
+    return min(nh, no)
+
+
+def test_dubins_known_divergences():
+    """The twelve dubins_car problems of the 8192-problem sweep whose trip counts differ (1 against 30 among them), one by one.
+    What the test pins:
+    * up to the first differing history entry the two sides took identical decisions;
+    * nine of them part at an interior point solve AT THE ITERATION CAP (gusto_ipm_opts.max_iter = 60): a subproblem that needs
+      55-80 iterations, where one side is through (OPTIMAL, or ALMOST at the cap) and the other one iteration short (FAILED ->
+      SubproblemFailed, scp_gusto.jl:106-111).  An LP on the hard rows (HiGHS, no oracle code) says those subproblems are
+      FEASIBLE: the side that solved is right, the side that failed ran out of iterations -- which side that is, is decided in
+      the last digits, on both implementations alike.  With the cap at 150 on both sides those solves finish and the runs agree
+      again (the remaining differences are a trip more or less before the same stop); the default stays 60: config 3 takes
+      2.2 x as long at 150 for 45 more converged problems of 65 536 (tools/cap_scan.py);
+    * the other three part late (entry >= 24) in runs that never settle (convergence measure O(1) trip after trip): drift, the
+      case _scp_parity counts."""
+    g, go = _mods()
+    P = g.problems
+    x0, glo, ghi, tf = P.dubins_batch(8192, first=20000)
+    x0, glo, ghi, tf = x0[DUBINS_KNOWN], glo[DUBINS_KNOWN], ghi[DUBINS_KNOWN], tf[DUBINS_KNOWN]
+    B = len(DUBINS_KNOWN)
+
+    def both(cap):
+        ig = g.default_ipm_opts(); ig.max_iter = cap
+        io_ = go.IpmOpts(tol=ig.tol, tol_acc=ig.tol_acc, mu_floor=ig.mu_floor, tr_tol=ig.tr_tol, mu_warm=ig.mu_warm, max_iter=cap,
+                         acc_iter=ig.acc_iter, mu_warm_gain=ig.mu_warm_gain, mu_warm_max=ig.mu_warm_max, sigma_max=ig.sigma_max)
+        s = g.BatchSolver(g.DUBINS_CAR, 30, B, hist_cap=64, ipm_opts=ig)
+        s.set_problems(x0, glo, ghi, tf); s.solve(30)
+        o = go.Oracle(go.DUBINS_CAR, 30, ipm_opts=io_)
+        runs = []
+        for j in range(B):
+            o.set_trace(34); o.set_problem(x0[j], glo[j], ghi[j], tf[j])
+            runs.append((o.solve(30), o.trace()))
+        return s.status(), s.history(), runs
+
+    st, h, runs = both(60)
+    at_cap, drift = [], []
+    for j, b in enumerate(DUBINS_KNOWN):
+        r, tr = runs[j]
+        t = _first_difference(h, j, r)
+        nh, no = int(h["n_hist"][j]), len(r["scp_status"])
+        # interior point iterations of the solve at which the runs part, and of the one before, on both sides
+        its = [int(h["ipm_iters"][j, q]) for q in (t - 1, t) if 1 <= q < nh] + [int(r["ipm_iters"][q]) for q in (t - 1, t) if 1 <= q < no]
+        if max(its) >= 50:
+            at_cap.append(j)
+            e = tr[min(t, len(tr)) - 1]                  # trip t starts from the trajectory the trace holds for it
+            assert _dubins_hard_rows_lp(e["Xp"], e["Up"], x0[j], glo[j], tf[j]) == 0, (b, t)     # feasible: solving it is right
+        else:
+            drift.append(j)
+            assert t >= 24, (b, t, its)
+    print("dubins known divergences: at the iteration cap", [DUBINS_KNOWN[j] for j in at_cap], "late drift", [DUBINS_KNOWN[j] for j in drift])
+    assert len(at_cap) >= 8 and len(drift) <= 4
+    st2, h2, runs2 = both(150)
+    agree = sum(int(st2["iterations"][j]) == runs2[j][0]["iterations"] and int(st2["stop_reason"][j]) == runs2[j][0]["stop_reason"]
+                for j in at_cap)
+    same_stop = sum(int(st2["stop_reason"][j]) == runs2[j][0]["stop_reason"] for j in at_cap)
+    print("  with max_iter = 150:", agree, "of", len(at_cap), "agree in trips and stop reason;", same_stop, "in the stop reason")
+    assert agree >= len(at_cap) - 3 and same_stop == len(at_cap)
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5])
+def test_out_of_sample_robustness(cfg):
+    """The solver's internal heuristics (warm-start triples, sigma_max, mu_floor: common.hpp warm_defaults) were measured on the
+    first problems of each BASELINE generator.  A batch drawn far along the same generator (first = 100 000, a quarter of the
+    config's size) must behave like the in-sample batch of that size: no more SubproblemFailed problems (plus a margin), a
+    comparable yield, a comparable number of interior point iterations per problem and kernel time -- the check that would have
+    caught a complementarity floor that makes out-of-sample manifold problems cycle."""
+    import bench
+    g, _ = _mods()
+    P = g.problems
+    c = bench.CONFIGS[cfg]
+    B = c["B"] // 4
+    res = {}
+    for first in (0, 100000):
+        model, boxes, spheres, batch = bench.workload(P, g, cfg, B, first)
+        s = g.BatchSolver(model, c["N"], B, hist_cap=64, boxes=boxes, spheres=spheres)
+        for _ in range(2):
+            s.set_problems(*batch); s.solve(30)
+        st = s.status()
+        res[first] = dict(ms=s.last_solve_ms(), failed=int((st["stop_reason"] == 2).sum()), conv=int(st["converged"].sum()),
+                          ipm=float(st["ipm_iters"].mean()), longest=int(st["ipm_iters"].max()))
+        s.close()
+    a, b = res[0], res[100000]
+    print(f"config {cfg} B={B}: in-sample {a} out-of-sample {b}")
+    assert b["failed"] <= 1.25 * a["failed"] + max(2, B // 500), (a, b)
+    assert b["conv"] >= 0.95 * a["conv"] - 2, (a, b)
+    # (the longest problem of a batch is an extreme-value statistic: 345 against 558 KKT solves in two dubins batches of 16 384)
+    assert b["ipm"] <= 1.2 * a["ipm"] and b["longest"] <= 2.0 * a["longest"] + 60, (a, b)
+    assert b["ms"] <= 1.4 * a["ms"] + 1.0, (a, b)
+
+
+def test_manifold_rows_and_objective_in_lockstep():
+    """AstrobeeSE3Manifold: inside its +-1e-4 BoxGoal on the quaternion the optimum is only weakly determined in X (gated at 3e-4
+    in the lock-step suite), so here the quantities that ARE determined carry the comparison, trip by trip from the oracle's
+    (traj_prev, Delta, omega): the objective to 1e-8 relative, and the value of EVERY row of the subproblem -- penalised state
+    rows, the +-eps quaternion pair, obstacle rows, hard control and BoxGoal rows (the oracle's assembled row list, evaluated
+    at both optima) -- to 1e-6 of the scaled row wherever the row is within 1e-4 of its bound on either side, U to 2e-6."""
+    g, go = _mods()
+    P = g.problems
+    boxes, sph = P.iss_corner_env(True)
+    x0, glo, ghi, tf = P.astrobee_manifold_batch(12)
+    model, N = g.ASTROBEE_SE3_MANIFOLD, 50
+    clr = g.default_params(model)[1].clearance
+    o = go.Oracle(model, N, boxes=boxes, spheres=sph)
+    trips = []
+    for b in range(12):
+        o.set_trace(8); o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        r = o.solve(4)
+        for t, e in enumerate(o.trace()):
+            trips.append((b, e["Xp"], e["Up"], r["Delta"][t], r["omega"][t]))
+    T = len(trips)
+    assert T >= 36
+    bi = np.array([q[0] for q in trips])
+    Xp, Up = np.stack([q[1] for q in trips]), np.stack([q[2] for q in trips])
+    Delta, omega = np.array([q[3] for q in trips]), np.array([q[4] for q in trips])
+    s = g.BatchSolver(model, N, T, hist_cap=8, boxes=boxes, spheres=sph)
+    s.set_problems(x0[bi], glo[bi], ghi[bi], tf[bi])
+    sub = s.subproblem(Xp, Up, Delta, omega, Delta / 8 + clr)
+    worst_row = worst_obj = worst_u = 0.0
+    n_rows = n_act = 0
+    for i, (b, xp, up, D, w) in enumerate(trips):
+        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+        c = o.subproblem(xp, up, D, w, D / 8 + clr)
+        assert c["status"] in (1, 2) and int(sub["status"][i]) in (1, 2)
+        rows = o.rows()
+        n_rows += len(rows)
+
+        def val(X, U, r_):
+            v = (U if r_["isu"] else X)[r_["k"]][r_["idx"]]
+            raw = float(np.sum(r_["a"] * (v - r_["v0"]) ** 2) + np.sum(r_["b"] * v) + r_["c0"])
+            return r_["mul"] * raw - r_["off"]
+        # a row far inside its bound is not determined by optimality (the BoxGoal rows on q, scaled by 1e3, are the case in
+        # point): the rows within 1e-4 of their bound on EITHER side -- active, or nearly -- must agree, the others be inactive on both
+        for r_ in rows:
+            vd, vo = val(sub["X"][i], sub["U"][i], r_), val(c["X"], c["U"], r_)
+            if max(vd, vo) > -1e-4:
+                n_act += 1
+                worst_row = max(worst_row, abs(vd - vo) / max(1.0, w))
+        worst_obj = max(worst_obj, abs(sub["obj"][i] - c["obj"]) / (max(1.0, w) * max(1.0, abs(c["obj"]))))
+        worst_u = max(worst_u, np.abs(sub["U"][i] - c["U"]).max() / max(1.0, w))
+    print(f"manifold rows in lock step: {T} subproblems, {n_rows} rows, {n_act} near their bound, worst difference there {worst_row:.2e}, objective {worst_obj:.2e}, U {worst_u:.2e}")
+    assert n_act >= T and worst_obj < 1e-8 and worst_row < 1e-6 and worst_u < 2e-6
+
+
+def _round3_ipm_opts(mod, ctor):
+    """the interior point options the frozen goldens were generated with (round 3: constant warm start at 1e-4, Mehrotra's centring
+    parameter unbounded, complementarity floor 1e-11 for every model)"""
+    d = mod.default_ipm_opts() if hasattr(mod, "default_ipm_opts") else None
+    kw = dict(tol=1e-8, tol_acc=1e-5, mu_floor=1e-11, tr_tol=1e-6, mu_warm=1e-4, max_iter=60, acc_iter=0, mu_warm_gain=0.0, mu_warm_max=1e-4, sigma_max=0.0)
+    if d is not None:
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    return ctor(**kw)
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_gpu_matches_frozen_round3_goldens(name):
+    """tests/golden/frozen_r3: fixtures generated by the ROUND-3 oracle and never regenerated since.  Today's kernels, run with
+    the round-3 interior point options spelled out, are held to the round-3 tolerances (subproblem X, U 1e-6 -- U 1e-5 and X 1e-4, the
+    width of its quaternion BoxGoal, for the manifold model --, objective 1e-8, identical trip counts / convergence flags / stop reasons, final trajectories 1e-3): a
+    regression that a change of defaults, mirrored in the oracle and its regenerated goldens, would carry along unseen shows here."""
+    import os
+    g, _ = _mods()
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frozen_r3", name + ".npz"))
+    model, N, B = int(d["model"]), int(d["N"]), len(d["x_init"])
+    s = g.BatchSolver(model, N, B, hist_cap=int(d["max_iter"]) + 8, boxes=d["boxes"], spheres=d["spheres"], ipm_opts=_round3_ipm_opts(g, None))
+    s.set_problems(d["x_init"], d["goal_lo"], d["goal_hi"], d["tf"])
+    X0, U0 = s.traj()
+    sp, mp = g.default_params(model)
+    sub = s.subproblem(X0, U0, sp.Delta0, 1.0, sp.Delta0 / 8 + mp.clearance)
+    for b in range(B):
+        assert int(sub["status"][b]) == int(d["sub_status"][b])
+        if int(d["sub_status"][b]) != 1:
+            continue
+        # (the manifold model's quaternion floats inside its +-1e-4 BoxGoal: X there is held to that width -- round 3 measured 1e-5,
+        # today's kernels 5e-5 -- while U and the objective, which ARE determined, keep the round-3 tolerances)
+        man = model == g.ASTROBEE_SE3_MANIFOLD
+        assert np.abs(sub["X"][b] - d["sub_X"][b]).max() < (1e-4 if man else SUB_ATOL), (b, np.abs(sub["X"][b] - d["sub_X"][b]).max())
+        assert np.abs(sub["U"][b] - d["sub_U"][b]).max() < (1e-5 if man else SUB_ATOL), (b, np.abs(sub["U"][b] - d["sub_U"][b]).max())
+        assert abs(sub["obj"][b] - d["sub_obj"][b]) <= 1e-8 * max(1.0, abs(d["sub_obj"][b]))
+    s.set_problems(d["x_init"], d["goal_lo"], d["goal_hi"], d["tf"])
+    s.solve(int(d["max_iter"]))
+    X, U = s.traj()
+    st = s.status()
+    for b in range(B):
+        assert bool(st["converged"][b]) == bool(d["converged"][b]) and int(st["iterations"][b]) == int(d["iterations"][b]), (b, st["iterations"][b], d["iterations"][b])
+        assert int(st["stop_reason"][b]) == int(d["stop_reason"][b])
+        assert np.abs(X[b] - d["X"][b]).max() < TRAJ_ATOL and np.abs(U[b] - d["U"][b]).max() < TRAJ_ATOL

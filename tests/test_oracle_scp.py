@@ -287,3 +287,29 @@ def test_warm_start_defaults_are_the_documented_triples():
             c = go.Oracle(model, N, boxes=bx, spheres=sp, ipm_opts=io)
             c.set_problem(x0[0], glo[0], ghi[0], tf[0]); a.set_problem(x0[0], glo[0], ghi[0], tf[0])
             assert list(c.solve(12)["ipm_iters"]) != list(a.solve(12)["ipm_iters"])
+
+
+@pytest.mark.parametrize("name", ["freeflyer_se2_n50", "dubins_car_n30", "astrobee_se3_n50", "astrobee_se3_manifold_n50"])
+def test_oracle_reproduces_the_frozen_round3_goldens(name):
+    """tests/golden/frozen_r3 (generated by the round-3 oracle, never regenerated): today's oracle with the round-3 interior point
+    options spelled out -- constant warm start 1e-4, no bound on Mehrotra's centring parameter, complementarity floor 1e-11 --
+    gives those runs again: same trip counts, flags and stop reasons, subproblem optimum to 1e-6 (1e-5 manifold), final
+    trajectory to 1e-3.  The defaults may move; this anchor does not move with them."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frozen_r3", name + ".npz"))
+    model, N = int(d["model"]), int(d["N"])
+    io = go.IpmOpts(tol=1e-8, tol_acc=1e-5, mu_floor=1e-11, tr_tol=1e-6, mu_warm=1e-4, max_iter=60, acc_iter=0, mu_warm_gain=0.0,
+                    mu_warm_max=1e-4, sigma_max=0.0)
+    o = go.Oracle(model, N, boxes=d["boxes"], spheres=d["spheres"], ipm_opts=io)
+    for b in range(min(3, len(d["x_init"]))):
+        o.set_problem(d["x_init"][b], d["goal_lo"][b], d["goal_hi"][b], d["tf"][b])
+        Xi, Ui = o.init_straightline()
+        sub = o.subproblem(Xi, Ui, o.sp.Delta0, 1.0, o.sp.Delta0 / 8 + o.mp.clearance)
+        assert sub["status"] == int(d["sub_status"][b])
+        if sub["status"] == 1:
+            tol = 1e-5 if model == go.ASTROBEE_SE3_MANIFOLD else 1e-6
+            assert np.abs(sub["X"] - d["sub_X"][b]).max() < tol and np.abs(sub["U"] - d["sub_U"][b]).max() < tol
+        o.set_problem(d["x_init"][b], d["goal_lo"][b], d["goal_hi"][b], d["tf"][b])
+        r = o.solve(int(d["max_iter"]))
+        assert r["iterations"] == int(d["iterations"][b]) and r["converged"] == bool(d["converged"][b]) and r["stop_reason"] == int(d["stop_reason"][b])
+        assert np.abs(r["X"] - d["X"][b]).max() < 1e-3
