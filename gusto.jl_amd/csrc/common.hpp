@@ -42,6 +42,15 @@ constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5,
 #define GUSTO_WAVES_PER_EU 1
 #endif
 
+#ifndef GUSTO_TO_SWEEP_CALL
+// the phases and sweeps of the astrobee TrajOpt kernels as real calls (register allocations of their own): inlined, trajopt_kernel<5>
+// spilled 3436 registers (6.6 KB of scratch per lane), <6> 4046 (7.6 KB); called, 491 / 554 -- B = 256 astrobeeSE3 831 -> 542 ms,
+// B = 128 manifold 1128 -> 893 ms, bit-identical
+#define GUSTO_TO_SWEEP_CALL true
+#endif
+#ifndef GUSTO_TO4_SWEEP_CALL
+#define GUSTO_TO4_SWEEP_CALL true   // ... of the freeflyer TrajOpt kernel (B = 1024: 58.3 -> 53.4 ms; the same schedule, results within 1e-9: contraction differs across the call)
+#endif
 #ifndef GUSTO_USE_MFMA
 #define GUSTO_USE_MFMA true   // -DGUSTO_USE_MFMA=false: the VALU two-step contraction instead (A/B measurements)
 #endif
@@ -148,7 +157,7 @@ template <> struct MT<GUSTO_TO_FREEFLYER_SE2> {
     using G = MT<GUSTO_FREEFLYER_SE2>;
     static constexpr int NDEF = 6, n = 6, m = 3 + NDEF, WS = 2, NFIX = 3, NHU = 2 + 2 * NDEF;
     static constexpr int WAVES_PER_EU = 1, SCHED_PROBE = 0, SCHED_SLICE = 0;
-    static constexpr bool SWEEP_CALL = false, MFMA = false, LTI = false, HAS_OBS = true, PG2 = false;
+    static constexpr bool SWEEP_CALL = GUSTO_TO4_SWEEP_CALL, MFMA = false, LTI = false, HAS_OBS = true, PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
     static constexpr int pg_r1(int) { return 0; }
     static constexpr bool Anz(int i, int j) { return G::Anz(i, j); }
@@ -161,7 +170,7 @@ template <> struct MT<GUSTO_TO_ASTROBEE_SE3> {
     using G = MT<GUSTO_ASTROBEE_SE3>;
     static constexpr int NDEF = 12, n = 12, m = 6 + NDEF, WS = 3, NFIX = 3, NHU = 2 + 2 * NDEF;
     static constexpr int WAVES_PER_EU = 1, SCHED_PROBE = 0, SCHED_SLICE = 0;
-    static constexpr bool SWEEP_CALL = false, MFMA = false, LTI = false, HAS_OBS = true, PG2 = false;
+    static constexpr bool SWEEP_CALL = GUSTO_TO_SWEEP_CALL, MFMA = false, LTI = false, HAS_OBS = true, PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
     static constexpr int pg_r1(int) { return 0; }
     static constexpr bool Anz(int i, int j) { return G::Anz(i, j); }
@@ -176,7 +185,7 @@ template <> struct MT<GUSTO_TO_ASTROBEE_SE3_MANIFOLD> {
     // fixed state rows of a knot: the +- band of the (hard) quaternion norm row, orientation sign, speed, rate
     static constexpr int NDEF = 13, n = 13, m = 6 + NDEF, WS = 3, NFIX = 5, NHU = 2 + 2 * NDEF;
     static constexpr int WAVES_PER_EU = 1, SCHED_PROBE = 0, SCHED_SLICE = 0;
-    static constexpr bool SWEEP_CALL = false, MFMA = false, LTI = false, HAS_OBS = true, PG2 = false;
+    static constexpr bool SWEEP_CALL = GUSTO_TO_SWEEP_CALL, MFMA = false, LTI = false, HAS_OBS = true, PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
     static constexpr int pg_r1(int) { return 0; }
     static constexpr bool Anz(int i, int j) { return G::Anz(i, j); }

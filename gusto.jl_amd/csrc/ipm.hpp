@@ -2422,8 +2422,17 @@ template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(typename 
     }
     else factor_sweep_1w<MODEL>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf);
 }
+// the multi-wave sweeps of the TrajOpt kernels whose phases are real calls (MT::SWEEP_CALL with defect controls): a register
+// allocation of their own, like the one-wave sweeps of the 12/13-state GuSTO kernels
+template <int MODEL, class BLK> __device__ __noinline__ void factor_sweep_mw_call(typename BLK::Args a, Prof* pf) {
+    BLK K(a, gusto_dyn_lds);
+    factor_sweep_mw<MODEL>(K, gusto_dyn_lds + BLK::C::misc + 8, *pf);
+}
+template <class BLK> __device__ __noinline__ void backward_sweep_mw_call(typename BLK::Args a) { BLK K(a, gusto_dyn_lds); backward_sweep_mw(K); }
+template <class BLK> __device__ __noinline__ void forward_sweep_mw_call(typename BLK::Args a) { BLK K(a, gusto_dyn_lds); forward_sweep_mw(K); }
 template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof& pf) {
-    if constexpr (!BLK::ONE) factor_sweep_mw<MODEL>(K, fail, pf);
+    if constexpr (!BLK::ONE && MT<MODEL>::SWEEP_CALL && MT<MODEL>::NDEF > 0) factor_sweep_mw_call<MODEL, BLK>(K.args(), &pf);
+    else if constexpr (!BLK::ONE) factor_sweep_mw<MODEL>(K, fail, pf);
 #ifndef GUSTO_SWEEP_INLINE
     else if constexpr (MT<MODEL>::SWEEP_CALL) factor_sweep_1w_call<MODEL>(K.args(), &pf);
 #endif
@@ -2447,12 +2456,14 @@ template <int MODEL> __device__ __noinline__ void forward_sweep_1w_call(typename
     forward_sweep_1w(SweepView<MODEL>::make(B));
 }
 template <int MODEL, class BLK> GD void backward_sweep(BLK& K) {
-    if constexpr (!BLK::ONE) backward_sweep_mw(K);
+    if constexpr (!BLK::ONE && MT<MODEL>::SWEEP_CALL && MT<MODEL>::NDEF > 0) backward_sweep_mw_call<BLK>(K.args());
+    else if constexpr (!BLK::ONE) backward_sweep_mw(K);
     else if constexpr (MT<MODEL>::SWEEP_CALL) backward_sweep_1w_call<MODEL>(K.args());
     else backward_sweep_1w(SweepView<MODEL>::make(K));
 }
 template <int MODEL, class BLK> GD void forward_sweep(BLK& K) {
-    if constexpr (!BLK::ONE) forward_sweep_mw(K);
+    if constexpr (!BLK::ONE && MT<MODEL>::SWEEP_CALL && MT<MODEL>::NDEF > 0) forward_sweep_mw_call<BLK>(K.args());
+    else if constexpr (!BLK::ONE) forward_sweep_mw(K);
     else if constexpr (MT<MODEL>::SWEEP_CALL) forward_sweep_1w_call<MODEL>(K.args());
     else forward_sweep_1w(SweepView<MODEL>::make(K));
 }
