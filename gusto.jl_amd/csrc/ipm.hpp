@@ -198,6 +198,16 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     GD Blk(const KParams& P_, double* lds_, int b_, int slot) : P(P_), lds(lds_) {
         b = b_; tid = threadIdx.x; NTr = blockDim.x; N = P.N; slot_ = slot;
         Pk = (const KParams*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // (this constructor is inlined into the kernel)
+#ifdef GUSTO_DEBUG_LDS
+        {   // the called phases read the kernel arguments THROUGH this pointer: KParams must be the first argument, at offset 0
+            typedef const __attribute__((address_space(4))) KParams CP;
+            CP* Pc = (CP*)(uintptr_t)Pk;
+            if (Pc->N != P.N || Pc->B != P.B || Pc->ws != P.ws) {
+                if (threadIdx.x == 0) printf("gusto: the kernarg segment does not start with this launch's KParams (block %d)\n", (int)blockIdx.x);
+                __builtin_trap();
+            }
+        }
+#endif
         rebind_lds(lds_);
         double* w = P.ws + (size_t)slot * P.wl.total;
         const WsLayout& W = P.wl;
