@@ -168,6 +168,7 @@ int gusto_destroy(gusto_handle h) {
     if (h->d_queue) hipFree(h->d_queue);
     if (h->d_sched_ord) hipFree(h->d_sched_ord);
     if (h->h_sched_err) hipHostFree(h->h_sched_err);
+    if (h->ev_gather) hipEventDestroy(h->ev_gather);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -455,7 +456,7 @@ int gusto_get_traj_dev(gusto_handle h, const double** X, const double** U) {
 // The final gather of a multi-GPU run below the host language (SURVEY.md 8(b) threading row, 8(e); north_star: "RCCL only
 // for the batch split and final gather").  One process, one handle per GPU: every shard goes to the GPU of `dst` with ONE
 // direct peer copy over xGMI (hipMemcpyPeerAsync: one hop per source, all links busy -- the fan-in 8(e) asks for, not a
-// ring), enqueued on dst's stream behind the completion of each source's solve.
+// ring), each enqueued on its SOURCE handle's stream right behind that shard's solve; dst's stream waits for their events.
 int gusto_gather_peer(gusto_handle dst, int n_src, const gusto_handle* src, const double** X_dev, const double** U_dev,
                       double* X_host, double* U_host, int* B_total) {
     if (!dst || n_src < 1 || !src) return GUSTO_ERR_ARG;
@@ -467,17 +468,14 @@ int gusto_gather_peer(gusto_handle dst, int n_src, const gusto_handle* src, cons
             dst->err = "gusto_gather_peer: every handle must hold the same model, algorithm and N";
             return GUSTO_ERR_ARG;
         }
-        HIPCHK(q, hipSetDevice(q->device));
-        { int rc = gusto_finish(q); if (rc) { dst->err = "gusto_gather_peer: source: " + q->err; return rc; } }
-        if (q->trajopt) {     // (device rows are (u | defect): compact them on the source GPU first)
-            if (!q->d_Upub) HIPCHK(q, dalloc(&q->d_Upub, (size_t)q->batch_cap * q->N * q->m_pub));
-            HIPCHK(q, copy_U(q, q->d_Upub, q->d_U, false, hipMemcpyDeviceToDevice));
-            HIPCHK(q, hipStreamSynchronize(q->stream));
-        }
         tot += q->B;
     }
     HIPCHK(dst, hipSetDevice(dst->device));
-    { int rc = gusto_finish(dst); if (rc) return rc; }
+    // (dst's own solve, if it is a source, is completed like the others below; a pending solve of a dst that is NOT among the
+    // sources is completed here)
+    bool dst_is_src = false;
+    for (int i = 0; i < n_src; i++) dst_is_src = dst_is_src || src[i] == dst;
+    if (!dst_is_src) { int rc = gusto_finish(dst); if (rc) return rc; }
     const size_t N = dst->N, n = dst->n, mp = dst->m_pub;
     if (tot > dst->gather_cap) {
         if (dst->d_gX) hipFree(dst->d_gX);
@@ -486,25 +484,47 @@ int gusto_gather_peer(gusto_handle dst, int n_src, const gusto_handle* src, cons
         HIPCHK(dst, dalloc(&dst->d_gX, tot * N * n)); HIPCHK(dst, dalloc(&dst->d_gU, tot * N * mp));
         dst->gather_cap = tot;
     }
+    // Every shard's copy is enqueued on ITS OWN handle's stream, right behind that shard's solve: no host-side wait for any
+    // solve before the first copy is queued, and the copies of different sources run side by side -- one xGMI link per source
+    // GPU, the direct fan-in of SURVEY.md 8(e) with all links busy -- instead of one after the other on dst's stream.
     size_t at = 0;
     for (int i = 0; i < n_src; i++) {
         gusto_handle q = src[i];
+        HIPCHK(q, hipSetDevice(q->device));
         if (q->device != dst->device) {   // (best effort: without peer access the runtime stages the copy)
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, dst->device, q->device) == hipSuccess && can) {
-                hipError_t e = hipDeviceEnablePeerAccess(q->device, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-                else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            if (hipDeviceCanAccessPeer(&can, q->device, dst->device) == hipSuccess && can) {
+                (void)hipDeviceEnablePeerAccess(dst->device, 0);
+                (void)hipGetLastError();
             }
         }
-        const double* su = q->trajopt ? q->d_Upub : q->d_U;
-        HIPCHK(dst, hipMemcpyPeerAsync(dst->d_gX + at * N * n, dst->device, q->d_X, q->device, sizeof(double) * q->B * N * n, dst->stream));
-        HIPCHK(dst, hipMemcpyPeerAsync(dst->d_gU + at * N * mp, dst->device, su, q->device, sizeof(double) * q->B * N * mp, dst->stream));
+        const double* su = q->d_U;
+        if (q->trajopt) {     // (device rows are (u | defect): compact them on the source GPU first, on the same stream)
+            if (!q->d_Upub) HIPCHK(q, dalloc(&q->d_Upub, (size_t)q->batch_cap * q->N * q->m_pub));
+            HIPCHK(q, copy_U(q, q->d_Upub, q->d_U, false, hipMemcpyDeviceToDevice));
+            su = q->d_Upub;
+        }
+        HIPCHK(q, hipMemcpyPeerAsync(dst->d_gX + at * N * n, dst->device, q->d_X, q->device, sizeof(double) * q->B * N * n, q->stream));
+        HIPCHK(q, hipMemcpyPeerAsync(dst->d_gU + at * N * mp, dst->device, su, q->device, sizeof(double) * q->B * N * mp, q->stream));
+        if (!q->ev_gather) HIPCHK(q, hipEventCreateWithFlags(&q->ev_gather, hipEventDisableTiming));
+        HIPCHK(q, hipEventRecord(q->ev_gather, q->stream));
         at += q->B;
     }
+    HIPCHK(dst, hipSetDevice(dst->device));
+    for (int i = 0; i < n_src; i++) HIPCHK(dst, hipStreamWaitEvent(dst->stream, src[i]->ev_gather, 0));
     if (X_host) HIPCHK(dst, hipMemcpyAsync(X_host, dst->d_gX, sizeof(double) * tot * N * n, hipMemcpyDeviceToHost, dst->stream));
     if (U_host) HIPCHK(dst, hipMemcpyAsync(U_host, dst->d_gU, sizeof(double) * tot * N * mp, hipMemcpyDeviceToHost, dst->stream));
     HIPCHK(dst, hipStreamSynchronize(dst->stream));
+    // the solves are complete now (their streams reached the copies): take their times and any latched scheduler error
+    int rc_all = GUSTO_OK;
+    for (int i = 0; i < n_src; i++) {
+        gusto_handle q = src[i];
+        HIPCHK(q, hipSetDevice(q->device));
+        const int rc = gusto_finish(q);
+        if (rc && !rc_all) { rc_all = rc; dst->err = "gusto_gather_peer: source: " + q->err; }
+    }
+    HIPCHK(dst, hipSetDevice(dst->device));
+    if (rc_all) return rc_all;
     if (X_dev) *X_dev = dst->d_gX;
     if (U_dev) *U_dev = dst->d_gU;
     if (B_total) *B_total = (int)tot;

@@ -36,6 +36,7 @@ struct gusto_handle_s {
     double *d_subD = nullptr, *d_subW = nullptr, *d_subT = nullptr, *d_subX = nullptr, *d_subU = nullptr, *d_subObj = nullptr;
     int *d_subSt = nullptr, *d_subIt = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_gather = nullptr;   // gusto_gather_peer: this shard's copy to the gathering GPU has been enqueued up to here
     double last_ms = 0.0;
     bool pending = false;  // a gusto_solve_async launch has not been waited for yet
     int probe_iters = 2, probe_min_batch = 2048;  // longest-first schedule (gusto_set_schedule)
