@@ -142,6 +142,24 @@ def test_c_program_through_the_c_abi(tmp_path):
     assert np.abs(xN - P.FREEFLYER_X_GOAL).max() < 1e-7 and np.abs(um - r["U"][25]).max() < 1e-3
 
 
+def test_c_program_replays_the_batch_wrappers(tmp_path):
+    """tests/c/c_abi_batch.c: the entry points GuSTOHIPBatch.jl's batch wrappers use -- gusto_set_env_batch, asynchronous shards,
+    gusto_gather_peer, gusto_set_active with one-trip solves and gusto_shoot, gusto_solve_trajopt_async + gusto_wait -- called in
+    the wrappers' order by a plain C program (no Julia in the image: this is their non-Python consumer) with its own checks."""
+    exe = os.path.join(tmp_path, "c_abi_batch")
+    lib = os.path.join(ROOT, "gusto.jl_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "c_abi_batch.c"), "-o", exe, "-L" + lib, "-lgusto_hip", "-lm",
+                           "-Wl,-rpath," + lib])
+    env = P.freeflyer_env()
+    boxes = os.path.join(tmp_path, "boxes.txt")
+    with open(boxes, "w") as f:
+        f.write(f"{len(env)}\n" + "\n".join(" ".join(repr(float(v)) for v in row) for row in env) + "\n")
+    out = subprocess.run([exe, boxes], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert out.stdout.split()[0] == "ok"
+
+
 def test_device_side_gather_of_two_handles():
     """gusto_gather_peer (SURVEY.md 8(b) threading row, 8(e)): the final gather of a one-process multi-GPU run in the C ABI --
     two handles (here on one GPU: the box has one) with shards of different sizes, solves still in flight when the gather
