@@ -1345,6 +1345,139 @@ template <int MODEL> GD void factor_sweep_1w(SweepView<MODEL> K, double* fail, P
     }
 }
 
+// The factor sweep of the single-input 3-state model (dubins_car: n = 3, m = 1, every per-knot operand in LDS), EVERY LANE THE
+// WHOLE STAGE -- a build switch (-DGUSTO_FACTOR_RED=1), measured and NOT the default.  factor_sweep_1w spreads the 9..12
+// entries of a 3 x 4 block over the wave and pays five dependent trips through LDS per stage (P -> T -> H -> S by readlane ->
+// W, Z -> P'): 2 250 cycles per stage at two waves per SIMD.  Here P, Pi, Gd (21 doubles) stay in the registers of every lane,
+// a stage is ~170 wave-uniform flops on operands read at wave-uniform LDS addresses, and lane 0 writes what the stage leaves
+// behind.  Same arithmetic in the same order: bit-identical results.  It is SLOWER (config 3: 114.6 against 104.2 ms,
+// profiles/r05_dubins_factor_red.txt): at two waves per SIMD the stage's latency is already covered by the other wave -- the
+// instruction issue of a SIMD is ~70 % busy -- and the redundant stage issues 129 VALU instructions more than the one it replaces.
+#ifndef GUSTO_FACTOR_RED
+#define GUSTO_FACTOR_RED 0
+#endif
+template <int MODEL> constexpr bool factor_red() {
+    using C = LdsC<MODEL, true>;
+    return GUSTO_FACTOR_RED && MT<MODEL>::n == 3 && MT<MODEL>::m == 1 && !MT<MODEL>::MFMA && C::KD_LDS && C::PG_LDS && C::PHICL_LDS && !C::PP_LDS;
+}
+template <int MODEL> GD void factor_sweep_red(SweepView<MODEL> K, double* fail, Prof& pf) {
+    using T = MT<MODEL>;
+    using R = Rec<MODEL>;
+    using C = LdsC<MODEL, true>;
+    constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n, NH = n * (n + 1) / 2;
+    static_assert(m == 1 && NH + NN < R::SNN, "single-input stage, P | Pi record");
+    const int tid = K.tid, N = K.N;
+    double P[NH], Pi[NN], Gd[NH];
+#pragma unroll
+    for (int e = 0; e < NH; e++) { P[e] = 0.0; Gd[e] = 0.0; }
+#pragma unroll
+    for (int e = 0; e < NN; e++) Pi[e] = 0.0;
+    K.pprec(N - 1)[tid] = 0.0;   // value function after the last knot (the whole padded record)
+    bool okall = true;
+    const bool goal[n] = { K.is_goal(0), K.is_goal(1), K.is_goal(2) };
+    for (int k = N - 1; k >= 0; k--) {
+        const auto PGs = K.pgl + k * NPG;
+        double pg[n][NZ], qq[NQ], cc[n];
+#pragma unroll
+        for (int l = 0; l < n; l++)
+#pragma unroll
+            for (int c = 0; c < NZ; c++) pg[l][c] = PGs[l * NZ + c];
+#pragma unroll
+        for (int e = 0; e < NQ; e++) qq[e] = K.kdl[k * C::KDS + e];
+#pragma unroll
+        for (int l = 0; l < n; l++) cc[l] = K.cv[k * n + l];
+        auto Pf = [&](int i, int j) { return P[sidx(i, j, n)]; };
+        // T = P [Phi Gam], H = QQ + [Phi Gam]^T T (upper triangle), Z = [Phi Gam]^T Pi (+E at the last knot)
+        double Tm[n][NZ], H[NZ][NZ], Z[NZ][n], rr[n], nn[n];
+#pragma unroll
+        for (int l = 0; l < n; l++)
+#pragma unroll
+            for (int c = 0; c < NZ; c++) {
+                double t = 0;
+#pragma unroll
+                for (int q = 0; q < n; q++) t += Pf(l, q) * pg[q][c];
+                Tm[l][c] = t;
+            }
+#pragma unroll
+        for (int i = 0; i < NZ; i++)
+#pragma unroll
+            for (int j = i; j < NZ; j++) {
+                double h = qq[sidx(i, j, NZ)];
+#pragma unroll
+                for (int l = 0; l < n; l++) h += pg[l][i] * Tm[l][j];
+                H[i][j] = h; H[j][i] = h;
+            }
+#pragma unroll
+        for (int c = 0; c < NZ; c++)
+#pragma unroll
+            for (int g = 0; g < n; g++) {
+                double z = 0;
+#pragma unroll
+                for (int l = 0; l < n; l++) z += pg[l][c] * Pi[l * n + g];
+                // E = [M^T C^T; b^T M^T C^T], M = (Phi + I)/2, M b = Gam/2; column g only for goal coordinates
+                const double ze = z + 0.5 * (pg[g][c] + ((c == g) ? 1.0 : 0.0));
+                Z[c][g] = (k == N - 1 && goal[g]) ? ze : z;
+            }
+#pragma unroll
+        for (int i = 0; i < n; i++) {   // r_k = P_k c_k and Pi_k^T c_k for the stage-parallel blocks
+            double a = 0, b = 0;
+#pragma unroll
+            for (int l = 0; l < n; l++) { a += Pf(i, l) * cc[l]; b += Pi[l * n + i] * cc[l]; }
+            rr[i] = a; nn[i] = b;
+        }
+        // S = H_uu (a scalar), L^-1 = S^-1/2 (chol_inv<1>)
+        const double d = H[n][n];
+        okall = okall && (d > 0.0);
+        const double Li = rsqrt_nr(d);
+        double W[n], V[n], Kk[n], Dk[n];
+#pragma unroll
+        for (int i = 0; i < n; i++) { W[i] = Li * H[i][n]; V[i] = Li * Z[n][i]; }
+#pragma unroll
+        for (int i = 0; i < n; i++) { Kk[i] = Li * W[i]; Dk[i] = Li * V[i]; }
+        double Pn[NH], Pin[NN], Ph[NN];
+#pragma unroll
+        for (int i = 0; i < n; i++)
+#pragma unroll
+            for (int j = 0; j < n; j++) {
+                if (i <= j) {
+                    Pn[sidx(i, j, n)] = H[i][j] - W[i] * W[j];
+                    Gd[sidx(i, j, n)] += V[i] * V[j];
+                }
+                Ph[i * n + j] = pg[i][j] - pg[i][n] * Kk[j];
+                Pin[i * n + j] = Z[i][j] - W[i] * V[j];
+            }
+        const double Sinv = Li * Li;
+#pragma unroll
+        for (int e = 0; e < NH; e++) P[e] = Pn[e];
+#pragma unroll
+        for (int e = 0; e < NN; e++) Pi[e] = Pin[e];
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < n; i++) { K.rv[k * n + i] = rr[i]; K.nun[k * n + i] = nn[i]; }
+#pragma unroll
+            for (int e = 0; e < NN; e++) K.Phicl[k * K.SPH + e] = Ph[e];
+#pragma unroll
+            for (int i = 0; i < n; i++) { K.kdl[k * C::KDS + i] = Kk[i]; K.kdl[k * C::KDS + n + i] = Dk[i]; }
+            K.kdl[k * C::KDS + 2 * n] = Sinv;
+            const auto rec = K.pprec(k - 1);   // (record -1 exists)
+#pragma unroll
+            for (int e = 0; e < NH; e++) rec[e] = Pn[e];
+#pragma unroll
+            for (int e = 0; e < NN; e++) rec[NH + e] = Pin[e];
+        }
+    }
+    // what the phases after the sweep read from LDS: P, Pi after knot 0 and the goal system Gd
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < n; i++)
+#pragma unroll
+            for (int j = 0; j < n; j++) { K.sP[i * n + j] = P[sidx(i, j, n)]; K.sPi[i * n + j] = Pi[i * n + j]; K.sGd[i * n + j] = Gd[sidx(i, j, n)]; }
+        if (!okall) *fail = 1.0;
+    }
+    pf.tick(PF_FCD);
+    K.sync();
+}
+
 // The factor sweep of the double-integrator model (MT::PG2, one wave, K | D | S^-1 in LDS), software pipelined.
 // A stage has two chains: the value function (P_k -> H -> chol(H_uu) -> W -> P_{k-1}: the critical path, ~45 dependent
 // flops of a wave-uniform 3 x 3 Cholesky in its middle) and the goal sensitivities (Pi_k -> Z -> V = L^-1 Z_u ->
@@ -2455,6 +2588,7 @@ template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof&
         } else factor_sweep_pg2<MODEL, false>(SweepView<MODEL>::make(K), fail, pf);
     }
 #endif
+    else if constexpr (factor_red<MODEL>()) factor_sweep_red<MODEL>(SweepView<MODEL>::make(K), fail, pf);
     else factor_sweep_1w<MODEL>(SweepView<MODEL>::make(K), fail, pf);
 }
 template <int MODEL> __device__ __noinline__ void backward_sweep_1w_call(typename Blk<MODEL, true>::Args a) {
