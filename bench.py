@@ -142,6 +142,60 @@ def committed_pmc(cfg):
         return None, None
 
 
+def live_pmc(cfg, timeout_s=150):
+    """HBM traffic of ONE launch of the config's batch measured in THIS run: two child `rocprofv3 --pmc` passes (FETCH_SIZE,
+    WRITE_SIZE -- each its own run, --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes) of
+    tools/pmc_probe.py, which solves the same seeded batch once and then reads + writes 1 GiB through a float64 elementwise
+    kernel as the calibration.  FETCH_SIZE x 2 on gfx950 (the calibration of this very run is reported next to it), both in
+    KiB.  None when rocprofv3 is absent or a pass fails (the caller falls back to the committed summary)."""
+    import collections, csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    # (a run that is itself being profiled does not start profilers of its own)
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    res = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                r = subprocess.run([exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", c, "--",
+                                    sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py"), str(cfg), "gusto"],
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+                for ln in r.stdout.splitlines():
+                    if ln.startswith("kernel_ms"):
+                        p = ln.split()
+                        res["kernel_ms"], res["kkt_solves"], res["scp_iters"] = float(p[1]), int(p[3]), int(p[5])
+                f = glob.glob(os.path.join(d, "**", f"{c}_counter_collection.csv"), recursive=True)
+                if not f:
+                    return None
+                acc = collections.defaultdict(float)
+                for row in csv.DictReader(open(f[0])):
+                    if row["Counter_Name"] == c:
+                        acc[row["Kernel_Name"]] += float(row["Counter_Value"])
+                k_scp = [k for k in acc if "scp_kernel" in k]
+                k_cal = [k for k in acc if "vectorized_elementwise" in k]
+                if not k_scp:
+                    return None
+                res[c] = acc[k_scp[0]]
+                if k_cal:   # the (a + 1.0) kernel reads 1 GiB and writes 1 GiB; the zeros fill only writes
+                    res["cal_" + c] = max(acc[k] for k in k_cal) if c == "FETCH_SIZE" else sum(acc[k] for k in k_cal)
+    except Exception:
+        return None
+    if "FETCH_SIZE" not in res or "WRITE_SIZE" not in res:
+        return None
+    res["fetch_bytes"], res["write_bytes"] = 2.0 * 1024 * res["FETCH_SIZE"], 1024.0 * res["WRITE_SIZE"]
+    res["traffic_bytes_per_launch"] = res["fetch_bytes"] + res["write_bytes"]
+    if res.get("cal_FETCH_SIZE"):
+        res["fetch_size_over_bytes_read"] = 1024.0 * res["cal_FETCH_SIZE"] / float(1 << 30)      # (0.5 on gfx950: the x 2 above)
+    if res.get("cal_WRITE_SIZE"):
+        res["write_size_over_bytes_written"] = 1024.0 * res["cal_WRITE_SIZE"] / float(2 << 30)
+    return res
+
+
 def valu_fp64(pmc, kkt_now):
     """fp64 VALU + matrix-core flops of one launch from the committed SQ counters (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 count
     wave instructions: x 64 lanes, an FMA = 2 flops; SQ_INSTS_VALU_MFMA_MOPS_F64 counts 512-flop units), scaled by the
@@ -209,6 +263,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="0 = the config's sample per usable host core (10-30 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the in-process lines of configs 3 / 4 / 5 (other_configs)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two child rocprofv3 --pmc passes (roofline.traffic then "
+                    "comes from the committed summary under profiles/)")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and overlapped extras (profiling runs: "
                     "every launch of the kernel is then one serial step, so rocprofv3's average is the step's)")
     ap.add_argument("--overlap", type=int, default=1,
@@ -398,14 +454,23 @@ def main():
         b_kkt, b_lin = algorithmic_bytes(n, m + (n if trajopt else 0), N_KNOTS)   # (TrajOpt: the n defect variables of a knot are controls)
         alg_bytes = b_kkt * ipm_iters + b_lin * scp_iters      # this rank, one launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        # HBM traffic of one solve: NOT measured in this run -- PMC counters need their own rocprofv3 --pmc passes
-        # (tools/profile_round.sh); the figure is read from the latest committed summary of the same workload
-        traffic, traffic_src, valu_flops = None, None, None
+        # HBM traffic of one solve.  PMC counters need their own rocprofv3 --pmc passes: the default single-GPU run makes
+        # them itself after the timed region (two child passes of tools/pmc_probe.py on the same seeded batch: live_pmc);
+        # otherwise, or if that fails, the figure is read from the latest committed summary of the same workload
+        traffic, traffic_src, valu_flops, traffic_live = None, None, None, None
         pmc, pmc_src = committed_pmc(args.config)
-        if pmc and not trajopt and B == CONFIGS[args.config]["B"]:
+        full_batch = not trajopt and B == CONFIGS[args.config]["B"]
+        if pmc and full_batch:
             traffic = pmc.get("traffic_bytes_per_launch")
             traffic_src = pmc_src + " (separate rocprofv3 --pmc passes, not this run)"
             valu_flops = valu_fp64(pmc, ipm_iters)
+        if full_batch and dist is None and not args.no_extras and not args.no_live_traffic:
+            traffic_live = live_pmc(args.config)
+            if traffic_live:
+                traffic_live["committed_traffic_bytes_per_launch"] = traffic
+                traffic = traffic_live["traffic_bytes_per_launch"]
+                traffic_src = ("live: two child rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE; KiB) of tools/pmc_probe.py in this run, "
+                               "one launch of the same seeded batch")
         others = None
         if args.config == 2 and not args.batch and dist is None and not args.no_extras and not trajopt and not args.no_other_configs:
             try:
@@ -430,6 +495,7 @@ def main():
                        "batches_in_flight": D},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None, "traffic_live": traffic_live,
                          # the issue-side bound next to the memory-side one (the kernels are register / LDS resident): fp64
                          # VALU (+ matrix core) flops of the launch from the committed SQ counters / this run's kernel time
                          "valu_fp64_tflops": (valu_flops / (avg_ms * 1e-3) / 1e12) if valu_flops else None,
