@@ -56,6 +56,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr bool ONE = ONEWAVE;
     static constexpr int MODEL_ID = MODEL;
+    static constexpr int SPH = R::SNN;   // stride of the Phicl records where the one-wave vector sweeps run on this view (the global, padded records)
     const KParams& P;
     int b, tid, N;
     int NTr;  // runtime block size (multi-wave problems)
@@ -723,6 +724,271 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail, Pr
         K.sync();
         pf.tick(PF_FCD);
     }
+}
+
+// factor_sweep_mw for a problem of ONE wave whose control block is large (the TrajOpt variants with N <= 64: m = 9 / 18 / 19 with
+// the defect controls, m > n).  The same stage -- the same sums in the same order, bit-identical results -- laid out for 64
+// lanes at compile time:
+//  * every round of an entry-per-lane product is unrolled, its LDS operands requested as a batch; the four Schur-type
+//    updates of phase 4 (P', Phicl, Pi', Gd) are formed by the lane of entry (i, j) from shared operands instead of four
+//    divergent passes over 4 n^2 entries;
+//  * the m x m Cholesky runs without LDS: lane i keeps row i of L in registers, column j takes row j from lane j by v_readlane
+//    (every lane forms the pivot itself: no synchronisation per column);
+//  * no global store under a branch (lanes without an entry aim at the padding slot of the record): the wait of a stage
+//    counts its stores instead of draining them.
+// Measured (freeflyerSE2 TrajOpt, B = 1024): the generic stage 12.9 k cycles, 49 % of a KKT solve (profiles/r05_trajopt_stage.txt).
+#ifndef GUSTO_TO_FACTOR_W1
+#define GUSTO_TO_FACTOR_W1 1
+#endif
+template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Prof& pf) {
+    using T = MT<MODEL>;
+    using R = Rec<MODEL>;
+    constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n, NZN = NZ * n;
+    constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64, RZ = (NZN + 63) / 64;
+    constexpr bool SMALL = n <= 8;   // (operands of all rounds of a phase in flight at once; the large models go round by round)
+    static_assert(2 * n + m <= 64 && R::SQQ == 64 * RQ && R::SNN > NN && R::SKD > 2 * m * n + m * m, "a lane per right-hand side; padded records");
+    const int tid = K.tid, N = K.N;
+    int hI[RQ], hJ[RQ];
+#pragma unroll
+    for (int r = 0; r < RQ; r++) { const int e = tid + 64 * r, ij = K.lut[e < NQ ? e : 0]; hI[r] = ij >> 8; hJ[r] = ij & 255; }
+#pragma unroll
+    for (int r = 0; r < RN; r++) { const int e = tid + 64 * r; if (e < NN) { K.sP[e] = 0; K.sPi[e] = 0; K.sGd[e] = 0; } }
+    double qq[RQ], pgn[RT];
+#pragma unroll
+    for (int r = 0; r < RQ; r++) qq[r] = K.QQ[(size_t)(N - 1) * R::SQQ + tid + 64 * r];   // (padded record: every lane has an entry)
+#pragma unroll
+    for (int r = 0; r < RT; r++) pgn[r] = 0.0;
+    {
+        const auto pg = K.PGk(N - 1);
+#pragma unroll
+        for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; if (e < NPG) K.sPG[((N - 1) & 1) * NPG + e] = pg[e]; }
+    }
+    bool okall = true;
+    K.sync();
+    for (int k = N - 1; k >= 0; k--) {
+        const double* PGs = K.sPG + (k & 1) * NPG;
+        // operands of knot k-1, in flight over the stage (clamped, unconditional)
+        double qqn[RQ];
+#pragma unroll
+        for (int r = 0; r < RQ; r++) qqn[r] = K.QQ[(size_t)((k > 0) ? k - 1 : 0) * R::SQQ + tid + 64 * r];
+        if constexpr (!T::LTI) {
+            const auto pg = K.PGk((k > 1) ? k - 1 : 1);
+#pragma unroll
+            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
+        }
+        // value function after knot k
+#pragma unroll
+        for (int r = 0; r < RN; r++) {
+            const int e = tid + 64 * r, ei = (e < NN) ? e : 0, eo = (e < NN) ? e : NN;
+            K.Paft[(size_t)k * R::SNN + eo] = K.sP[ei];
+            K.Piaft[(size_t)k * R::SNN + eo] = K.sPi[ei];
+        }
+        pf.tick(PF_FPRE);
+        // ---- phase 1: T = P [Phi Gam], Z = [Phi Gam]^T Pi (+ E at the last knot), r_k = P_k c_k, Pi_k^T c_k --------------
+        auto round_T = [&](int r, double* a, double* bb) {
+            const int e = tid + 64 * r, i = (e < NPG) ? e / NZ : 0, j = (e < NPG) ? e % NZ : 0;
+#pragma unroll
+            for (int l = 0; l < n; l++) { a[l] = K.sP[i * n + l]; bb[l] = PGs[l * NZ + j]; }
+        };
+        auto round_Z = [&](int r, double* a, double* bb, double& add) {
+            const int e2 = tid + 64 * r, j = (e2 < NZN) ? e2 / n : 0, g = (e2 < NZN) ? e2 % n : 0;
+#pragma unroll
+            for (int l = 0; l < n; l++) { a[l] = PGs[l * NZ + j]; bb[l] = K.sPi[l * n + g]; }
+            // E = [M^T C^T; b^T M^T C^T] (factor_sweep_mw): column g only for goal coordinates, no entry for a defect control
+            const double ev = 0.5 * (PGs[g * NZ + j] + ((j == g) ? 1.0 : 0.0));
+            add = (k == N - 1 && K.is_goal(g) && !(T::NDEF > 0 && j >= NZ - T::NDEF)) ? ev : 0.0;
+        };
+        auto dot = [&](const double* a, const double* bb, double s) {
+#pragma unroll
+            for (int l = 0; l < n; l++) s += a[l] * bb[l];
+            return s;
+        };
+        if constexpr (SMALL) {
+            double ta[RT][n], tb[RT][n], za[RZ][n], zb[RZ][n], zadd[RZ], ra[n], rb[n];
+            const bool isr = tid < n;
+            const int ri = isr ? tid : ((tid < 2 * n) ? tid - n : 0);
+#pragma unroll
+            for (int r = 0; r < RT; r++) round_T(r, ta[r], tb[r]);
+#pragma unroll
+            for (int r = 0; r < RZ; r++) round_Z(r, za[r], zb[r], zadd[r]);
+#pragma unroll
+            for (int l = 0; l < n; l++) { ra[l] = *(isr ? K.sP + ri * n + l : K.sPi + l * n + ri); rb[l] = K.cv[k * n + l]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RT; r++) { const double t = dot(ta[r], tb[r], 0.0); if (tid + 64 * r < NPG) K.sT[tid + 64 * r] = t; }
+#pragma unroll
+            for (int r = 0; r < RZ; r++) { const double z = dot(za[r], zb[r], 0.0) + zadd[r]; if (tid + 64 * r < NZN) K.sZ[tid + 64 * r] = z; }
+            { const double rr = dot(ra, rb, 0.0); if (tid < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = rr; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                double a[n], bb[n];
+                round_T(r, a, bb);
+                __builtin_amdgcn_sched_barrier(0);
+                const double t = dot(a, bb, 0.0);
+                if (tid + 64 * r < NPG) K.sT[tid + 64 * r] = t;
+            }
+#pragma unroll
+            for (int r = 0; r < RZ; r++) {
+                double a[n], bb[n], add;
+                round_Z(r, a, bb, add);
+                __builtin_amdgcn_sched_barrier(0);
+                const double z = dot(a, bb, 0.0) + add;
+                if (tid + 64 * r < NZN) K.sZ[tid + 64 * r] = z;
+            }
+            {
+                const bool isr = tid < n;
+                const int ri = isr ? tid : ((tid < 2 * n) ? tid - n : 0);
+                double ra[n], rb[n];
+#pragma unroll
+                for (int l = 0; l < n; l++) { ra[l] = *(isr ? K.sP + ri * n + l : K.sPi + l * n + ri); rb[l] = K.cv[k * n + l]; }
+                const double rr = dot(ra, rb, 0.0);
+                if (tid < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = rr;
+            }
+        }
+        K.sync();
+        pf.tick(PF_FAB);
+        // ---- phase 2: Hh = QQ + [Phi Gam]^T T (one triangle, mirrored) ----------------------------------------------------
+        auto round_H = [&](int r, double* a, double* bb) {
+#pragma unroll
+            for (int l = 0; l < n; l++) { a[l] = PGs[l * NZ + hI[r]]; bb[l] = K.sT[l * NZ + hJ[r]]; }
+        };
+        if constexpr (SMALL) {
+            double ha[RQ][n], hb[RQ][n];
+#pragma unroll
+            for (int r = 0; r < RQ; r++) round_H(r, ha[r], hb[r]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RQ; r++) {
+                const double h = dot(ha[r], hb[r], qq[r]);
+                if (tid + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = h; K.sHh[hJ[r] * NZ + hI[r]] = h; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RQ; r++) {
+                double a[n], bb[n];
+                round_H(r, a, bb);
+                __builtin_amdgcn_sched_barrier(0);
+                const double h = dot(a, bb, qq[r]);
+                if (tid + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = h; K.sHh[hJ[r] * NZ + hI[r]] = h; }
+            }
+        }
+        K.sync();
+        pf.tick(PF_F1);
+        // ---- phase 3: L = chol(S) (lane i = row i, row j by v_readlane), then a lane per right-hand side: W = L^-1 Hyu^T, V = L^-1 Zu,
+        //      K = L^-T W, D = L^-T V, S^-1 = L^-T L^-1 ---------------------------------------------------------------------
+        auto Lu = [&](int i, int j) -> decltype(auto) { return (K.sHh[(n + i) * NZ + n + j]); };
+        double rinv[m];   // 1 / L(i, i): wave-uniform
+        {
+            const int i = tid < m ? tid : m - 1;
+            double row[m];
+#pragma unroll
+            for (int l = 0; l < m; l++) row[l] = Lu(i, l);
+            static_for<0, m>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                double rj[j > 0 ? j : 1];
+#pragma unroll
+                for (int l = 0; l < j; l++) rj[l] = readlane_f64(row[l], j);
+                double d = readlane_f64(row[j], j), sacc = row[j];
+#pragma unroll
+                for (int l = 0; l < j; l++) { d -= rj[l] * rj[l]; sacc -= row[l] * rj[l]; }
+                const double r = rsqrt_nr(d);
+                okall = okall && (d > 0.0);
+                row[j] = sacc * r;
+                rinv[j] = r;
+            });
+#pragma unroll
+            for (int l = 0; l < m - 1; l++) if (tid < m && tid > l) Lu(tid, l) = row[l];
+        }
+        K.sync();
+        pf.tick(PF_F4);
+        {
+            const int c = tid < 2 * n + m ? tid : 0;
+            const bool isK = c < n, isD = c >= n && c < 2 * n;
+            const int g = isK ? c : (isD ? c - n : c - 2 * n);
+            double w[m], kk[m];
+#pragma unroll
+            for (int l = 0; l < m; l++) w[l] = isK ? K.sHh[g * NZ + n + l] : (isD ? K.sZ[(n + l) * n + g] : ((l == g) ? 1.0 : 0.0));
+#pragma unroll
+            for (int i = 0; i < m; i++) {      // L w = col
+                double sacc = w[i];
+#pragma unroll
+                for (int l = 0; l < i; l++) sacc -= Lu(i, l) * w[l];
+                w[i] = sacc * rinv[i];
+            }
+#pragma unroll
+            for (int i = m - 1; i >= 0; i--) {  // L^T kk = w
+                double sacc = w[i];
+#pragma unroll
+                for (int l = i + 1; l < m; l++) sacc -= Lu(l, i) * kk[l];
+                kk[i] = sacc * rinv[i];
+            }
+            const bool rhs = tid < 2 * n + m, kd = rhs && (isK || isD);
+            double* sw = isK ? K.sW : K.sV;
+            double* sk = isK ? K.sK : K.sD;
+            // (one unconditional store per entry: K and D at oK / oD + i n + g, column g of S^-1 at oS + i m + g, idle lanes in the padding)
+            const int gbase = !rhs ? 2 * m * n + m * m : (isK ? R::oK + g : (isD ? R::oD + g : R::oS + g));
+            const int gstr = !rhs ? 0 : ((isK || isD) ? n : m);
+#pragma unroll
+            for (int i = 0; i < m; i++) {
+                if (kd) { sw[i * n + g] = w[i]; sk[i * n + g] = kk[i]; }
+                K.KD[(size_t)k * R::SKD + gbase + i * gstr] = kk[i];
+            }
+        }
+        K.sync();
+        pf.tick(PF_F6);
+        // ---- phase 4: P' = Hyy - W^T W, Phicl = Phi - Gam K, Pi' = Zy - W^T V, Gd += V^T V: the lane of entry (i, j) all four ----
+#pragma unroll
+        for (int r = 0; r < RN; r++) {
+            const int e2 = tid + 64 * r;
+            const bool on = e2 < NN;
+            const int i = on ? e2 / n : 0, j = on ? e2 % n : 0;
+            double wi[m], wj[m], vi[m], vj[m], gi[m], kj[m];
+#pragma unroll
+            for (int l = 0; l < m; l++) {
+                wi[l] = K.sW[l * n + i]; wj[l] = K.sW[l * n + j]; vi[l] = K.sV[l * n + i]; vj[l] = K.sV[l * n + j];
+                gi[l] = PGs[i * NZ + n + l]; kj[l] = K.sK[l * n + j];
+            }
+            double pn = K.sHh[i * NZ + j], ph = PGs[i * NZ + j], pin = K.sZ[i * n + j], gd = K.sGd[on ? e2 : 0];
+            if constexpr (SMALL) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int l = 0; l < m; l++) pn -= wi[l] * wj[l];
+#pragma unroll
+            for (int l = 0; l < m; l++) ph -= gi[l] * kj[l];
+#pragma unroll
+            for (int l = 0; l < m; l++) pin -= wi[l] * vj[l];
+#pragma unroll
+            for (int l = 0; l < m; l++) gd += vi[l] * vj[l];
+            if (on) { K.sP[e2] = pn; K.sPi[e2] = pin; K.sGd[e2] = gd; }
+            K.Phicl[(size_t)k * R::SNN + (on ? e2 : NN)] = ph;
+        }
+        // operands of the next knot: knot 0 has Phi = 0, Gam = b_0 (x_1 is pinned)
+        if (k > 1) {
+#pragma unroll
+            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; if (e < NPG) K.sPG[((k - 1) & 1) * NPG + e] = T::LTI ? PGs[e] : pgn[r]; }
+        } else if (k == 1) {
+            double B[n * m];
+            Dyn<MODEL>::B(K.P.mp, B);
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                const int e = tid + 64 * r;
+                if (e < NPG) {
+                    const int i = e / NZ, j = e % NZ;
+                    double v = 0.0;
+#pragma unroll
+                    for (int q = 0; q < n * m; q++) if (j >= n && q == i * m + (j - n)) v = 0.5 * K.dt * B[q];
+                    if constexpr (T::NDEF > 0) { if (j >= n + (m - T::NDEF) && j - n - (m - T::NDEF) == i) v = 1.0; }
+                    K.sPG[0 * NPG + e] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RQ; r++) qq[r] = qqn[r];
+        pf.tick(PF_F7);
+        K.sync();
+        pf.tick(PF_FCD);
+    }
+    if (!okall) *fail = 1.0;
 }
 
 // p_{k-1} = Phicl_k^T (p_k + r_k) + qt_k, k = N-1..1; pv[k] holds qt_k on entry and p_k on exit
@@ -2091,7 +2357,8 @@ template <int MODEL, bool NOPP> GD void factor_sweep_mfma(SweepView<MODEL> K, do
 #ifndef GUSTO_SWEEP_RING
 #define GUSTO_SWEEP_RING 4
 #endif
-template <class BLK> GD void backward_sweep_1w(BLK K) {
+template <class BLKA> GD void backward_sweep_1w(BLKA K) {
+    using BLK = std::remove_cv_t<std::remove_reference_t<BLKA>>;   // (a SweepView by value, or a Blk by reference)
     constexpr int n = BLK::n, C = 64 / n, PS = n > 8 ? 4 : 1;
     // 12/13-state models: the n-vector goes from group to group through 64 doubles of LDS (one ds_write per lane, broadcast
     // ds_reads at compile-time addresses) instead of 2 n v_readlane per knot
@@ -2253,7 +2520,8 @@ template <class BLK> GD void backward_sweep_1w(BLK K) {
 }
 
 // forward: dy_k = Phicl_k dy_{k-1} + ct_k, k = 0..N-1; dY[k] holds ct_k on entry and dy_k on exit
-template <class BLK> GD void forward_sweep_1w(BLK K) {
+template <class BLKA> GD void forward_sweep_1w(BLKA K) {
+    using BLK = std::remove_cv_t<std::remove_reference_t<BLKA>>;   // (a SweepView by value, or a Blk by reference)
     constexpr int n = BLK::n, C = 64 / n, PS = n > 8 ? 4 : 1;
     constexpr bool XL = n > GUSTO_XL_MIN;   // (see backward_sweep_1w)
     double* ex = K.sHh;
@@ -2569,10 +2837,24 @@ template <int MODEL> __device__ __noinline__ void factor_sweep_1w_call(typename 
 // allocation of their own, like the one-wave sweeps of the 12/13-state GuSTO kernels
 template <int MODEL, class BLK> __device__ __noinline__ void factor_sweep_mw_call(typename BLK::Args a, Prof* pf) {
     BLK K(a, gusto_dyn_lds);
+    if constexpr (GUSTO_TO_FACTOR_W1 && MT<MODEL>::m >= GUSTO_COOP_CHOL_MIN) {
+        if (K.NTr <= 64) { factor_sweep_w1<MODEL>(K, gusto_dyn_lds + BLK::C::misc + 8, *pf); return; }
+    }
     factor_sweep_mw<MODEL>(K, gusto_dyn_lds + BLK::C::misc + 8, *pf);
 }
-template <class BLK> __device__ __noinline__ void backward_sweep_mw_call(typename BLK::Args a) { BLK K(a, gusto_dyn_lds); backward_sweep_mw(K); }
-template <class BLK> __device__ __noinline__ void forward_sweep_mw_call(typename BLK::Args a) { BLK K(a, gusto_dyn_lds); forward_sweep_mw(K); }
+// (a problem of ONE wave -- every TrajOpt launch with N <= 64 -- takes the one-wave vector sweeps: groups of n lanes for
+// consecutive knots, one batch of loads per chunk of the chain instead of a trip to the Phicl record per knot)
+#ifndef GUSTO_TO_SWEEP_1W
+#define GUSTO_TO_SWEEP_1W 1
+#endif
+template <class BLK> __device__ __noinline__ void backward_sweep_mw_call(typename BLK::Args a) {
+    BLK K(a, gusto_dyn_lds);
+    if (GUSTO_TO_SWEEP_1W && K.NTr <= 64) backward_sweep_1w<const BLK&>(K); else backward_sweep_mw(K);
+}
+template <class BLK> __device__ __noinline__ void forward_sweep_mw_call(typename BLK::Args a) {
+    BLK K(a, gusto_dyn_lds);
+    if (GUSTO_TO_SWEEP_1W && K.NTr <= 64) forward_sweep_1w<const BLK&>(K); else forward_sweep_mw(K);
+}
 template <int MODEL, class BLK> GD void factor_sweep(BLK& K, double* fail, Prof& pf) {
     if constexpr (!BLK::ONE && MT<MODEL>::SWEEP_CALL && MT<MODEL>::NDEF > 0) factor_sweep_mw_call<MODEL, BLK>(K.args(), &pf);
     else if constexpr (!BLK::ONE) factor_sweep_mw<MODEL>(K, fail, pf);
