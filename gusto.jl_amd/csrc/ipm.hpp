@@ -767,31 +767,37 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
     K.sync();
     for (int k = N - 1; k >= 0; k--) {
         const double* PGs = K.sPG + (k & 1) * NPG;
+        // (large models: the entry indices of the rounds -- e / NZ, e % NZ, the table look-ups, dozens of LDS addresses -- are
+        // formed again in every stage from a lane id the compiler cannot see through; hoisted out of the knot loop, as it
+        // does unasked, they do not fit the register file and the stage makes ~300 scratch accesses: 652 against 465 ms per
+        // astrobeeSE3 TrajOpt batch of 256)
+        int tl = tid;
+        if constexpr (!SMALL) asm volatile("" : "+v"(tl));
         // operands of knot k-1, in flight over the stage (clamped, unconditional)
         double qqn[RQ];
 #pragma unroll
-        for (int r = 0; r < RQ; r++) qqn[r] = K.QQ[(size_t)((k > 0) ? k - 1 : 0) * R::SQQ + tid + 64 * r];
+        for (int r = 0; r < RQ; r++) qqn[r] = K.QQ[(size_t)((k > 0) ? k - 1 : 0) * R::SQQ + tl + 64 * r];
         if constexpr (!T::LTI) {
             const auto pg = K.PGk((k > 1) ? k - 1 : 1);
 #pragma unroll
-            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
+            for (int r = 0; r < RT; r++) { const int e = tl + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
         }
         // value function after knot k
 #pragma unroll
         for (int r = 0; r < RN; r++) {
-            const int e = tid + 64 * r, ei = (e < NN) ? e : 0, eo = (e < NN) ? e : NN;
+            const int e = tl + 64 * r, ei = (e < NN) ? e : 0, eo = (e < NN) ? e : NN;
             K.Paft[(size_t)k * R::SNN + eo] = K.sP[ei];
             K.Piaft[(size_t)k * R::SNN + eo] = K.sPi[ei];
         }
         pf.tick(PF_FPRE);
         // ---- phase 1: T = P [Phi Gam], Z = [Phi Gam]^T Pi (+ E at the last knot), r_k = P_k c_k, Pi_k^T c_k --------------
         auto round_T = [&](int r, double* a, double* bb) {
-            const int e = tid + 64 * r, i = (e < NPG) ? e / NZ : 0, j = (e < NPG) ? e % NZ : 0;
+            const int e = tl + 64 * r, i = (e < NPG) ? e / NZ : 0, j = (e < NPG) ? e % NZ : 0;
 #pragma unroll
             for (int l = 0; l < n; l++) { a[l] = K.sP[i * n + l]; bb[l] = PGs[l * NZ + j]; }
         };
         auto round_Z = [&](int r, double* a, double* bb, double& add) {
-            const int e2 = tid + 64 * r, j = (e2 < NZN) ? e2 / n : 0, g = (e2 < NZN) ? e2 % n : 0;
+            const int e2 = tl + 64 * r, j = (e2 < NZN) ? e2 / n : 0, g = (e2 < NZN) ? e2 % n : 0;
 #pragma unroll
             for (int l = 0; l < n; l++) { a[l] = PGs[l * NZ + j]; bb[l] = K.sPi[l * n + g]; }
             // E = [M^T C^T; b^T M^T C^T] (factor_sweep_mw): column g only for goal coordinates, no entry for a defect control
@@ -805,8 +811,8 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
         };
         if constexpr (SMALL) {
             double ta[RT][n], tb[RT][n], za[RZ][n], zb[RZ][n], zadd[RZ], ra[n], rb[n];
-            const bool isr = tid < n;
-            const int ri = isr ? tid : ((tid < 2 * n) ? tid - n : 0);
+            const bool isr = tl < n;
+            const int ri = isr ? tl : ((tl < 2 * n) ? tl - n : 0);
 #pragma unroll
             for (int r = 0; r < RT; r++) round_T(r, ta[r], tb[r]);
 #pragma unroll
@@ -815,10 +821,10 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
             for (int l = 0; l < n; l++) { ra[l] = *(isr ? K.sP + ri * n + l : K.sPi + l * n + ri); rb[l] = K.cv[k * n + l]; }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < RT; r++) { const double t = dot(ta[r], tb[r], 0.0); if (tid + 64 * r < NPG) K.sT[tid + 64 * r] = t; }
+            for (int r = 0; r < RT; r++) { const double t = dot(ta[r], tb[r], 0.0); if (tl + 64 * r < NPG) K.sT[tl + 64 * r] = t; }
 #pragma unroll
-            for (int r = 0; r < RZ; r++) { const double z = dot(za[r], zb[r], 0.0) + zadd[r]; if (tid + 64 * r < NZN) K.sZ[tid + 64 * r] = z; }
-            { const double rr = dot(ra, rb, 0.0); if (tid < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = rr; }
+            for (int r = 0; r < RZ; r++) { const double z = dot(za[r], zb[r], 0.0) + zadd[r]; if (tl + 64 * r < NZN) K.sZ[tl + 64 * r] = z; }
+            { const double rr = dot(ra, rb, 0.0); if (tl < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = rr; }
         } else {
 #pragma unroll
             for (int r = 0; r < RT; r++) {
@@ -826,7 +832,7 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
                 round_T(r, a, bb);
                 __builtin_amdgcn_sched_barrier(0);
                 const double t = dot(a, bb, 0.0);
-                if (tid + 64 * r < NPG) K.sT[tid + 64 * r] = t;
+                if (tl + 64 * r < NPG) K.sT[tl + 64 * r] = t;
             }
 #pragma unroll
             for (int r = 0; r < RZ; r++) {
@@ -834,16 +840,16 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
                 round_Z(r, a, bb, add);
                 __builtin_amdgcn_sched_barrier(0);
                 const double z = dot(a, bb, 0.0) + add;
-                if (tid + 64 * r < NZN) K.sZ[tid + 64 * r] = z;
+                if (tl + 64 * r < NZN) K.sZ[tl + 64 * r] = z;
             }
             {
-                const bool isr = tid < n;
-                const int ri = isr ? tid : ((tid < 2 * n) ? tid - n : 0);
+                const bool isr = tl < n;
+                const int ri = isr ? tl : ((tl < 2 * n) ? tl - n : 0);
                 double ra[n], rb[n];
 #pragma unroll
                 for (int l = 0; l < n; l++) { ra[l] = *(isr ? K.sP + ri * n + l : K.sPi + l * n + ri); rb[l] = K.cv[k * n + l]; }
                 const double rr = dot(ra, rb, 0.0);
-                if (tid < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = rr;
+                if (tl < 2 * n) (isr ? K.rv : K.nun)[k * n + ri] = rr;
             }
         }
         K.sync();
@@ -853,6 +859,10 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
 #pragma unroll
             for (int l = 0; l < n; l++) { a[l] = PGs[l * NZ + hI[r]]; bb[l] = K.sT[l * NZ + hJ[r]]; }
         };
+        if constexpr (!SMALL) {
+#pragma unroll
+            for (int r = 0; r < RQ; r++) { const int e = tl + 64 * r, ij = K.lut[e < NQ ? e : 0]; hI[r] = ij >> 8; hJ[r] = ij & 255; }
+        }
         if constexpr (SMALL) {
             double ha[RQ][n], hb[RQ][n];
 #pragma unroll
@@ -861,7 +871,7 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
 #pragma unroll
             for (int r = 0; r < RQ; r++) {
                 const double h = dot(ha[r], hb[r], qq[r]);
-                if (tid + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = h; K.sHh[hJ[r] * NZ + hI[r]] = h; }
+                if (tl + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = h; K.sHh[hJ[r] * NZ + hI[r]] = h; }
             }
         } else {
 #pragma unroll
@@ -870,7 +880,7 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
                 round_H(r, a, bb);
                 __builtin_amdgcn_sched_barrier(0);
                 const double h = dot(a, bb, qq[r]);
-                if (tid + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = h; K.sHh[hJ[r] * NZ + hI[r]] = h; }
+                if (tl + 64 * r < NQ) { K.sHh[hI[r] * NZ + hJ[r]] = h; K.sHh[hJ[r] * NZ + hI[r]] = h; }
             }
         }
         K.sync();
@@ -880,7 +890,7 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
         auto Lu = [&](int i, int j) -> decltype(auto) { return (K.sHh[(n + i) * NZ + n + j]); };
         double rinv[m];   // 1 / L(i, i): wave-uniform
         {
-            const int i = tid < m ? tid : m - 1;
+            const int i = tl < m ? tl : m - 1;
             double row[m];
 #pragma unroll
             for (int l = 0; l < m; l++) row[l] = Lu(i, l);
@@ -898,12 +908,12 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
                 rinv[j] = r;
             });
 #pragma unroll
-            for (int l = 0; l < m - 1; l++) if (tid < m && tid > l) Lu(tid, l) = row[l];
+            for (int l = 0; l < m - 1; l++) if (tl < m && tl > l) Lu(tl, l) = row[l];
         }
         K.sync();
         pf.tick(PF_F4);
         {
-            const int c = tid < 2 * n + m ? tid : 0;
+            const int c = tl < 2 * n + m ? tl : 0;
             const bool isK = c < n, isD = c >= n && c < 2 * n;
             const int g = isK ? c : (isD ? c - n : c - 2 * n);
             double w[m], kk[m];
@@ -923,7 +933,7 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
                 for (int l = i + 1; l < m; l++) sacc -= Lu(l, i) * kk[l];
                 kk[i] = sacc * rinv[i];
             }
-            const bool rhs = tid < 2 * n + m, kd = rhs && (isK || isD);
+            const bool rhs = tl < 2 * n + m, kd = rhs && (isK || isD);
             double* sw = isK ? K.sW : K.sV;
             double* sk = isK ? K.sK : K.sD;
             // (one unconditional store per entry: K and D at oK / oD + i n + g, column g of S^-1 at oS + i m + g, idle lanes in the padding)
@@ -940,7 +950,7 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
         // ---- phase 4: P' = Hyy - W^T W, Phicl = Phi - Gam K, Pi' = Zy - W^T V, Gd += V^T V: the lane of entry (i, j) all four ----
 #pragma unroll
         for (int r = 0; r < RN; r++) {
-            const int e2 = tid + 64 * r;
+            const int e2 = tl + 64 * r;
             const bool on = e2 < NN;
             const int i = on ? e2 / n : 0, j = on ? e2 % n : 0;
             double wi[m], wj[m], vi[m], vj[m], gi[m], kj[m];
@@ -965,13 +975,13 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
         // operands of the next knot: knot 0 has Phi = 0, Gam = b_0 (x_1 is pinned)
         if (k > 1) {
 #pragma unroll
-            for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; if (e < NPG) K.sPG[((k - 1) & 1) * NPG + e] = T::LTI ? PGs[e] : pgn[r]; }
+            for (int r = 0; r < RT; r++) { const int e = tl + 64 * r; if (e < NPG) K.sPG[((k - 1) & 1) * NPG + e] = T::LTI ? PGs[e] : pgn[r]; }
         } else if (k == 1) {
             double B[n * m];
             Dyn<MODEL>::B(K.P.mp, B);
 #pragma unroll
             for (int r = 0; r < RT; r++) {
-                const int e = tid + 64 * r;
+                const int e = tl + 64 * r;
                 if (e < NPG) {
                     const int i = e / NZ, j = e % NZ;
                     double v = 0.0;
