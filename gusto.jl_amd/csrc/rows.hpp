@@ -18,6 +18,9 @@ namespace gusto {
 #ifndef GUSTO_GOAL_BATCH
 #define GUSTO_GOAL_BATCH 1   // 0: BoxGoal rows one at a time (rounds 1-4)
 #endif
+#ifndef GUSTO_TO_ROW_BATCH
+#define GUSTO_TO_ROW_BATCH 1   // 0: the rows of the TrajOpt subproblem one memory round trip each (rounds 3-4)
+#endif
 #ifndef GUSTO_OBS_BATCH
 #define GUSTO_OBS_BATCH 4
 #endif
@@ -105,8 +108,19 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
         // weight mu (:222-235; c.omega = mu), the dynamics as mu |d_kj| on the defect controls (:257-275, the pair +-mu d <= v)
         constexpr bool is2 = MODEL == GUSTO_TO_FREEFLYER_SE2, man = MODEL == GUSTO_TO_ASTROBEE_SE3_MANIFOLD;
         constexpr int nv = is2 ? 2 : 3, iw = is2 ? 5 : (man ? 10 : 9), nw = is2 ? 1 : 3, m0 = T::m - T::NDEF;
+        // The row state of up to OBS_BATCH rows is fetched in one batch before they are processed (Op::obs_load, the buffer of the
+        // obstacle batches; round 5): one row at a time, each row's loads wait behind the stores of the row before it and a pass
+        // pays a memory round trip per row -- 17 + the active obstacles per knot here, 105 k cycles per pass for the freeflyer.
+        // Same rows in the same order: bit-identical.
+        constexpr bool FB = GUSTO_FIX_BATCH && GUSTO_TO_ROW_BATCH && Op::FIX_BATCH;
+#define GUSTO_FXQ(q) (FB ? FX_OBS + (q) : -1)
+        auto batch = [&](int s0, int s1, int s2, int s3) {
+            if constexpr (FB) { const int fs[OBS_BATCH] = {s0, s1, s2, s3}; op.obs_load(fs); }
+        };
+        static_assert(OBS_BATCH == 4 || !FB, "batches of four rows");
         if constexpr (!man) {
-            quad_row<false, 0, n>(op, 0, ROW_HARD, xs, one, c.xp, -c.Delta, 1.0 / c.Delta, 0.0);
+            batch(0, 1, 2, 2);
+            quad_row<false, 0, n, GUSTO_FXQ(0)>(op, 0, ROW_HARD, xs, one, c.xp, -c.Delta, 1.0 / c.Delta, 0.0);
         } else {
             // the manifold model registers no trust region row (astrobee_se3_manifold.jl:601); its convex_state_eq row, the
             // linearised quaternion norm (:308-313), is HARD in TrajOpt (scp_trajopt.jl:200-208): the band |h| <= TRAJOPT_EQ_BAND;
@@ -116,15 +130,42 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
             double bp[4], bm[4], c0 = qn - 1.0;
 #pragma unroll
             for (int j = 0; j < 4; j++) { bp[j] = qp[j] / qn; bm[j] = -bp[j]; c0 -= qp[j] * qp[j] / qn; }
-            lin_row<false, 6, 4>(op, 0, ROW_HARD, xs, bm, -c0, 1.0 / TRAJOPT_EQ_BAND, 1.0);   // (scaled to O(1) like every hard row)
-            lin_row<false, 6, 4>(op, 3, ROW_HARD, xs, bp, c0, 1.0 / TRAJOPT_EQ_BAND, 1.0);
+            batch(0, 3, 4, 4);
+            lin_row<false, 6, 4, GUSTO_FXQ(0)>(op, 0, ROW_HARD, xs, bm, -c0, 1.0 / TRAJOPT_EQ_BAND, 1.0);   // (scaled to O(1) like every hard row)
+            lin_row<false, 6, 4, GUSTO_FXQ(1)>(op, 3, ROW_HARD, xs, bp, c0, 1.0 / TRAJOPT_EQ_BAND, 1.0);
             const double m1 = -1.0;
-            lin_row<false, 6, 1>(op, 4, ROW_PEN, xs, &m1, 0.0, kw, 0.0);
+            lin_row<false, 6, 1, GUSTO_FXQ(2)>(op, 4, ROW_PEN, xs, &m1, 0.0, kw, 0.0);
+            batch(1, 2, 2, 2);
         }
-        quad_row<false, 3, nv>(op, 1, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
-        quad_row<false, iw, nw>(op, 2, ROW_PEN, xs, one, nullptr, -mp.hard_limit_omega * mp.hard_limit_omega, kw, 0.0);
+        quad_row<false, 3, nv, GUSTO_FXQ(man ? 0 : 1)>(op, 1, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
+        quad_row<false, iw, nw, GUSTO_FXQ(man ? 1 : 2)>(op, 2, ROW_PEN, xs, one, nullptr, -mp.hard_limit_omega * mp.hard_limit_omega, kw, 0.0);
         uint64_t mk = c.mask;
-        while (mk) {   // (one at a time: this path is not tuned)
+        if constexpr (FB) {
+            while (mk) {   // (the obstacle rows in batches, as in the GuSTO branch below)
+                int oi[OBS_BATCH], oslot[OBS_BATCH];
+                bool ov[OBS_BATCH];
+                int last = 0;
+#pragma unroll
+                for (int q = 0; q < OBS_BATCH; q++) {
+                    ov[q] = mk != 0;
+                    if (ov[q]) { last = __ffsll((unsigned long long)mk) - 1; mk &= mk - 1; }
+                    oi[q] = last; oslot[q] = slot_obs + last;
+                }
+                double ob[OBS_BATCH][T::WS], oc[OBS_BATCH];
+#pragma unroll
+                for (int q = 0; q < OBS_BATCH; q++) {
+#pragma unroll
+                    for (int j = 0; j < T::WS; j++) ob[q][j] = -(c.obs_nh + (size_t)(oi[q] * T::WS + j) * (size_t)c.N)[c.k];
+                    oc[q] = (c.obs_c0 + (size_t)oi[q] * (size_t)c.N)[c.k];
+                }
+                op.obs_load(oslot);
+                static_for<0, OBS_BATCH>([&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
+                    if (ov[q]) lin_row<false, 0, T::WS, FX_OBS + q>(op, oslot[q], ROW_PEN, xs, ob[q], oc[q], kw, 0.0);
+                });
+            }
+        } else
+        while (mk) {   // (one at a time)
             const int oi = __ffsll((unsigned long long)mk) - 1;
             mk &= mk - 1;
             double ob[T::WS];
@@ -133,22 +174,34 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
             const double oc = (c.obs_c0 + (size_t)oi * (size_t)c.N)[c.k];
             lin_row<false, 0, T::WS>(op, slot_obs + oi, ROW_PEN, xs, ob, oc, kw, 0.0);
         }
-        if (c.k < c.N - 1) {
+        {
+            // the NHU control rows -- the two acceleration bounds (not at the last knot), then mu |d_kj| as the pair +-mu d <= v per
+            // defect (the defect of the last knot moves nothing and is driven to zero) -- in batches of four
             constexpr int nf = is2 ? 2 : 3, im = is2 ? 2 : 3, nm = is2 ? 1 : 3;
             double af[nf], am[nm];
 #pragma unroll
             for (int j = 0; j < nf; j++) af[j] = 1.0 / (mp.mass * mp.mass);
 #pragma unroll
             for (int j = 0; j < nm; j++) { const double ji = 1.0 / mp.Jdiag[is2 ? 2 : j]; am[j] = ji * ji; }
-            quad_row<true, 0, nf>(op, slot_u, ROW_PEN, us, af, nullptr, -mp.hard_limit_accel * mp.hard_limit_accel, kw, 0.0);
-            quad_row<true, im, nm>(op, slot_u + 1, ROW_PEN, us, am, nullptr, -mp.hard_limit_alpha * mp.hard_limit_alpha, kw, 0.0);
-        }
-        static_for<0, T::NDEF>([&](auto J) {   // mu |d_kj| (the defect of the last knot moves nothing and is driven to zero)
-            constexpr int j = decltype(J)::value;
             const double p1 = 1.0, m1 = -1.0;
-            lin_row<true, m0 + j, 1>(op, slot_u + 2 + 2 * j, ROW_PEN, us, &p1, 0.0, kw, 0.0);
-            lin_row<true, m0 + j, 1>(op, slot_u + 3 + 2 * j, ROW_PEN, us, &m1, 0.0, kw, 0.0);
-        });
+            static_for<0, (T::NHU + 3) / 4>([&](auto BB) {
+                constexpr int b0 = 4 * decltype(BB)::value;
+                auto sl = [&](int q) { return slot_u + (b0 + q < T::NHU ? b0 + q : T::NHU - 1); };
+                batch(sl(0), sl(1), sl(2), sl(3));
+                static_for<0, 4>([&](auto Q) {
+                    constexpr int q = decltype(Q)::value, r = b0 + q;
+                    if constexpr (r == 0) {
+                        if (c.k < c.N - 1) quad_row<true, 0, nf, GUSTO_FXQ(q)>(op, slot_u, ROW_PEN, us, af, nullptr, -mp.hard_limit_accel * mp.hard_limit_accel, kw, 0.0);
+                    } else if constexpr (r == 1) {
+                        if (c.k < c.N - 1) quad_row<true, im, nm, GUSTO_FXQ(q)>(op, slot_u + 1, ROW_PEN, us, am, nullptr, -mp.hard_limit_alpha * mp.hard_limit_alpha, kw, 0.0);
+                    } else if constexpr (r < T::NHU) {
+                        constexpr int j = (r - 2) / 2;
+                        lin_row<true, m0 + j, 1, GUSTO_FXQ(q)>(op, slot_u + r, ROW_PEN, us, ((r - 2) % 2 == 0) ? &p1 : &m1, 0.0, kw, 0.0);
+                    }
+                });
+            });
+        }
+#undef GUSTO_FXQ
     } else
     if constexpr (MODEL == GUSTO_FREEFLYER_SE2 || MODEL == GUSTO_ASTROBEE_SE3 || MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD) {
         constexpr bool is2 = MODEL == GUSTO_FREEFLYER_SE2, man = MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD;
