@@ -133,7 +133,8 @@ def committed_pmc(cfg):
     """The latest committed PMC summary of a config (profiles/r*_pmc.json for config 2, r*_pmc_config{c}.json otherwise;
     separate rocprofv3 --pmc passes, tools/profile_round.sh) or None."""
     import glob
-    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json" if cfg == 2 else f"r*_pmc_config{cfg}.json")))
+    pat = "r*_pmc_trajopt_config2.json" if cfg == "trajopt" else ("r*_pmc.json" if cfg == 2 else f"r*_pmc_config{cfg}.json")
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not pmc:
         return None, None
     try:
@@ -142,7 +143,7 @@ def committed_pmc(cfg):
         return None, None
 
 
-def live_pmc(cfg, timeout_s=150):
+def live_pmc(cfg, timeout_s=150, algo="gusto"):
     """HBM traffic of ONE launch of the config's batch measured in THIS run: two child `rocprofv3 --pmc` passes (FETCH_SIZE,
     WRITE_SIZE -- each its own run, --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes) of
     tools/pmc_probe.py, which solves the same seeded batch once and then reads + writes 1 GiB through a float64 elementwise
@@ -163,7 +164,7 @@ def live_pmc(cfg, timeout_s=150):
                 env.pop(k, None)
             for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 r = subprocess.run([exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", c, "--",
-                                    sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py"), str(cfg), "gusto"],
+                                    sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py"), str(cfg), algo],
                                    cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
                 for ln in r.stdout.splitlines():
                     if ln.startswith("kernel_ms"):
@@ -176,7 +177,7 @@ def live_pmc(cfg, timeout_s=150):
                 for row in csv.DictReader(open(f[0])):
                     if row["Counter_Name"] == c:
                         acc[row["Kernel_Name"]] += float(row["Counter_Value"])
-                k_scp = [k for k in acc if "scp_kernel" in k]
+                k_scp = [k for k in acc if ("trajopt_kernel" if algo == "trajopt" else "scp_kernel") in k]
                 k_cal = [k for k in acc if "vectorized_elementwise" in k]
                 if not k_scp:
                     return None
@@ -248,6 +249,40 @@ def other_configs(P, g, torch, dev_ord, steps=3, warmup=1):
             "traffic_over_algorithmic": (pmc or {}).get("traffic_over_algorithmic"), "traffic_source": src,
             "setup_s": time.perf_counter() - t0 - float(np.sum(wall)),
         }
+    # ... and the second SCP algorithm behind the same seam: TrajOpt on the freeflyerSE2 batch of `bench.py --algo trajopt`
+    # (1024 problems through the whole penalty / convex / trust-region schedule; value = problems per second)
+    try:
+        t0 = time.perf_counter()
+        c, B = CONFIGS[2], 1024
+        model, boxes, spheres, (x0, glo, ghi, tf) = workload(P, g, 2, B, 0)
+        n, m = g.MODEL_DIMS[model]
+        tp = g.default_trajopt_params(model)
+        cap = tp.max_penalty_iteration * tp.max_convex_iteration * tp.max_trust_iteration
+        s = g.TrajOptSolver(model, c["N"], B, hist_cap=2 * cap + 16, device=dev_ord, boxes=boxes, spheres=spheres)
+        ms, wall = [], []
+        for i in range(warmup + steps):
+            t1 = time.perf_counter()
+            s.set_problems(x0, glo, ghi, tf)
+            s.solve(cap)
+            if i >= warmup:
+                wall.append(time.perf_counter() - t1)
+                ms.append(s.last_solve_ms())
+        st = s.status()
+        s.close()
+        b_kkt, b_lin = algorithmic_bytes(n, m + n, c["N"])     # (the n defect variables of a knot are controls)
+        kkt, scp = int(st["ipm_iters"].sum()), int(st["iterations"].sum())
+        avg = float(np.mean(ms))
+        pmc, src = committed_pmc("trajopt")
+        out["trajopt"] = {
+            "workload": f"TrajOpt (gusto_solve_trajopt), freeflyerSE2 batch={B}, N={c['N']}, fp64", "steps": steps,
+            "ms_per_step_host_to_host": 1e3 * float(np.mean(wall)), "avg_launch_ms": avg, "value": B / (avg * 1e-3),
+            "unit": "problems/s through the whole schedule (kernel time)", "problems": B, "kkt_solves_per_launch": kkt, "subproblems_per_launch": scp,
+            "frac": (b_kkt * kkt + b_lin * scp) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic_over_algorithmic": (pmc or {}).get("traffic_over_algorithmic"), "traffic_source": src,
+            "setup_s": time.perf_counter() - t0 - float(np.sum(wall)),
+        }
+    except Exception as e:
+        out["trajopt"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return out
 
 
@@ -464,8 +499,12 @@ def main():
             traffic = pmc.get("traffic_bytes_per_launch")
             traffic_src = pmc_src + " (separate rocprofv3 --pmc passes, not this run)"
             valu_flops = valu_fp64(pmc, ipm_iters)
-        if full_batch and dist is None and not args.no_extras and not args.no_live_traffic:
-            traffic_live = live_pmc(args.config)
+        if trajopt and args.config == 2 and B == 1024:     # (tools/pmc_probe.py's TrajOpt batch)
+            pmc_t, src_t = committed_pmc("trajopt")
+            if pmc_t:
+                traffic, traffic_src = pmc_t.get("traffic_bytes_per_launch"), src_t + " (separate rocprofv3 --pmc passes, not this run)"
+        if (full_batch or (trajopt and args.config == 2 and B == 1024)) and dist is None and not args.no_extras and not args.no_live_traffic:
+            traffic_live = live_pmc(args.config, algo="trajopt" if trajopt else "gusto")
             if traffic_live:
                 traffic_live["committed_traffic_bytes_per_launch"] = traffic
                 traffic = traffic_live["traffic_bytes_per_launch"]
