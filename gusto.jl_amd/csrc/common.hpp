@@ -246,8 +246,27 @@ template <int MODEL> struct Rec {
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr int r64(int c) { return (c + 63) / 64 * 64; }
     // (+1: every record keeps at least one padding slot, the target of the lanes that hold no entry of a tile store)
-    static constexpr int SQQ = r64(NZ * (NZ + 1) / 2), SNN = r64(n * n + 1), SKD = r64(2 * m * n + m * m + 1);
+    // -DGUSTO_S_TRI=1 (a build switch, off): the freeflyerSE2 and astrobeeSE3 TrajOpt variants keep S^-1 as its upper triangle
+    // (m = 9 / 18: 45 / 171 doubles instead of 81 / 324).  Their stage-parallel phases walk the record a lane per knot at HBM
+    // latency and pay for its number of lines: astrobeeSE3 B = 256 427 -> 397 ms, freeflyerSE2 B = 1024 34.9 -> 34.5.  Off
+    // because the TrajOpt subproblems at the edge of break-down respond to the changed rounding (one S^-1 entry serving both
+    // triangles): schedules stay identical on 1024 / 256 problems, but the J_true outliers of the freeflyerSE2 sweep go
+    // 11 -> 18 of 1024 and one of the 48 problems of test_whole_runs_match_the_oracle leaves its 1e-6 objective gate
+    // (profiles/r05_trajopt_stage.txt).
+#ifndef GUSTO_S_TRI
+#define GUSTO_S_TRI 0
+#endif
+    static constexpr bool S_TRI = GUSTO_S_TRI && T::NDEF > 0 && T::n != 13;
+    static constexpr int NS = S_TRI ? m * (m + 1) / 2 : m * m;
+    static constexpr int SQQ = r64(NZ * (NZ + 1) / 2), SNN = r64(n * n + 1), SKD = r64(2 * m * n + NS + 1);
     static constexpr int oK = 0, oD = m * n, oS = 2 * m * n;
+    static constexpr int KD_DUMMY = 2 * m * n + NS;   // the padding slot behind the entries
+    // record position of S^-1[i][l]
+    static constexpr int sS(int i, int l) {
+        if (!S_TRI) return oS + i * m + l;
+        const int a = i < l ? i : l, b = i < l ? l : i;
+        return oS + a * m - a * (a - 1) / 2 + (b - a);
+    }
 };
 
 // Compact [Phi Gam] record of the matrix-core models (MT::MFMA): only the structural nonzeros of Phi = 2 M - I (MT::Mnz) and

@@ -132,7 +132,7 @@ template <int MODEL, bool ONEWAVE> struct Blk {
     }
     GD double kdS(int k, int i, int l) const {
         if constexpr (C::KD_LDS) return kdl[k * C::KDS + 2 * m * n + sidx(i, l, m)];
-        else return KD[(size_t)k * R::SKD + R::oS + i * m + l];
+        else return KD[(size_t)k * R::SKD + R::sS(i, l)];
     }
 
     GD void rebind_global() {   // (see rebind_lds)
@@ -620,7 +620,7 @@ template <int MODEL, class BLK> GD void factor_sweep_mw(BLK& K, double* fail, Pr
                     for (int i = 0; i < m; i++) { sw[i * n + g] = w[i]; sk[i * n + g] = kk[i]; gk[i * n + g] = kk[i]; }
                 } else {   // column g of S^-1 = L^-T L^-1 (feed-forward only)
 #pragma unroll
-                    for (int i = 0; i < m; i++) K.KD[(size_t)k * R::SKD + R::oS + i * m + g] = kk[i];
+                    for (int i = 0; i < m; i++) K.KD[(size_t)k * R::SKD + ((R::S_TRI && i > g) ? R::KD_DUMMY : R::sS(i, g))] = kk[i];
                 }
             }
         } else
@@ -746,7 +746,7 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
     constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NPG = n * NZ, NN = n * n, NZN = NZ * n;
     constexpr int RT = (NPG + 63) / 64, RQ = (NQ + 63) / 64, RN = (NN + 63) / 64, RZ = (NZN + 63) / 64;
     constexpr bool SMALL = n <= 8;   // (operands of all rounds of a phase in flight at once; the large models go round by round)
-    static_assert(2 * n + m <= 64 && R::SQQ == 64 * RQ && R::SNN > NN && R::SKD > 2 * m * n + m * m, "a lane per right-hand side; padded records");
+    static_assert(2 * n + m <= 64 && R::SQQ == 64 * RQ && R::SNN > NN && R::SKD > R::KD_DUMMY, "a lane per right-hand side; padded records");
     const int tid = K.tid, N = K.N;
     int hI[RQ], hJ[RQ];
 #pragma unroll
@@ -937,12 +937,15 @@ template <int MODEL, class BLK> GD void factor_sweep_w1(BLK& K, double* fail, Pr
             double* sw = isK ? K.sW : K.sV;
             double* sk = isK ? K.sK : K.sD;
             // (one unconditional store per entry: K and D at oK / oD + i n + g, column g of S^-1 at oS + i m + g, idle lanes in the padding)
-            const int gbase = !rhs ? 2 * m * n + m * m : (isK ? R::oK + g : (isD ? R::oD + g : R::oS + g));
+            const bool isS = rhs && !isK && !isD;
+            const int gbase = !rhs ? R::KD_DUMMY : (isK ? R::oK + g : (isD ? R::oD + g : R::oS + g));
             const int gstr = !rhs ? 0 : ((isK || isD) ? n : m);
 #pragma unroll
             for (int i = 0; i < m; i++) {
                 if (kd) { sw[i * n + g] = w[i]; sk[i * n + g] = kk[i]; }
-                K.KD[(size_t)k * R::SKD + gbase + i * gstr] = kk[i];
+                // (S^-1 as its upper triangle for the TrajOpt variants, Rec::S_TRI: the lane of column g stores rows i <= g)
+                const int gi = (R::S_TRI && isS) ? ((i <= g) ? R::oS + (i * m - i * (i - 1) / 2 - i) + g : R::KD_DUMMY) : gbase + i * gstr;
+                K.KD[(size_t)k * R::SKD + gi] = kk[i];
             }
         }
         K.sync();
