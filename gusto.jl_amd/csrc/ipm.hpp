@@ -3674,6 +3674,10 @@ __device__ __noinline__ ResidOut resid_phase_call(typename BLK::Args a, RowScal 
     return resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, gusto_dyn_lds + C::misc + 32);
 }
 
+}  // namespace gusto
+#include "seg.hpp"
+namespace gusto {
+
 // ---- the interior point method ---------------------------------------------------------------------
 // Register discipline: nothing per-thread stays live across a sequential sweep.  Every stage-parallel block
 // re-reads the iterate (Xw/Uw), the linearisation point (Xp/Up) and the stage matrices it needs from LDS / L2
@@ -3694,6 +3698,10 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     double* gxs = K.misc + 16;   // gx of knot 0 (n values)
     double* mug = K.misc + 32;   // goal multipliers (state-index space)
     double* mugn = K.misc + 48;  // ... of the current Newton step
+    // the horizon split into two Riccati segments (seg.hpp): chain A = stages 0 .. seg_s - 1, chain B = seg_s .. N - 1
+    constexpr bool SEG = seg2_model<MODEL>() && BLK::ONE;
+    const bool seg = SEG && N >= GUSTO_SEG_MIN_N;
+    const int seg_s = seg_split(N);
 
     RowCtx<MODEL> ctx;
     ctx.P = &K.P; ctx.N = N; ctx.k = k; ctx.nslot = K.P.wl.nslot; ctx.kappa = kappa; ctx.omega = omega; ctx.Delta = Delta;
@@ -3813,6 +3821,17 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             K.sync();
         }
         // (4) factorise
+        bool seg_done = false;
+        if constexpr (SEG) {
+            if (seg) {
+                factor_sweep_pg2s<MODEL>(SweepView<MODEL>::make(K), fail, pf, seg_s);
+                pf.tick(PF_FACTOR);
+                GUSTO_REFRESH_K();
+                seg_coarse_factor<MODEL>(K, fail);
+                seg_done = true;
+            }
+        }
+        if (!seg_done) {
         factor_sweep<MODEL>(K, fail, pf);
         pf.tick(PF_FACTOR);
         GUSTO_REFRESH_K();
@@ -3836,6 +3855,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             }
         }
         if constexpr (n > 8) inv_spd_block<MODEL>(K, fail);   // (the whole workgroup: one lane took 170 k cycles for n = 12)
+        }
         K.sync();
         if (*fail != 0.0) break;
         pf.tick(PF_POSTF);
@@ -3903,13 +3923,16 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             }
             K.sync();
             pf.tick(PF_RHS);
-            backward_sweep<MODEL>(K);
+            if constexpr (SEG) { if (seg) backward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else backward_sweep<MODEL>(K); }
+            else backward_sweep<MODEL>(K);
             pf.tick(PF_BACK);
             GUSTO_REFRESH_K();
             if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL, BLK>(K.args(), k, act, hdt, &pf);
+            else if constexpr (SEG) { if (seg) mid_phase_seg<MODEL>(K, k, act, hdt, seg_s, mugn, &pf); else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf); }
             else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf);
             pf.tick(PF_MID);
-            forward_sweep<MODEL>(K);
+            if constexpr (SEG) { if (seg) forward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else forward_sweep<MODEL>(K); }
+            else forward_sweep<MODEL>(K);
             if constexpr (GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL)
                 if (!adj_now)
                 if (pass == 1 || ncomp == 0) costate_pass_1w_call<MODEL>(K.args());
@@ -3922,7 +3945,12 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             ctx.pf = &pf; ctx.pfb = PF_S0;
 #endif
             if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL, BLK>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
-            else so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mugn, gxs);
+            else {
+                // (segmented solve: the costates of chain A's knots hang on dlam, those of chain B's on mu_g)
+                const double* mult = mugn;
+                if constexpr (SEG) mult = (seg && k < seg_s) ? (const double*)(K.misc + (SegC<MODEL>::LAM - BLK::C::misc)) : mult;
+                so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mult, gxs);
+            }
             if constexpr (costate_adjoint<MODEL>() && BLK::ONE)
                 if (adj_now && (pass == 1 || ncomp == 0)) adjoint_sweep_1w_call<MODEL>(K.args(), hdt);
             (void)adj_now;
