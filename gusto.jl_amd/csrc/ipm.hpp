@@ -3674,9 +3674,18 @@ __device__ __noinline__ ResidOut resid_phase_call(typename BLK::Args a, RowScal 
     return resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, gusto_dyn_lds + C::misc + 32);
 }
 
+// The KKT solve as two Riccati segments joined by a coarse LQR stage (round 6; seg.hpp): parity-green, slower on one wave -- the
+// sequential phases are ISSUE-bound, not latency-bound (profiles/r06_two_chains.txt).  A build switch, off.
+#ifndef GUSTO_SEG2
+#define GUSTO_SEG2 0
+#endif
+#if GUSTO_SEG2
 }  // namespace gusto
 #include "seg.hpp"
 namespace gusto {
+#else
+template <int MODEL> constexpr bool seg2_model() { return false; }
+#endif
 
 // ---- the interior point method ---------------------------------------------------------------------
 // Register discipline: nothing per-thread stays live across a sequential sweep.  Every stage-parallel block
@@ -3700,8 +3709,10 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     double* mugn = K.misc + 48;  // ... of the current Newton step
     // the horizon split into two Riccati segments (seg.hpp): chain A = stages 0 .. seg_s - 1, chain B = seg_s .. N - 1
     constexpr bool SEG = seg2_model<MODEL>() && BLK::ONE;
+#if GUSTO_SEG2
     const bool seg = SEG && N >= GUSTO_SEG_MIN_N;
     const int seg_s = seg_split(N);
+#endif
 
     RowCtx<MODEL> ctx;
     ctx.P = &K.P; ctx.N = N; ctx.k = k; ctx.nslot = K.P.wl.nslot; ctx.kappa = kappa; ctx.omega = omega; ctx.Delta = Delta;
@@ -3822,6 +3833,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         }
         // (4) factorise
         bool seg_done = false;
+#if GUSTO_SEG2
         if constexpr (SEG) {
             if (seg) {
                 factor_sweep_pg2s<MODEL>(SweepView<MODEL>::make(K), fail, pf, seg_s);
@@ -3831,6 +3843,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 seg_done = true;
             }
         }
+#endif
         if (!seg_done) {
         factor_sweep<MODEL>(K, fail, pf);
         pf.tick(PF_FACTOR);
@@ -3923,16 +3936,24 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             }
             K.sync();
             pf.tick(PF_RHS);
+#if GUSTO_SEG2
             if constexpr (SEG) { if (seg) backward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else backward_sweep<MODEL>(K); }
-            else backward_sweep<MODEL>(K);
+            else
+#endif
+            backward_sweep<MODEL>(K);
             pf.tick(PF_BACK);
             GUSTO_REFRESH_K();
             if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL, BLK>(K.args(), k, act, hdt, &pf);
+#if GUSTO_SEG2
             else if constexpr (SEG) { if (seg) mid_phase_seg<MODEL>(K, k, act, hdt, seg_s, mugn, &pf); else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf); }
+#endif
             else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf);
             pf.tick(PF_MID);
+#if GUSTO_SEG2
             if constexpr (SEG) { if (seg) forward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else forward_sweep<MODEL>(K); }
-            else forward_sweep<MODEL>(K);
+            else
+#endif
+            forward_sweep<MODEL>(K);
             if constexpr (GUSTO_COSTATE_PASS && BLK::ONE && T::SWEEP_CALL)
                 if (!adj_now)
                 if (pass == 1 || ncomp == 0) costate_pass_1w_call<MODEL>(K.args());
@@ -3948,7 +3969,9 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             else {
                 // (segmented solve: the costates of chain A's knots hang on dlam, those of chain B's on mu_g)
                 const double* mult = mugn;
+#if GUSTO_SEG2
                 if constexpr (SEG) mult = (seg && k < seg_s) ? (const double*)(K.misc + (SegC<MODEL>::LAM - BLK::C::misc)) : mult;
+#endif
                 so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mult, gxs);
             }
             if constexpr (costate_adjoint<MODEL>() && BLK::ONE)

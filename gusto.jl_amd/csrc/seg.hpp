@@ -23,9 +23,6 @@
 
 namespace gusto {
 
-#ifndef GUSTO_SEG2
-#define GUSTO_SEG2 1
-#endif
 #ifndef GUSTO_SEG_MIN_N
 #define GUSTO_SEG_MIN_N 8       // shorter horizons keep the sequential recursion (a segment of two or three stages is barely controllable)
 #endif
@@ -59,64 +56,12 @@ template <int MODEL> struct SegC {
     static_assert(n <= 8, "misc slots");
 };
 
-// Cholesky A = L L' of an n x n matrix in LDS (row-major at `src`, lower triangle read) by the first n lanes of the wave, lane r
-// holding row r in registers, columns exchanged by v_readlane (inv_spd_block's scheme).  Writes L (if dstL >= 0) and L^-1 (lower,
-// row-major) to LDS.  floor_rel > 0: pivots are floored at floor_rel x the largest diagonal entry (positive SEMI-definite input);
-// idmask: rows / columns whose bit is set are replaced by the identity (coordinates without a goal row).
-template <int n> GD bool seg_chol(LPtr<double> L, int tid, int src, int dstL, int dstLi, double floor_rel, unsigned idmask) {
-    const int r = tid < n ? tid : n - 1;   // (lanes >= n mirror the last row and are never read)
-    double a[n];
-#pragma unroll
-    for (int c = 0; c < n; c++) {
-        a[c] = L[src + r * n + c];
-        const bool idr = (idmask >> r) & 1u, idc = (idmask >> c) & 1u;
-        if (idr || idc) a[c] = (c == r) ? 1.0 : 0.0;
-    }
-    double dmax = 0.0;
-    static_for<0, n>([&](auto J) { constexpr int j = decltype(J)::value; dmax = fmax(dmax, readlane_f64(a[j], j)); });
-    const double flo = floor_rel * dmax;
-    bool bad = !(dmax > 0.0);
-    static_for<0, n>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        double ajj = readlane_f64(a[j], j);
-        if (floor_rel > 0.0) ajj = (ajj > flo) ? ajj : flo;
-        else if (!(ajj > 0.0)) bad = true;
-        const double d = rsqrt_nr(ajj);
-        const double ljj = ajj * d;                              // sqrt(a_jj)
-        a[j] = (r > j) ? a[j] * d : ((r == j) ? ljj : a[j]);     // column j of L
-        static_for<j + 1, n>([&](auto Cc) {                      // trailing update of the lower triangle
-            constexpr int c = decltype(Cc)::value;
-            const double lcj = readlane_f64(a[j], c);
-            double t = a[c];
-            t -= a[j] * lcj;
-            a[c] = (r >= c) ? t : a[c];
-        });
-    });
-    // column r of L^-1 by forward substitution; row i of L comes from lane i
-    double x[n];
-    static_for<0, n>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        const double ri = rcp_nr(readlane_f64(a[i], i));
-        double acc = 0;
-        static_for<0, i>([&](auto L_) {
-            constexpr int l = decltype(L_)::value;
-            acc -= readlane_f64(a[l], i) * x[l];
-        });
-        x[i] = (i == r) ? ri : ((i > r) ? acc * ri : 0.0);
-    });
-    if (tid < n) {
-#pragma unroll
-        for (int i = 0; i < n; i++) L[dstLi + i * n + tid] = x[i];
-        if (dstL >= 0) {
-#pragma unroll
-            for (int c = 0; c < n; c++) L[dstL + tid * n + c] = (c <= tid) ? a[c] : 0.0;
-        }
-    }
-    return !bad;
-}
-
-// The coarse stage's matrices from what the factor sweep left (see the head of this file).  Whole wave; ~a dozen 6 x 6 products,
-// an entry per lane, and three Cholesky factorisations.
+// The coarse stage's matrices from what the factor sweep left (head of this file).  Whole wave, an entry per lane:
+//   X = I + P_B Gd_A,  Ta' = X^-1 by Gauss-Jordan in LDS (no pivoting: X is similar to the SPD matrix I + G' P_B G; the CPU prototype
+//   ran every BASELINE batch with and without partial pivoting, profiles/r06_segmented_riccati_proto.txt; a zero pivot
+//   ends the solve as a failed factorisation),  Sig = Gd_A Ta',  Pa = Ta' P_B,  A3 = Ta' Pi_B,  A2 = Sig Pi_B,
+//   Gdc = Gd_B + Pi_B' A2 (identity on the coordinates without a point goal),  Gdc^-1 by Cholesky,  A1 = Gdc^-1 Pi_B'.
+// (Ta' of this comment is the matrix the head of the file calls Tt' = (I + P_B Gd_A)^-1; LDS slot Tt holds its TRANSPOSE.)
 template <int MODEL, class BLK> GD void seg_coarse_factor(BLK& K, double* fail) {
     using S = SegC<MODEL>;
     constexpr int n = S::n, NN = S::NN, h3 = n / 2;
@@ -126,63 +71,94 @@ template <int MODEL, class BLK> GD void seg_coarse_factor(BLK& K, double* fail) 
     const bool on = tid < NN;
     const int i = on ? tid / n : 0, j = on ? tid % n : 0;
     auto pcol = [](int j_) { return 2 * (j_ % h3) + j_ / h3; };
-    // element accessors (offsets)
     auto rm = [](int base) { return [base](int r_, int c_) { return base + r_ * n + c_; }; };     // row-major
     auto tr = [](int base) { return [base](int r_, int c_) { return base + c_ * n + r_; }; };     // the transpose of a row-major matrix
     auto pb = [&](int r_, int c_) { return S::PB + r_ * n + pcol(c_); };                          // P_B (columns interleaved)
     auto pib = [](int r_, int c_) { return S::PIB + c_ * n + r_; };                               // Pi_B (stored transposed)
     auto pibT = [](int r_, int c_) { return S::PIB + r_ * n + c_; };                              // Pi_B'
     // dst(i, j) = add + sum_l A(i, l) B(l, j), an entry per lane
-    auto prod = [&](int dst, auto A, auto B, double add) {
+    auto prod = [&](auto A, auto B, double add) {
         double acc = add;
 #pragma unroll
         for (int l = 0; l < n; l++) acc += L[A(i, l)] * L[B(l, j)];
-        if (on) L[dst + tid] = acc;
+        return acc;
     };
     bool ok = true;
-    // G = chol(Gd_A) -> A1, G^-1 -> A2
-    ok = seg_chol<n>(L, tid, S::GDA, S::A1, S::A2, GUSTO_SEG_PIV, 0u) && ok;
+    // ---- W = X = I + P_B Gd_A, inverted in place (slot X1): lane (i, j) keeps its entry in a register ----
+    double w = prod(pb, rm(S::GDA), (i == j) ? 1.0 : 0.0);
+    if (on) L[S::X1 + tid] = w;
     K.sync();
-    prod(S::X1, pb, rm(S::A1), 0.0);                         // X1 = P_B G
-    K.sync();
-    prod(S::X2, tr(S::A1), rm(S::X1), (i == j) ? 1.0 : 0.0); // M = I + G' P_B G
-    K.sync();
-    ok = seg_chol<n>(L, tid, S::X2, -1, S::X1, 0.0, 0u) && ok;   // Lm^-1 -> X1
-    K.sync();
-    prod(S::X2, rm(S::X1), tr(S::A1), 0.0);                  // Y = Lm^-1 G'
-    prod(S::A3, rm(S::X1), rm(S::A2), 0.0);                  // Z1 = Lm^-1 G^-1
-    K.sync();
-    prod(S::Sg, tr(S::X2), rm(S::X2), 0.0);                  // Sig = Y' Y
-    prod(S::Tt, tr(S::X2), rm(S::A3), 0.0);                  // Tt = Y' Z1 = G M^-1 G^-1
-    prod(S::X1, rm(S::X2), pb, 0.0);                         // Y P_B
-    K.sync();
-    prod(S::Pa, tr(S::A3), rm(S::X1), 0.0);                  // Pa = Z1' Y P_B = Tt' P_B
-    prod(S::A2, rm(S::Sg), pib, 0.0);                        // A2 = Sig Pi_B
-    K.sync();
-    prod(S::A3, tr(S::Tt), pib, 0.0);                        // A3 = Tt' Pi_B
-    {   // Gdc = Gd_B + Pi_B' Sig Pi_B
-        double acc = L[S::GDB + (on ? tid : 0)];
-#pragma unroll
-        for (int l = 0; l < n; l++) acc += L[pibT(i, l)] * L[S::A2 + l * n + j];
-        if (on) L[S::X1 + tid] = acc;
+    static_for<0, n>([&](auto Cc) {
+        constexpr int c = decltype(Cc)::value;
+        const double piv = L[S::X1 + c * n + c], wcj = L[S::X1 + c * n + j], wic = L[S::X1 + i * n + c];
+        if (!(fabs(piv) > 0.0) || !isfinite(piv)) ok = false;   // (pivots of either sign occur: X is not symmetric)
+        const double d = rcp_nr(piv);
+        const double rowc = (j == c) ? d : wcj * d;                      // the new row c
+        const double other = (j == c) ? -(wic * d) : w - wic * (wcj * d);
+        w = (i == c) ? rowc : other;
+        K.sync();
+        if (on) L[S::X1 + tid] = w;
+        K.sync();
+    });
+    // X1 = (I + P_B Gd_A)^-1 =: Y.  Tt = Y' (slot Tt: row-major transpose), Sig = Gd_A Y, Pa = Y P_B, A3 = Y Pi_B
+    {
+        const double sg = prod(rm(S::GDA), rm(S::X1), 0.0);
+        const double pa = prod(rm(S::X1), pb, 0.0);
+        const double a3 = prod(rm(S::X1), pib, 0.0);
+        if (on) { L[S::Tt + j * n + i] = w; L[S::Sg + tid] = sg; L[S::Pa + tid] = pa; L[S::A3 + tid] = a3; }
     }
     K.sync();
-    unsigned idmask = 0;
+    {   // Sig is symmetric in exact arithmetic: both triangles from one mean
+        const double sgm = 0.5 * (L[S::Sg + i * n + j] + L[S::Sg + j * n + i]);
+        K.sync();
+        if (on) L[S::Sg + tid] = sgm;
+        K.sync();
+    }
+    {
+        const double a2 = prod(rm(S::Sg), pib, 0.0);                      // A2 = Sig Pi_B
+        if (on) L[S::A2 + tid] = a2;
+    }
+    K.sync();
+    {   // Gdc = Gd_B + Pi_B' A2 -> X2 (identity on the coordinates without a point goal)
+        double g = L[S::GDB + (on ? tid : 0)] + prod(pibT, rm(S::A2), 0.0);
+        if (!K.is_goal(i) || !K.is_goal(j)) g = (i == j) ? 1.0 : 0.0;
+        if (on) L[S::X2 + tid] = g;
+    }
+    K.sync();
+    {   // Gdc^-1: every lane factors the n x n block itself (broadcast reads; the flops of ONE lane), lane 0 publishes L^-1
+        double G[n * n], Li[n * n];
 #pragma unroll
-    for (int g = 0; g < n; g++) if (!K.is_goal(g)) idmask |= 1u << g;
-    ok = seg_chol<n>(L, tid, S::X1, -1, S::X2, 0.0, idmask) && ok;   // Lc^-1 -> X2
+        for (int e = 0; e < n * n; e++) G[e] = L[S::X2 + e];
+        if (!chol_inv<n>(G, Li)) ok = false;
+        K.sync();
+        if (tid == 0) {
+#pragma unroll
+            for (int e = 0; e < n * n; e++) L[S::X2 + e] = Li[e];
+        }
+        K.sync();
+        const double gi = prod(tr(S::X2), rm(S::X2), 0.0);               // Lc^-T Lc^-1
+        if (on) L[S::Gci + tid] = gi;
+    }
     K.sync();
-    prod(S::Gci, tr(S::X2), rm(S::X2), 0.0);                 // Gdc^-1 = Lc^-T Lc^-1
-    K.sync();
-    prod(S::A1, rm(S::Gci), pibT, 0.0);                      // A1 = Gdc^-1 Pi_B'
+    {
+        const double a1 = prod(rm(S::Gci), pibT, 0.0);                    // A1 = Gdc^-1 Pi_B'
+        if (on) L[S::A1 + tid] = a1;
+    }
     if (!ok) *fail = 1.0;
     K.sync();
 }
 
 // ---- the factor sweep of the two chains ----------------------------------------------------------------------------------
-// factor_sweep_pg2 (ipm.hpp) for the stages khi .. klo of one chain.  Chain A (isA): P = 0, Pi = I behind its last knot (record
-// khi = (0 | I)), no E term.  Chain B: the sweep as it was, but its last stage (k = klo = s) and its last tail leave P_B, Pi_B in
-// LDS only -- record s-1 belongs to chain A.
+// factor_sweep_pg2 (ipm.hpp: the software-pipelined, predication-free stage of the double integrator) for TWO chains at once:
+// every phase of a stage is issued for chain A and chain B back to back -- operand loads of both, then the arithmetic of both,
+// then the stores of both, one ordering point -- so that the LDS round trips, the v_readlane exchanges and the dependent flops of
+// the 3 x 3 Cholesky of one chain run in the shadow of the other's.  Per chain the operations and their order are those of
+// factor_sweep_pg2.
+//   Chain B (stages N-1 .. s): the sweep as it was, but its last stage (k = s) and its last tail leave P_B, Pi_B in LDS only --
+//     record s-1 belongs to chain A (their stores aim at the junk record -1).
+//   Chain A (stages s-1 .. 0): P = 0, Pi = I behind its last knot (record s-1 = (0 | I)), no E term; its working set sits in the
+//     [Phi Gam] staging buffers (SegC).
+// On exit: P_B in sP, Pi_B in sPi, Gd_B in sGd, Gd_A behind it.
 template <int MODEL> GD void factor_sweep_pg2s(SweepView<MODEL> K, double* fail, Prof& pf, int s) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
@@ -191,8 +167,9 @@ template <int MODEL> GD void factor_sweep_pg2s(SweepView<MODEL> K, double* fail,
     constexpr int n = T::n, m = T::m, NZ = n + m, NQ = NZ * (NZ + 1) / 2, NN = n * n, NZN = NZ * n, h3 = n / 2, NH = n * (n + 1) / 2;
     static_assert(T::PG2 && T::LTI && C::KD_LDS && NQ <= 64 && NZN <= 64 && NN <= 64 && n >= 2 * m, "shape");
     static_assert(NH + NN < R::SNN && !C::BIG, "P | Pi record, dummy slot");
+    static_assert(n * NZ >= 16 + 36, "dummy slot");
     const int tid = K.tid, N = K.N;
-    // ---- lane roles ----
+    // ---- lane roles (factor_sweep_pg2) ----
     const int ijh = K.lut[tid < NQ ? tid : 0], hc = ijh >> 8, hj = ijh & 255, i0 = T::pg_r0(hc), j0 = T::pg_r0(hj);   // H[hc][hj]
     const int zc = tid < NZN ? tid / n : 0, zg = tid < NZN ? tid % n : 0, z0 = T::pg_r0(zc);                       // Z[zc][zg]
     const int ri = tid < n ? tid : 0;                                                                             // r[ri], Pi^T c [ri]
@@ -201,25 +178,37 @@ template <int MODEL> GD void factor_sweep_pg2s(SweepView<MODEL> K, double* fail,
     const LPtr<double> L = K.lds;
     typedef double v2d __attribute__((ext_vector_type(2)));
     auto ld2 = [&](int off) { return *(const __attribute__((address_space(3))) v2d*)(L.p + off); };   // ds_read_b128 (off even)
-    const int dmy = C::sT0 + (tid & 15);
+    const int dmy = C::sT0 + (tid & 15);             // dummy slot of this lane (+ immediates < 36 stay inside the T buffer)
     auto pcol = [](int j_) { return 2 * (j_ % h3) + j_ / h3; };
-    const int oPP = C::sP + i0 * n + 2 * j0, oPZ = C::sPi + zg * n + z0, oPr = C::sP + ri * n, oPir = C::sPi + ri * n;
-    const int wH1 = tid < NQ ? C::sHh + hc * NZ + hj : dmy;
-    const int wZ = tid < NZN ? C::sZ + tid : dmy;
-    const int oHi = C::sHh + i * NZ + n, oHj = C::sHh + j * NZ + n, oPn = C::sHh + (i < j ? i : j) * NZ + (i < j ? j : i);
-    const int oZi = C::sZ + n * n + i, oZj = C::sZ + n * n + j;
-    const int wP = on ? C::sP + i * n + pcol(j) : dmy, wPi = on ? C::sPi + j * n + i : dmy;
-    const int vecs = C::vecs, oCv = vecs + 3 * N * n, oRv = vecs + 4 * N * n, oNun = vecs + 6 * N * n;
+    // ---- LDS operands of the two chains ----
+    struct Off { int oPP, oPZ, oPr, oPir, wH1, wZ, oHi, oHj, oPn, oZi, oZj, wP, wPi; };
+    Off oB, oA;
+    oB.oPP = C::sP + i0 * n + 2 * j0; oB.oPZ = C::sPi + zg * n + z0; oB.oPr = C::sP + ri * n; oB.oPir = C::sPi + ri * n;
+    oB.wH1 = tid < NQ ? C::sHh + hc * NZ + hj : dmy;
+    oB.wZ = tid < NZN ? C::sZ + tid : dmy;
+    oB.oHi = C::sHh + i * NZ + n; oB.oHj = C::sHh + j * NZ + n; oB.oPn = C::sHh + (i < j ? i : j) * NZ + (i < j ? j : i);
+    oB.oZi = C::sZ + n * n + i; oB.oZj = C::sZ + n * n + j;
+    oB.wP = on ? C::sP + i * n + pcol(j) : dmy; oB.wPi = on ? C::sPi + j * n + i : dmy;
+    auto hA = [](int r_, int c_) { return (r_ < S::HSPLIT ? S::aH0 + r_ * NZ : S::aH1 + (r_ - S::HSPLIT) * NZ) + c_; };   // (rows 0..n-1 of H only: S travels by v_readlane)
+    oA.oPP = S::aP + i0 * n + 2 * j0; oA.oPZ = S::aPi + zg * n + z0; oA.oPr = S::aP + ri * n; oA.oPir = S::aPi + ri * n;
+    oA.wH1 = (tid < NQ && hc < n) ? hA(hc, hj) : dmy;
+    oA.wZ = tid < NZN ? S::aZ + tid : dmy;
+    oA.oHi = hA(i, n); oA.oHj = hA(j, n); oA.oPn = hA(i < j ? i : j, i < j ? j : i);
+    oA.oZi = S::aZ + n * n + i; oA.oZj = S::aZ + n * n + j;
+    oA.wP = on ? S::aP + i * n + pcol(j) : dmy; oA.wPi = on ? S::aPi + j * n + i : dmy;
+    const int vecs = C::vecs, oCv = vecs + 3 * N * n, oRv = vecs + 4 * N * n, oNun = vecs + 6 * N * n;   // (Blk::rebind_lds)
     const int wRv = tid < n ? oRv + tid : dmy, wNun = tid < n ? oNun + tid : dmy, sRv = tid < n ? n : 0;
     const int kdo = K.kd_off;
-    const int wKD = tid < n ? kdo + tid : dmy, sKD = tid < n ? C::KDS : 0;
-    const int wSi = tid == 0 ? kdo + 2 * m * n : dmy, sSi = tid == 0 ? C::KDS : 0;
-    const int ep = (on && i <= j) ? sidx(i, j, n) : R::SNN - 1, eq = on ? NH + tid : R::SNN - 1;
+    const int wKD = tid < n ? kdo + tid : dmy, sKD = tid < n ? C::KDS : 0;             // K[a][tid] at + a n, D[a][tid] at + (m + a) n
+    const int wSi = tid == 0 ? kdo + 2 * m * n : dmy, sSi = tid == 0 ? C::KDS : 0;     // S^-1, upper triangle
+    const int ep = (on && i <= j) ? sidx(i, j, n) : R::SNN - 1, eq = on ? NH + tid : R::SNN - 1;   // packed P | Pi record
+    const int qi = tid < NQ ? tid : 0;
+    // ---- [Phi Gam] entries of this lane: the block of the sweep and the knot-0 block [0 | b_0] ----
     struct PGC { double a0, a1, b0, b1, zv0, zv1; };
     double Bd[n * m];
     Dyn<MODEL>::B(*K.mpp, Bd);
     auto pg_main = [&](int r_, int c_) { return K.PGk(N - 1)[r_ * NZ + c_]; };
-    auto pg_zero = [&](int r_, int c_) {
+    auto pg_zero = [&](int r_, int c_) {   // ([0 | dt/2 B], formed as factor_sweep_1w forms it)
         double v = 0.0;
 #pragma unroll
         for (int q = 0; q < n * m; q++) if (c_ >= n && q == r_ * m + (c_ - n)) v = 0.5 * K.dt * Bd[q];
@@ -230,159 +219,171 @@ template <int MODEL> GD void factor_sweep_pg2s(SweepView<MODEL> K, double* fail,
     cN.zv0 = pg_main(z0, zc); cN.zv1 = pg_main(z0 + h3, zc);
     c0.a0 = pg_zero(i0, hc); c0.a1 = pg_zero(i0 + h3, hc); c0.b0 = pg_zero(j0, hj); c0.b1 = pg_zero(j0 + h3, hj);
     c0.zv0 = pg_zero(z0, zc); c0.zv1 = pg_zero(z0 + h3, zc);
+    // E = [M^T C^T; b^T M^T C^T] of the last knot (chain B), column g only for goal coordinates
     const double eterm = pg_main(zg, zc) + ((zc == zg) ? 1.0 : 0.0);
     const bool egoal = K.is_goal(zg);
     bool okall = true;
     auto msync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
 
-    auto chain = [&](int khi, int klo, bool isA) {
-        L[wP] = 0.0; L[wPi] = 0.0; L[wZ] = 0.0;
-        double gdR = 0.0, zR = (isA && on && i == j) ? 1.0 : 0.0;
-        if (tid < R::SNN) K.Paft[(size_t)khi * R::SNN + tid] = (isA && tid >= NH && tid < NH + NN && (tid - NH) / n == (tid - NH) % n) ? 1.0 : 0.0;
-        double qq = K.kdl[khi * C::KDS + (tid < NQ ? tid : 0)];
-        double LiP[m * m], wiP[m];
+    // ---- what a chain keeps across stages: the prefetched stage cost and this lane's entry of Gd ----
+    struct St { double qq, gdR; };
+    struct Tmp {   // operands and intermediate results of one stage
+        double p00, p01, p10, p11, ra[n], rb[n], pa[n], zb0, zb1, qqn, h, z;
+        double hi[m], hjv[m], zi[m], zj[m], pn;
+    };
+    const int nB = N - s, nA = s;   // stages of the chains (nB - nA = 0 or 1)
+    St stB, stA;
+    // start: P = 0 behind the last knot of a chain; Pi = 0 (chain B) / I (chain A)
+    L[oB.wP] = 0.0; L[oB.wPi] = 0.0;
+    L[oA.wP] = 0.0; L[oA.wPi] = (on && i == j) ? 1.0 : 0.0;
+    stB.gdR = 0.0; stA.gdR = 0.0;
+    if (tid < R::SNN) {
+        K.Paft[(size_t)(N - 1) * R::SNN + tid] = 0.0;
+        K.Paft[(size_t)(s - 1) * R::SNN + tid] = (tid >= NH && tid < NH + NN && (tid - NH) / n == (tid - NH) % n) ? 1.0 : 0.0;
+    }
+    stB.qq = K.kdl[(N - 1) * C::KDS + qi];
+    stA.qq = K.kdl[(s - 1) * C::KDS + qi];
+    K.sync();
+
+    // ---- the two halves of a stage.  (factor_sweep_pg2 runs the goal chain half a stage behind the value chain to fill the
+    // latency of the Cholesky; here the other CHAIN fills it, and a stage is H, Z, r, Pi' c | ordering point | L, W, K, P', V, D,
+    // Pi', Gd | ordering point -- the same operations per chain, one exchange through LDS less per stage.) ----
+    auto h1_load = [&](const Off& o, Tmp& t, int k, int klo) {
+        const v2d pA = ld2(o.oPP), pB = ld2(o.oPP + h3 * n);
+        t.p00 = pA.x; t.p01 = pA.y; t.p10 = pB.x; t.p11 = pB.y;
 #pragma unroll
-        for (int e = 0; e < m * m; e++) LiP[e] = 0.0;
+        for (int l = 0; l < n; l += 2) {
+            const v2d a2 = ld2(o.oPr + l), b2 = ld2(oCv + k * n + l), c2 = ld2(o.oPir + l);
+            // row ri of P holds the columns in the order 0, n/2, 1, n/2 + 1, ...: ra[] back in natural order
+            t.ra[l / 2] = a2.x; t.ra[l / 2 + h3] = a2.y; t.rb[l] = b2.x; t.rb[l + 1] = b2.y; t.pa[l] = c2.x; t.pa[l + 1] = c2.y;
+        }
+        t.zb0 = L[o.oPZ]; t.zb1 = L[o.oPZ + h3];
+        t.qqn = K.kdl[((k > klo) ? k - 1 : klo) * C::KDS + qi];   // (slot k-1 still holds QQ_{k-1})
+    };
+    auto h1_comp = [&](const Off& o, const St& st, Tmp& t, int k, const PGC& c, bool last) {
+        t.h = st.qq + c.a0 * (c.b0 * t.p00 + c.b1 * t.p01) + c.a1 * (c.b0 * t.p10 + c.b1 * t.p11);
+        L[o.wH1] = t.h;
+        double z = c.zv0 * t.zb0 + c.zv1 * t.zb1;
+        const double zE = fma(0.5, eterm, z);
+        z = (last && egoal) ? zE : z;
+        L[o.wZ] = z;
+        t.z = z;
+        double rr = 0, rp = 0;
 #pragma unroll
-        for (int e = 0; e < m; e++) wiP[e] = 0.0;
-        K.sync();
-        // tail of stage kt: V, Pi_{kt-1}, Gd, D_kt; the Pi part of record `rec`
-        auto tail = [&](int kt, int rec, const double* zi, const double* zj) {
-            double pin = zR, gd = gdR;
-            double vi[m], vj[m], dj[m];
+        for (int l = 0; l < n; l++) rr += t.ra[l] * t.rb[l];
 #pragma unroll
-            for (int a = 0; a < m; a++) {
-                double s3 = 0, s4 = 0;
+        for (int l = 0; l < n; l++) rp += t.pa[l] * t.rb[l];
+        L[wRv + k * sRv] = rr;
+        L[wNun + k * sRv] = rp;
+    };
+    auto h2_load = [&](const Off& o, Tmp& t, double* Sm) {
 #pragma unroll
-                for (int l = 0; l <= a; l++) { s3 += LiP[a * m + l] * zi[l]; s4 += LiP[a * m + l] * zj[l]; }
-                vi[a] = s3; vj[a] = s4;
+        for (int a = 0; a < m; a++)
+#pragma unroll
+            for (int b = 0; b < m; b++) {
+                const int e = sidx(n + (a < b ? a : b), n + (a < b ? b : a), NZ);
+                Sm[a * m + b] = readlane_f64(t.h, e);
             }
 #pragma unroll
-            for (int a = 0; a < m; a++) {
-                double s2 = 0;
+        for (int l = 0; l < m; l++) { t.hi[l] = L[o.oHi + l]; t.hjv[l] = L[o.oHj + l]; t.zi[l] = L[o.oZi + l * n]; t.zj[l] = L[o.oZj + l * n]; }
+        t.pn = L[o.oPn];
+    };
+    // L = chol(H_uu) is in Li; W = L^-1 H_uy, K = L^-T W, P' = H_yy - W^T W | V = L^-1 Z_u, D = L^-T V, Pi' = Z_y - W^T V, Gd += V^T V
+    auto h2_comp = [&](const Off& o, St& st, Tmp& t, const double* Li, int k, int rec) {
+        double wi[m], wj[m], kj[m], vi[m], vj[m], dj[m];
 #pragma unroll
-                for (int l = a; l < m; l++) s2 += LiP[l * m + a] * vj[l];
-                dj[a] = s2;
+        for (int a = 0; a < m; a++) {
+            double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+            for (int l = 0; l <= a; l++) {
+                s1 += Li[a * m + l] * t.hi[l]; s2 += Li[a * m + l] * t.hjv[l];
+                s3 += Li[a * m + l] * t.zi[l]; s4 += Li[a * m + l] * t.zj[l];
             }
+            wi[a] = s1; wj[a] = s2; vi[a] = s3; vj[a] = s4;
+        }
 #pragma unroll
-            for (int l = 0; l < m; l++) { pin -= wiP[l] * vj[l]; gd += vi[l] * vj[l]; }
-            L[wPi] = pin; gdR = gd;
-            K.Paft[(size_t)rec * R::SNN + eq] = pin;
+        for (int a = 0; a < m; a++) {
+            double s1 = 0, s2 = 0;
 #pragma unroll
-            for (int a = 0; a < m; a++) L[wKD + kt * sKD + (m + a) * n] = dj[a];
-        };
-        auto stage = [&](int k, const PGC& c, bool last) {
-            const v2d pA = ld2(oPP), pB = ld2(oPP + h3 * n);
-            const double p00 = pA.x, p01 = pA.y, p10 = pB.x, p11 = pB.y;
-            double ra[n], rb[n];
+            for (int l = a; l < m; l++) { s1 += Li[l * m + a] * wj[l]; s2 += Li[l * m + a] * vj[l]; }
+            kj[a] = s1; dj[a] = s2;
+        }
+        double pn = t.pn, pin = t.z, gd = st.gdR;
 #pragma unroll
-            for (int l = 0; l < n; l += 2) {
-                const v2d a2 = ld2(oPr + l), b2 = ld2(oCv + k * n + l);
-                ra[l / 2] = a2.x; ra[l / 2 + h3] = a2.y; rb[l] = b2.x; rb[l + 1] = b2.y;
-            }
-            double zi[m], zj[m];
+        for (int l = 0; l < m; l++) pn -= wi[l] * wj[l];
 #pragma unroll
-            for (int l = 0; l < m; l++) { zi[l] = L[oZi + l * n]; zj[l] = L[oZj + l * n]; }
-            const double qqn = K.kdl[((k > klo) ? k - 1 : klo) * C::KDS + (tid < NQ ? tid : 0)];
-            const double h = qq + c.a0 * (c.b0 * p00 + c.b1 * p01) + c.a1 * (c.b0 * p10 + c.b1 * p11);
-            L[wH1] = h;
-            {
-                double rr = 0;
+        for (int l = 0; l < m; l++) { pin -= wi[l] * vj[l]; gd += vi[l] * vj[l]; }
+        L[o.wP] = pn; L[o.wPi] = pin; st.gdR = gd;
+        K.Paft[(size_t)rec * R::SNN + ep] = pn;
+        K.Paft[(size_t)rec * R::SNN + eq] = pin;
 #pragma unroll
-                for (int l = 0; l < n; l++) rr += ra[l] * rb[l];
-                L[wRv + k * sRv] = rr;
-            }
-            msync();
-            double Sm[m * m], Li[m * m];
+        for (int a = 0; a < m; a++) { L[wKD + k * sKD + a * n] = kj[a]; L[wKD + k * sKD + (m + a) * n] = dj[a]; }
 #pragma unroll
-            for (int a = 0; a < m; a++)
+        for (int a = 0; a < m; a++)   // S^-1 = L^-T L^-1, upper triangle (wave-uniform values)
 #pragma unroll
-                for (int b = 0; b < m; b++) {
-                    const int e = sidx(n + (a < b ? a : b), n + (a < b ? b : a), NZ);
-                    Sm[a * m + b] = readlane_f64(h, e);
-                }
-            double hi[m], hjv[m];
-#pragma unroll
-            for (int l = 0; l < m; l++) { hi[l] = L[oHi + l]; hjv[l] = L[oHj + l]; }
-            double pn = L[oPn];
-            {   // the goal chain is one half stage behind: tail of the stage before (the first stage of a chain: a dummy on zeros)
-                const int kt = (k + 1 <= khi) ? k + 1 : khi;
-                // (record kt - 1; chain B's record s - 1 belongs to chain A: aimed at the junk record -1)
-                tail(kt, (!isA && kt - 1 < klo) ? -1 : kt - 1, zi, zj);
-            }
-            msync();
-            const double zb0 = L[oPZ], zb1 = L[oPZ + h3];
-            double pa[n];
-#pragma unroll
-            for (int l = 0; l < n; l += 2) { const v2d a2 = ld2(oPir + l); pa[l] = a2.x; pa[l + 1] = a2.y; }
-            okall = chol_inv<m>(Sm, Li) && okall;
-            {
-                double z = c.zv0 * zb0 + c.zv1 * zb1;
-                const double zE = fma(0.5, eterm, z);
-                z = (last && egoal) ? zE : z;
-                L[wZ] = z;
-                zR = z;
-                double rr = 0;
-#pragma unroll
-                for (int l = 0; l < n; l++) rr += pa[l] * rb[l];
-                L[wNun + k * sRv] = rr;
-            }
-            double wi[m], wj[m], kj[m];
-#pragma unroll
-            for (int a = 0; a < m; a++) {
-                double s1 = 0, s2 = 0;
-#pragma unroll
-                for (int l = 0; l <= a; l++) { s1 += Li[a * m + l] * hi[l]; s2 += Li[a * m + l] * hjv[l]; }
-                wi[a] = s1; wj[a] = s2;
-            }
-#pragma unroll
-            for (int a = 0; a < m; a++) {
+            for (int b = 0; b <= a; b++) {
                 double s1 = 0;
 #pragma unroll
-                for (int l = a; l < m; l++) s1 += Li[l * m + a] * wj[l];
-                kj[a] = s1;
+                for (int l = a; l < m; l++) s1 += Li[l * m + a] * Li[l * m + b];
+                L[wSi + k * sSi + sidx(b, a, m)] = s1;
             }
-#pragma unroll
-            for (int l = 0; l < m; l++) pn -= wi[l] * wj[l];
-            L[wP] = pn;
-            K.Paft[(size_t)((!isA && k - 1 < klo) ? -1 : k - 1) * R::SNN + ep] = pn;
-#pragma unroll
-            for (int a = 0; a < m; a++) L[wKD + k * sKD + a * n] = kj[a];
-            {
-#pragma unroll
-                for (int a = 0; a < m; a++)
-#pragma unroll
-                    for (int b = 0; b <= a; b++) {
-                        double s1 = 0;
-#pragma unroll
-                        for (int l = a; l < m; l++) s1 += Li[l * m + a] * Li[l * m + b];
-                        L[wSi + k * sSi + sidx(b, a, m)] = s1;
-                    }
-            }
-            qq = qqn;
-#pragma unroll
-            for (int e = 0; e < m * m; e++) LiP[e] = Li[e];
-#pragma unroll
-            for (int e = 0; e < m; e++) wiP[e] = wi[e];
-            msync();
-        };
-        for (int k = khi; k >= klo + 1; k--) stage(k, cN, !isA && k == N - 1);
-        if (klo == 0) stage(0, c0, false); else stage(klo, cN, false);
-        {
-            double zi[m], zj[m];
-#pragma unroll
-            for (int l = 0; l < m; l++) { zi[l] = L[oZi + l * n]; zj[l] = L[oZj + l * n]; }
-            tail(klo, (!isA) ? -1 : klo - 1, zi, zj);
-        }
-        K.sync();
-        return gdR;
+        st.qq = t.qqn;
     };
-    // chain B, then (this version: one after the other, in the same working set) chain A
-    const double gdB = chain(N - 1, s, false);
-    if (on) { L[S::Tt + tid] = L[C::sP + tid]; L[S::Sg + tid] = L[C::sPi + tid]; }
-    K.sync();
-    const double gdA = chain(s - 1, 0, true);
-    if (on) { L[C::sP + tid] = L[S::Tt + tid]; L[C::sPi + tid] = L[S::Sg + tid]; L[S::GDB + tid] = gdB; L[S::GDA + tid] = gdA; }
+    // chain B's stage k leaves record k - 1 (k = s: the junk record -1 -- record s-1 belongs to chain A), chain A's stage k record k - 1
+    auto recB = [&](int k) { return k > s ? k - 1 : -1; };
+    // one stage of chain B alone (odd N: chain B is one stage longer)
+    auto stage1B = [&](int k, bool last) {
+        Tmp t;
+        double Sm[m * m], Li[m * m];
+        h1_load(oB, t, k, s);
+        h1_comp(oB, stB, t, k, cN, last);
+        msync();
+        h2_load(oB, t, Sm);
+        okall = chol_inv<m>(Sm, Li) && okall;
+        h2_comp(oB, stB, t, Li, k, recB(k));
+        msync();
+    };
+    // one stage of both chains
+    // GUSTO_STAGE_PROF (with GUSTO_PROFILE): time stamps INSIDE a stage, read asynchronously (s_memtime is issued where the wave
+    // is, its result only waited for at the end of the stage)
+#if defined(GUSTO_PROFILE) && defined(GUSTO_STAGE_PROF)
+#define STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define STAMPS_END() do { pf.acc[PF_FPRE] += (long long)(t1_ - t0_); pf.acc[PF_FAB] += (long long)(t2_ - t1_); \
+                          pf.acc[PF_F4] += (long long)(t3_ - t2_); pf.acc[PF_F5] += (long long)(t4_ - t3_); pf.acc[PF_FCD] += (long long)(t5_ - t4_); } while (0)
+#else
+#define STAMP(v) do {} while (0)
+#define STAMPS_END() do {} while (0)
+#endif
+    auto stage2 = [&](int kB, bool lastB, int kA, const PGC& cA) {
+        Tmp tB, tA;
+        double SmB[m * m], SmA[m * m], LiB[m * m], LiA[m * m];
+        STAMP(t0_);
+        h1_load(oB, tB, kB, s);
+        h1_load(oA, tA, kA, 0);
+        h1_comp(oB, stB, tB, kB, cN, lastB);
+        h1_comp(oA, stA, tA, kA, cA, false);
+        STAMP(t1_);
+        msync();
+        h2_load(oB, tB, SmB);
+        h2_load(oA, tA, SmA);
+        STAMP(t2_);
+        okall = chol_inv<m>(SmB, LiB) && okall;
+        okall = chol_inv<m>(SmA, LiA) && okall;
+        STAMP(t3_);
+        h2_comp(oB, stB, tB, LiB, kB, recB(kB));
+        h2_comp(oA, stA, tA, LiA, kA, kA - 1);
+        STAMP(t4_);
+        msync();
+        STAMP(t5_);
+        STAMPS_END();
+    };
+#undef STAMP
+#undef STAMPS_END
+    int kB = N - 1;
+    if (nB > nA) { stage1B(kB, true); kB--; }
+    for (int t = 0; t + 1 < nA; t++) stage2(kB - t, kB - t == N - 1, s - 1 - t, cN);
+    stage2(s, s == N - 1, 0, c0);
+    if (on) { L[S::GDB + tid] = stB.gdR; L[S::GDA + tid] = stA.gdR; }
     if (!okall) *fail = 1.0;
     K.sync();
     (void)pf;

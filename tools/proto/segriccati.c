@@ -65,6 +65,26 @@ static int seg_chol_floor(double* L, double* Li, const double* A, int n) {
     }
     return 0;
 }
+/* Gauss-Jordan inverse WITHOUT pivoting (what a row-per-lane kernel version would like to do) */
+static int seg_inv_nopiv(double* Ainv, const double* A, int n) {
+    double W[NX * 2 * NX];
+    int w = 2 * n;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) { W[i * w + j] = A[i * n + j]; W[i * w + n + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < n; c++) {
+        if (W[c * w + c] == 0.0) return -1;
+        double d = 1.0 / W[c * w + c];
+        for (int j = 0; j < w; j++) W[c * w + j] *= d;
+        for (int r = 0; r < n; r++) {
+            if (r == c) continue;
+            double f = W[r * w + c];
+            for (int j = 0; j < w; j++) W[r * w + j] -= f * W[c * w + j];
+        }
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Ainv[i * n + j] = W[i * w + n + j];
+    return 0;
+}
 static int seg_fwd_mode(void) { const char* e = getenv("GO_SEG_FWD"); return e ? atoi(e) : 0; }     /* 1: a segment starts from the actual end state of the one before (sequential forward pass) */
 
 /* the oracle's stage recursion over lo..hi; last != 0: goal rows (ngc = ng, E term at knot N-1), else Pi starts as I (ngc = n) */
@@ -194,6 +214,14 @@ static int riccati_factor(go_problem* p, int ng, const int* gidx) {
          *   Sig = (Gdf^-1 + Pc)^-1 = G M^-1 G',   Ta = (I + Pc Gdf)^-1 = G^-T M^-1 G',   Pa = Ta Pc
          * -- products only: Gdf^-1 itself (pivots squared) is never formed */
         double G[NX * NX], Gi[NX * NX], Mi[NX * NX];
+        if (form == 2) {   /* GO_SEG_FORM=2: Ta = (I + Pc Gd)^-1 by Gauss-Jordan with partial pivoting, Sig = Gd Ta, Pa = Ta Pc: no factor of Gd at all */
+            mm(H, Pc, w->Gdf[j], n, n, n);
+            for (int i = 0; i < n; i++) H[i * n + i] += 1.0;
+            if (getenv("GO_SEG_NOPIV") ? seg_inv_nopiv(w->Ta[j], H, n) : inv_gj(w->Ta[j], H, n)) return -3;
+            mm(w->Sig[j], w->Gdf[j], w->Ta[j], n, n, n);
+            for (int i = 0; i < n; i++) for (int c = 0; c < i; c++) { const double a = 0.5 * (w->Sig[j][i * n + c] + w->Sig[j][c * n + i]); w->Sig[j][i * n + c] = a; w->Sig[j][c * n + i] = a; }
+            mm(w->Pa[j], w->Ta[j], Pc, n, n, n);
+        } else {
         if (seg_chol_floor(G, Gi, w->Gdf[j], n)) { if (getenv("GO_DEBUG")) fprintf(stderr, "seg: Gd of segment %d not PSD\n", j); return -3; }
         mm(t1, Pc, G, n, n, n);
         mtm(H, G, t1, n, n, n);
@@ -207,6 +235,7 @@ static int riccati_factor(go_problem* p, int ng, const int* gidx) {
         mm(t2, Mi, t1, n, n, n);
         mm(w->Sig[j], G, t2, n, n, n);           /* Sig = G M^-1 G' */
         mm(w->Pa[j], w->Ta[j], Pc, n, n, n);
+        }
         for (int i = 0; i < n; i++)
             for (int c = 0; c < i; c++) { const double a = 0.5 * (w->Pa[j][i * n + c] + w->Pa[j][c * n + i]); w->Pa[j][i * n + c] = a; w->Pa[j][c * n + i] = a; }
         /* Gdc_j = Gdc + Pic' Sig Pic */
