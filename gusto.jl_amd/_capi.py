@@ -50,7 +50,7 @@ class IpmOpts(C.Structure):
 
 
 class ShootOpts(C.Structure):
-    _fields_ = [("substeps", C.c_int), ("max_newton", C.c_int), ("ftol", C.c_double), ("group_pass", C.c_int)]
+    _fields_ = [("substeps", C.c_int), ("max_newton", C.c_int), ("ftol", C.c_double), ("no_group_pass", C.c_int)]
 
 
 class TrajOptParams(C.Structure):
@@ -392,7 +392,7 @@ class BatchSolver:
 
     def shoot(self, p0=None, substeps=4, max_newton=100, ftol=1e-3, group_pass=True):
         """gusto_shoot + gusto_get_shoot: indirect shooting of every problem from p0 (default: the SCP duals)."""
-        o = ShootOpts(substeps=substeps, max_newton=max_newton, ftol=ftol, group_pass=int(bool(group_pass)))
+        o = ShootOpts(substeps=substeps, max_newton=max_newton, ftol=ftol, no_group_pass=int(not group_pass))
         pv = None if p0 is None else _arr(p0).reshape(self.B, self.n)
         self._chk(self.L.gusto_shoot(self.h, None if pv is None else pv.ctypes.data, C.byref(o)), "shoot")
         B = self.B

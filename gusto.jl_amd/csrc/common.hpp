@@ -26,18 +26,6 @@ constexpr int RS_T = 0, RS_LAM = 1, RS_LAMB = 2, RS_S = 3, RS_DT = 4, RS_DL = 5,
 #ifndef GUSTO_DUBINS_WAVES
 #define GUSTO_DUBINS_WAVES 2
 #endif
-#ifndef GUSTO_PP_LDS
-#define GUSTO_PP_LDS 0   // (measured: 146 vs 141.5 ms per dubins batch with the records in LDS)
-#endif
-#ifndef GUSTO_LC_LDS
-#define GUSTO_LC_LDS 1
-#endif
-#ifndef GUSTO_PG_LDS
-#define GUSTO_PG_LDS 1
-#endif
-#ifndef GUSTO_KD_LDS_SMALL
-#define GUSTO_KD_LDS_SMALL 1
-#endif
 #ifndef GUSTO_WAVES_PER_EU
 #define GUSTO_WAVES_PER_EU 1
 #endif
@@ -136,18 +124,11 @@ template <> struct MT<GUSTO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr bool PG2 = false;
     static constexpr int pg_r0(int) { return 0; }
     static constexpr int pg_r1(int) { return 0; }
-#ifdef GUSTO_MANIFOLD_DENSE
-    static constexpr bool Anz(int, int) { return true; }
-    static constexpr bool Mnz(int, int) { return true; }
-    static constexpr bool Bnz(int, int) { return true; }
-    static constexpr bool Gnz(int, int) { return true; }
-#else
     // x = (r, v, q, w): the block pattern of astrobeeSE3 with a 4-row quaternion block
     static constexpr bool Anz(int i, int j) { return i < 3 ? j == i + 3 : (i < 6 ? false : (i < 10 ? j >= 6 : j >= 10)); }
     static constexpr bool Mnz(int i, int j) { return i < 3 ? (j == i || j == i + 3) : (i < 6 ? j == i : (i < 10 ? j >= 6 : j >= 10)); }
     static constexpr bool Bnz(int i, int j) { return j < 3 ? i == j + 3 : i == j + 7; }
     static constexpr bool Gnz(int i, int j) { return j < 3 ? (i == j || i == j + 3) : i >= 6; }
-#endif
     // (no trust region row on the manifold: the Hessian of the rows is block diagonal in r, v, q (4 rows), w)
     static constexpr int hblk(int i) { return i < 3 ? 0 : (i < 6 ? 1 : (i < 10 ? 2 : 3)); }
     static constexpr bool Hnz(int i, int j) { return hblk(i) == hblk(j); }
@@ -246,17 +227,9 @@ template <int MODEL> struct Rec {
     static constexpr int n = T::n, m = T::m, NZ = n + m;
     static constexpr int r64(int c) { return (c + 63) / 64 * 64; }
     // (+1: every record keeps at least one padding slot, the target of the lanes that hold no entry of a tile store)
-    // -DGUSTO_S_TRI=1 (a build switch, off): the freeflyerSE2 and astrobeeSE3 TrajOpt variants keep S^-1 as its upper triangle
-    // (m = 9 / 18: 45 / 171 doubles instead of 81 / 324).  Their stage-parallel phases walk the record a lane per knot at HBM
-    // latency and pay for its number of lines: astrobeeSE3 B = 256 427 -> 397 ms, freeflyerSE2 B = 1024 34.9 -> 34.5.  Off
-    // because the TrajOpt subproblems at the edge of break-down respond to the changed rounding (one S^-1 entry serving both
-    // triangles): schedules stay identical on 1024 / 256 problems, but the J_true outliers of the freeflyerSE2 sweep go
-    // 11 -> 18 of 1024 and one of the 48 problems of test_whole_runs_match_the_oracle leaves its 1e-6 objective gate
-    // (profiles/r05_trajopt_stage.txt).
-#ifndef GUSTO_S_TRI
-#define GUSTO_S_TRI 0
-#endif
-    static constexpr bool S_TRI = GUSTO_S_TRI && T::NDEF > 0 && T::n != 13;
+    // (S^-1 of the TrajOpt variants as its upper triangle was built and measured in round 5 -- astrobeeSE3 B = 256 427 -> 397 ms -- and
+    // dropped: the changed rounding moves the subproblems at the edge of break-down, profiles/r05_trajopt_stage.txt)
+    static constexpr bool S_TRI = false;
     static constexpr int NS = S_TRI ? m * (m + 1) / 2 : m * m;
     static constexpr int SQQ = r64(NZ * (NZ + 1) / 2), SNN = r64(n * n + 1), SKD = r64(2 * m * n + NS + 1);
     static constexpr int oK = 0, oD = m * n, oS = 2 * m * n;
@@ -354,35 +327,23 @@ template <int MODEL, bool ONE> struct LdsC {
     // Phicl = Phi - Gam K is ONE fma per entry from K and the model constants, so the vector sweeps rebuild their
     // operands from K, and the stage-parallel phases -- which walked these records in global memory, one cache line per
     // lane per load, ~160 loads per interior point iteration -- read them from LDS.
-#ifdef GUSTO_NO_KD_LDS
-    static constexpr bool KD_LDS = false;
-#else
     // (the 3-state model too: it keeps BOTH K | D | S^-1 -- 10 doubles per knot, for the stage-parallel phases -- and Phicl,
     // for the vector sweeps, in LDS; no select chains for the K | D | S^-1 record, no QQ record in global memory)
-    static constexpr bool KD_LDS = ONE && n <= 8 && (T::PG2 || GUSTO_KD_LDS_SMALL);
-#endif
+    static constexpr bool KD_LDS = ONE && n <= 8;
     static constexpr bool PHI_FROM_K = KD_LDS && T::PG2;   // the vector sweeps rebuild Phicl from K (double integrator)
     // the 3-state time-varying model keeps [Phi Gam] of every knot in LDS as well (12 doubles per knot): linearize() writes
     // it there, the factor sweep reads its stage operands in place (no prefetch, no staging buffer) and the stage-parallel
     // phases read M and Gam of their knot from LDS instead of walking a global record
-    static constexpr bool PG_LDS = ONE && !T::LTI && n <= 4 && GUSTO_PG_LDS;
-    // ... and the packed P | Pi record of every knot (upper triangle of P, then Pi: 15 doubles, one more as the dummy slot
-    // of the unconditional stores; record -1 exists), which the factor sweep writes and the corrector's costates read
-    static constexpr bool PP_LDS = KD_LDS && !T::PG2 && GUSTO_PP_LDS;
-    static constexpr int PPS = (n * (n + 1) / 2 + n * n + 2) & ~1;
+    static constexpr bool PG_LDS = ONE && !T::LTI && n <= 4;
     // ... and two numbers per knot from which f and A of the linearisation point follow without a sin / cos (Dyn::lin_cache):
     // the phases of an interior point iteration asked for them six times, ~140 instructions apiece in double precision
-    static constexpr bool LC_LDS = ONE && MODEL == GUSTO_DUBINS_CAR && GUSTO_LC_LDS;
+    static constexpr bool LC_LDS = ONE && MODEL == GUSTO_DUBINS_CAR;
     static constexpr int KDW = 2 * m * n + m * (m + 1) / 2;
     // ... and the slot of knot k first holds the stage cost QQ_k (NZ (NZ + 1) / 2 doubles): the residual phase writes it
     // there, factor stage k reads it and then overwrites the slot with K_k | D_k | S_k^-1 -- the factors of the previous
     // interior point iteration are dead by the time the next residual phase runs.  No QQ record in global memory at all.
     static constexpr int KDS = (KDW > NZ * (NZ + 1) / 2) ? KDW : NZ * (NZ + 1) / 2;
-#ifdef GUSTO_NO_PHICL_LDS
-    static constexpr bool PHICL_LDS = false;
-#else
     static constexpr bool PHICL_LDS = n <= 8 && !PHI_FROM_K;
-#endif
 };
 struct LdsLayout {
     int total;
@@ -390,7 +351,6 @@ struct LdsLayout {
     int kd;     // offset of K | D | S^-1 per knot in LDS (LdsC::KD_LDS), -1 if in the global workspace
     int pg;     // offset of [Phi Gam] per knot in LDS (LdsC::PG_LDS), -1 if in the global workspace
     int lc;     // offset of the linearisation cache (LdsC::LC_LDS: 2 doubles per knot), -1 if none
-    int pp;     // offset of the packed P | Pi records (LdsC::PP_LDS: N + 1 records of PPS doubles), -1 if in the global workspace
 };
 template <int MODEL> inline LdsLayout make_lds_layout(int N, bool multi_wave = false) {
     using C1 = LdsC<MODEL, true>;
@@ -406,8 +366,6 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N, bool multi_wave = f
     if (C1::PG_LDS && one) { L.pg = L.total; L.total += N * C1::n * C1::NZ; }
     L.lc = -1;
     if (C1::LC_LDS && one) { L.lc = L.total; L.total += 2 * N; }
-    L.pp = -1;
-    if (C1::PP_LDS && one) { L.pp = L.total; L.total += (N + 1) * C1::PPS; }
     return L;
 }
 

@@ -207,6 +207,9 @@ int gusto_set_decomposition(gusto_handle h, int decomposition) {
     if (!h || decomposition < GUSTO_DECOMP_AUTO || decomposition > GUSTO_DECOMP_LANE) return GUSTO_ERR_ARG;
     { int rc = setter_enter(h); if (rc) return rc; }
     // (a lane per problem exists for the models without obstacle rows -- dubins_car; the others keep their wave per problem)
+#ifndef GUSTO_WITH_LANE
+    if (decomposition == GUSTO_DECOMP_LANE) { h->err = "the lane-per-problem kernel is not in this build (-DGUSTO_WITH_LANE)"; return GUSTO_ERR_ARG; }
+#endif
     h->decomposition = decomposition;
     return GUSTO_OK;
 }

@@ -7,7 +7,11 @@
 
 #include "handle.hpp"
 #include "scp.hpp"
+// the lane-per-problem kernel of dubins_car (lane.hpp: parity-green, 4.3x slower than the wave kernel at config 3) is built only
+// with -DGUSTO_WITH_LANE; without it gusto_set_decomposition(GUSTO_DECOMP_LANE) is refused
+#ifdef GUSTO_WITH_LANE
 #include "lane.hpp"
+#endif
 
 using namespace gusto;
 
@@ -147,6 +151,7 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     return GUSTO_OK;
 }
 
+#ifdef GUSTO_WITH_LANE
 // Which decomposition a GuSTO solve of this handle runs (models that have the lane-per-problem kernel, lane.hpp): the
 // caller's choice (gusto_set_decomposition), else GUSTO_DEV_LANE=0/1, else a wave per problem -- measured on MI355X
 // (profiles/r04_lane_vs_wave.txt) the lane kernel is the slower one at every batch size of BASELINE.json: an interior point
@@ -202,6 +207,7 @@ template <int MODEL> static int launch_lane(gusto_handle h, int mode, int max_it
     h->pending = true;
     return GUSTO_OK;
 }
+#endif   // GUSTO_WITH_LANE
 
 // TrajOpt: every problem of the batch through trajopt_kernel (scp.hpp); mode 1 = one subproblem per problem (parity hook)
 template <int MODEL> static int launch_trajopt(gusto_handle h, int mode, int max_iter) {

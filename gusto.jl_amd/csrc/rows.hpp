@@ -12,15 +12,6 @@
 
 namespace gusto {
 
-#ifndef GUSTO_FIX_BATCH
-#define GUSTO_FIX_BATCH 1    // 0: the fixed rows of the 12/13-state models one memory round trip each (rounds 1-4)
-#endif
-#ifndef GUSTO_GOAL_BATCH
-#define GUSTO_GOAL_BATCH 1   // 0: BoxGoal rows one at a time (rounds 1-4)
-#endif
-#ifndef GUSTO_TO_ROW_BATCH
-#define GUSTO_TO_ROW_BATCH 1   // 0: the rows of the TrajOpt subproblem one memory round trip each (rounds 3-4)
-#endif
 #ifndef GUSTO_OBS_BATCH
 #define GUSTO_OBS_BATCH 4
 #endif
@@ -112,7 +103,7 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
         // obstacle batches; round 5): one row at a time, each row's loads wait behind the stores of the row before it and a pass
         // pays a memory round trip per row -- 17 + the active obstacles per knot here, 105 k cycles per pass for the freeflyer.
         // Same rows in the same order: bit-identical.
-        constexpr bool FB = GUSTO_FIX_BATCH && GUSTO_TO_ROW_BATCH && Op::FIX_BATCH;
+        constexpr bool FB = Op::FIX_BATCH;
 #define GUSTO_FXQ(q) (FB ? FX_OBS + (q) : -1)
         auto batch = [&](int s0, int s1, int s2, int s3) {
             if constexpr (FB) { const int fs[OBS_BATCH] = {s0, s1, s2, s3}; op.obs_load(fs); }
@@ -210,7 +201,7 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
         // Ops without a RowPre (the 12/13-state models: it does not fit their registers) borrow the obstacle batch buffer, idle
         // until the obstacle loop, for the first four state rows and again for the two control rows: a pass pays two or three
         // memory round trips for these rows instead of one per row (5 / 7).  Same rows, same order: bit-identical.
-        constexpr bool FB = GUSTO_FIX_BATCH && Op::FIX_BATCH;
+        constexpr bool FB = Op::FIX_BATCH;
         constexpr int NB1 = T::NFIX < OBS_BATCH ? T::NFIX : OBS_BATCH;
 #define GUSTO_FXB(i, fx) ((FB && (i) < NB1) ? FX_OBS + (i) : (fx))
         if constexpr (FB) {
@@ -304,7 +295,6 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
     // first: without it the last knot's lane walked 2n dependent loads of the goal bounds in every row pass -- to find, for a
     // point goal, that there is no such row -- while the other 49 lanes waited (12 k of 200 k cycles per KKT solve)
     if (c.boxmask != 0 && c.k == c.N - 1) {
-#if GUSTO_GOAL_BATCH
         // Only the last knot's lane has these rows and the other lanes wait for it, so what counts is its number of memory
         // round trips: two coordinates (four rows) at a time, their bounds and the row state the Op needs (Op::obs_load, as
         // for the obstacle rows) fetched in one batch; coordinates without a BoxGoal are skipped on the mask, without a load.
@@ -334,19 +324,6 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
                 }
             }
         });
-#else
-        static_for<0, n>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            const double lo = c.goal_lo[i], hi = c.goal_hi[i];
-            if (lo != hi) {
-                const double hw = (isfinite(hi) && isfinite(lo)) ? 0.5 * (hi - lo) : 1.0;
-                const double sc = 1.0 / fmax(1e-3, fmin(1.0, hw));
-                const double p1 = 1.0, m1 = -1.0;
-                if (isfinite(hi)) lin_row<false, i, 1>(op, slot_goal + 2 * i, ROW_HARD, xs, &p1, -hi, sc, 0.0);
-                if (isfinite(lo)) lin_row<false, i, 1>(op, slot_goal + 2 * i + 1, ROW_HARD, xs, &m1, lo, sc, 0.0);
-            }
-        });
-#endif
     }
 }
 
@@ -537,7 +514,6 @@ template <int NP, class RST = RowState, bool HDX = false> struct OpStep {
     double *gAx, *gAu, *gBx, *gBu;   // (pass 0) corrector row sums of this knot
     const RowPre<NP>* pre;           // state of the fixed-position rows, fetched in one batch (small models)
     double* hdx = nullptr;           // (HDX) H_x dx of this knot
-    double* hdu = nullptr;           // (HDX, optional) the same for the control rows: sum sigma grad grad^T du + lam hess du
     StepFrac amax;
     double c0 = 0, c1 = 0, c2 = 0;
     ObsPre ob;
@@ -590,13 +566,10 @@ template <int NP, class RST = RowState, bool HDX = false> struct OpStep {
                 cB = (1.0 - lol) * rD;
             }
         }
-        if constexpr (HDX) {
-            double* hd_ = ISU ? hdu : hdx;
-            if (!ISU || hdu) {
-                const double sw = sig * w;
+        if constexpr (HDX && !ISU) {
+            const double sw = sig * w;
 #pragma unroll
-                for (int a = 0; a < CNT; a++) hd_[I0 + a] += sw * ev.gr[a] + (lam * ev.hd[a]) * dv[I0 + a];
-            }
+            for (int a = 0; a < CNT; a++) hdx[I0 + a] += sw * ev.gr[a] + (lam * ev.hd[a]) * dv[I0 + a];
         }
         amax.test(t, dt, tau);
         amax.test(lam, dl, tau);

@@ -255,9 +255,6 @@ template <int MODEL, bool ONEWAVE> GD int scp_problem(const KParams& P, double* 
 // starts its last slice or stops inside a finite one, and a workgroup that finds nothing to take retires once it is zero.
 //   hand-off of a problem between workgroups (possibly on different XCDs): the producer writes the state, releases at
 //   agent scope, then publishes the list entry; the consumer claims an index, spins until the entry is there, acquires.
-#ifndef GUSTO_SCHED_PREEMPT
-#define GUSTO_SCHED_PREEMPT 1
-#endif
 constexpr int SCHED_SPIN_LIMIT = 1 << 20;   // (seconds of sleeping polls: a scheduler bug must not hang the GPU)
 // wave-uniform primitives: every lane of the wave executes them, the result is the same scalar in every lane
 GD int uload(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
@@ -308,7 +305,7 @@ GD int sched_pop(const KParams& P, bool& cont, int& from) {   // from: the level
         // A problem whose penalty weight has been raised (level >= 1: the long ones) goes ahead of the fresh problems.
         // SQ_HI is only a hint that such an entry may be waiting (one load instead of a scan of every list per fresh
         // problem); whatever it misses is found by the full scan below -- at the latest by the workgroup that pushed it.
-        if (GUSTO_SCHED_PREEMPT && uload(Q + SQ_HI) > 0) {
+        if (uload(Q + SQ_HI) > 0) {
             const int e = take(SCHED_LEVELS - 1, 1);
             if (e != -2) { cont = true; return e; }
         }

@@ -353,7 +353,7 @@ extern "C" {
 int gusto_default_shoot_opts(gusto_shoot_opts* o) {
     if (!o) return GUSTO_ERR_ARG;
     o->substeps = 4; o->max_newton = 100; o->ftol = 1e-3;      // shooting.jl:14: iterations = 100, ftol = 1e-3
-    o->group_pass = 1;
+    o->no_group_pass = 0;
     return GUSTO_OK;
 }
 
@@ -370,7 +370,7 @@ int gusto_shoot(gusto_handle h, const double* p0, const gusto_shoot_opts* opts) 
     gusto_shoot_opts o;
     gusto_default_shoot_opts(&o);
     if (opts) o = *opts;
-    if (o.substeps < 1 || o.max_newton < 0 || !(o.ftol > 0)) { h->err = "gusto_shoot: bad options"; return GUSTO_ERR_ARG; }
+    if (o.substeps < 1 || o.max_newton < 0 || !(o.ftol > 0) || (o.no_group_pass != 0 && o.no_group_pass != 1)) { h->err = "gusto_shoot: bad options"; return GUSTO_ERR_ARG; }
     const size_t B = h->batch_cap, N = h->N;
     if (!h->d_shX) {
         HIPCHK(h, dalloc(&h->d_shX, B * N * n)); HIPCHK(h, dalloc(&h->d_shU, B * N * m)); HIPCHK(h, dalloc(&h->d_shP, B * n));
@@ -393,7 +393,7 @@ int gusto_shoot(gusto_handle h, const double* p0, const gusto_shoot_opts* opts) 
     // two passes: a lane per problem for the first SHOOT_CAP Newton iterations (the problems that converge need 0-4), then
     // the stragglers with a group of lanes each (shoot_group_kernel)
     constexpr int SHOOT_CAP = 8;
-    S.cap = (!o.group_pass || o.max_newton <= SHOOT_CAP) ? o.max_newton : SHOOT_CAP;
+    S.cap = (o.no_group_pass || o.max_newton <= SHOOT_CAP) ? o.max_newton : SHOOT_CAP;
     S.list = h->d_shList; S.count = h->d_shList + h->batch_cap;
     S.active = h->n_active >= 0 ? h->d_active : nullptr;
     HIPCHK(h, hipMemsetAsync(S.count, 0, sizeof(int), h->stream));

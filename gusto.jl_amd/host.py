@@ -449,6 +449,11 @@ def solve_SCPshooting_batch(TOSs, TOPs, solve_method=None, init_method=init_traj
     inits = [init_method(t) if callable(init_method) else Trajectory(init_method.X.copy(), init_method.U.copy(), init_method.Tf)
              for t in TOPs]
     SCPSs = [SCPSolution(p, i) for p, i in zip(SCPPs, inits)]
+    # ONE handle solves the batch with ONE set of SCP and model parameters (gusto_set_params): a problem with another robot's
+    # mass or another trust-region schedule would silently be solved with problem 0's
+    for p in SCPPs[1:]:
+        if bytes(p.scp_params) != bytes(SCPPs[0].scp_params) or bytes(p.model_params) != bytes(SCPPs[0].model_params):
+            raise ValueError("solve_SCPshooting_batch!: all problems must share the SCP parameters and the model / robot parameters")
     bs = BatchSolver(model.model_id, N, B, hist_cap=kwarg.get("hist_cap") or _hist_cap(max_iter), device=device,
                      boxes=TOP0.PD.env.boxes, spheres=TOP0.PD.env.spheres, scp_params=SCPPs[0].scp_params,
                      model_params=SCPPs[0].model_params)

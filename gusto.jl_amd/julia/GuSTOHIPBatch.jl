@@ -5,7 +5,7 @@
 # batched indirect shooting from SP.p0 (= SCPS.dual).  Use it in place of `solve!` inside solve_SCPshooting!
 # (src/traj_opt.jl:28): `ss_sol = solve_shooting_hip!(SS, SP, SCPS)`.
 struct GustoShootOpts      # gusto_shoot_opts
-  substeps::Cint; max_newton::Cint; ftol::Cdouble; group_pass::Cint
+  substeps::Cint; max_newton::Cint; ftol::Cdouble; no_group_pass::Cint
 end
 function solve_shooting_hip!(SS::ShootingSolution, SP::ShootingProblem, SCPS::SCPSolution; substeps=4, max_newton=100, ftol=1e-3)
   h = get(GUSTO_HANDLES, SCPS, C_NULL)
@@ -14,7 +14,7 @@ function solve_shooting_hip!(SS::ShootingSolution, SP::ShootingProblem, SCPS::SC
   n, m = model.x_dim, model.u_dim
   t0 = time_ns()
   gusto_check(ccall((:gusto_shoot, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{GustoShootOpts}),
-                    h, Float64.(SP.p0), GustoShootOpts(substeps, max_newton, ftol, 1)), h, "shoot")
+                    h, Float64.(SP.p0), GustoShootOpts(substeps, max_newton, ftol, 0)), h, "shoot")
   st, it, res, p0 = zeros(Cint, 1), zeros(Cint, 1), zeros(1), zeros(n)
   X, U = zeros(n, N), zeros(m, N)
   gusto_check(ccall((:gusto_get_shoot, libgusto_hip), Cint,
@@ -201,6 +201,10 @@ function solve_SCPshooting_batch!(TOSs::Vector, TOPs::Vector, init_method=init_t
   n, m, B = model.x_dim, model.u_dim, length(TOPs)
   all(T -> typeof(T.PD.model) == typeof(model) && T.N == N, TOPs) ||
     error("solve_SCPshooting_batch!: all problems must share the model type and N")
+  # ONE handle = one set of SCP and model parameters: a batch of different robots or thresholds is refused, not solved with problem 1's
+  mp0 = gusto_model_params(TOP0.PD.robot, model)
+  all(T -> isequal(gusto_model_params(T.PD.robot, T.PD.model), mp0) && T.fixed_final_time == TOP0.fixed_final_time, TOPs) ||
+    error("solve_SCPshooting_batch!: all problems must share the model / robot parameters and the SCP parameters")
   alg0 = SCPParam_GuSTO(model)
   thr = SCPParam(model, TOP0.fixed_final_time).convergence_threshold
   sp = GustoScpParams(alg0.Δ0, alg0.ω0, alg0.ω_max, alg0.ε, alg0.ρ0, alg0.ρ1, alg0.β_succ, alg0.β_fail, alg0.γ_fail, thr)
@@ -258,7 +262,7 @@ function solve_SCPshooting_batch!(TOSs::Vector, TOPs::Vector, init_method=init_t
     gusto_check(ccall((:gusto_set_active, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cint}), h, Cint.(live)), h, "set_active")
     t0 = time_ns()
     gusto_check(ccall((:gusto_shoot, libgusto_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{GustoShootOpts}),
-                      h, C_NULL, GustoShootOpts(4, 100, 1e-3, 1)), h, "shoot")     # seeds = SCPS.dual of every problem
+                      h, C_NULL, GustoShootOpts(4, 100, 1e-3, 0)), h, "shoot")     # seeds = SCPS.dual of every problem
     st, it, res, p0 = zeros(Cint, B), zeros(Cint, B), zeros(B), zeros(n, B)
     X, U = zeros(n, N, B), zeros(m, N, B)
     gusto_check(ccall((:gusto_get_shoot, libgusto_hip), Cint,

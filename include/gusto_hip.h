@@ -222,8 +222,9 @@ typedef struct {
     int substeps;    /* RK4 steps per knot interval (default 4)             */
     int max_newton;  /* nlsolve(..., iterations = 100, ...)  shooting.jl:14 */
     double ftol;     /* nlsolve(..., ftol = 1e-3)            shooting.jl:14 */
-    int group_pass;  /* 1 (default): problems still iterating after 8 Newton steps go on with 16 lanes each; 0: a lane per
-                      * problem throughout -- the same results bit for bit, slower for the stragglers (tests compare the two) */
+    int no_group_pass;  /* 0 (default, also what a zero- or brace-initialised struct gives): problems still iterating after 8
+                         * Newton steps go on with 16 lanes each; 1: a lane per problem throughout -- the same results bit for
+                         * bit, slower for the stragglers (tests compare the two).  Any other value: GUSTO_ERR_ARG */
 } gusto_shoot_opts;
 int gusto_default_shoot_opts(gusto_shoot_opts* o);
 int gusto_shoot(gusto_handle h, const double* p0, const gusto_shoot_opts* opts);

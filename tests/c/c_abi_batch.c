@@ -78,7 +78,7 @@ int main(int argc, char** argv) {
     CHECKH(d, gusto_set_active(d, act));
     gusto_shoot_opts so;
     CHECKH(d, gusto_default_shoot_opts(&so));
-    REQUIRE(so.group_pass == 1);
+    REQUIRE(so.no_group_pass == 0);
     CHECKH(d, gusto_shoot(d, 0, &so));                       /* seeds = the SCP duals, on the device */
     int sst[BD];
     CHECKH(d, gusto_get_shoot(d, sst, 0, 0, 0, 0, 0));

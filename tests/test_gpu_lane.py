@@ -10,6 +10,18 @@ import test_gpu_parity as tp
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _needs_the_lane_kernel():
+    """csrc/lane.hpp is built only with -DGUSTO_WITH_LANE (tools/build_variant.sh lane1 1 -DGUSTO_WITH_LANE; round 6: the kernel is
+    4.3x slower than the wave kernel and off by default, so the default library does not carry it)."""
+    import gusto_jl_amd as g
+    probe = g.BatchSolver(g.DUBINS_CAR, 30, 1)
+    try:
+        probe.set_decomposition(2)
+    except g.GustoError:
+        pytest.skip("this libgusto_hip.so was built without -DGUSTO_WITH_LANE")
+
+
 @pytest.fixture
 def lane(monkeypatch):
     """every dubins_car handle the test creates gets gusto_set_decomposition(GUSTO_DECOMP_LANE)"""

@@ -3,6 +3,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 D=/tmp/fc; rm -rf $D; mkdir -p $D
 for c in FETCH_SIZE WRITE_SIZE; do
+  [ -x tools/ub/fetch_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ub/fetch_calib tools/ub/fetch_calib.hip
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $D -o $c -- tools/ub/fetch_calib > $D/$c.log 2>&1
 done
 python3 - <<'PY' | tee gpurun_out/fetch_calib.txt
