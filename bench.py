@@ -127,6 +127,33 @@ def cpu_baseline(P, g, cfg, n_sample, threads, B_gpu, algo="gusto"):
 
 
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak (MI355X_MICROARCH.md)
+LDS_PEAK_TBS = 150.0             # aggregate ds_read_b64 / b128 rate with every CU streaming (MI355X_MICROARCH.md, LDS section)
+N_CU, CLOCK_GHZ = 256, 2.4
+INFINITY_CACHE_BYTES = 256 << 20
+# what the FETCH_SIZE / WRITE_SIZE counters behind `roofline.traffic` are (MI355X_MICROARCH.md, HBM section: FETCH_SIZE derives from
+# TCC_EA0_RDREQ, "Infinity-Cache hits appear to be counted, not excluded")
+TRAFFIC_KIND = ("L2 <-> fabric bytes of one launch (FETCH_SIZE x 2 + WRITE_SIZE: every request that leaves an L2, Infinity-Cache hits "
+                "included) -- an upper bound of the HBM traffic, not HBM alone")
+
+
+def lds_level(pmc, kkt_now, avg_ms):
+    """The third bound ("an LDS-resident design additionally reports an LDS-level fraction"), from the committed SQ
+    counters of one launch, scaled by this run's KKT solves: `busy` = LDS-array cycles (SQ_LDS_IDX_ACTIVE, bank-conflict cycles
+    included) over CU-cycles of the launch; `frac` = bytes moved by the DS wave-instructions -- SQ_INSTS_LDS x 64 lanes x 8 B, the
+    kernels' DS traffic is fp64 words; ds_read_b128 counts double -- over time over the 150 TB/s the guide gives for ds_read_b64."""
+    sq = (pmc or {}).get("sq_counters_per_launch") or {}
+    if "SQ_INSTS_LDS" not in sq or not avg_ms:
+        return None
+    sc = (kkt_now / float(pmc["kkt_solves"])) if pmc.get("kkt_solves") else 1.0
+    t = avg_ms * 1e-3
+    out = {"ds_wave_instructions_per_launch": sq["SQ_INSTS_LDS"] * sc,
+           "bytes_per_launch_at_8B_per_lane": 512.0 * sq["SQ_INSTS_LDS"] * sc,
+           "achieved_tbs": 512.0 * sq["SQ_INSTS_LDS"] * sc / t / 1e12, "peak_tbs": LDS_PEAK_TBS,
+           "frac": 512.0 * sq["SQ_INSTS_LDS"] * sc / t / 1e12 / LDS_PEAK_TBS}
+    if "SQ_LDS_IDX_ACTIVE" in sq:
+        out["lds_array_busy"] = sq["SQ_LDS_IDX_ACTIVE"] * sc / (N_CU * CLOCK_GHZ * 1e9 * t)
+        out["bank_conflict_share"] = sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_LDS_IDX_ACTIVE"]
+    return out
 
 
 def committed_pmc(cfg):
@@ -212,15 +239,21 @@ def valu_fp64(pmc, kkt_now):
     return flops
 
 
-def other_configs(P, g, torch, dev_ord, steps=3, warmup=1):
+def other_configs(P, g, torch, dev_ord, steps=3, warmup=1, live=True):
     """BASELINE.json configs 3 / 4 / 5 measured in this process after the timed region of the headline config: `steps` serial
     steps each (inputs resident in HBM, HIP-event kernel time of the one launch per step), the roofline fraction priced like
     the headline's, the traffic ratio from the committed PMC summary of the same workload."""
     out = {}
-    for cfg in (3, 4, 5):
-        c = CONFIGS[cfg]
+    for cfg in (3, 4, 5, "5_notebook_tf10"):
+        c = CONFIGS[5 if cfg == "5_notebook_tf10" else cfg]
         t0 = time.perf_counter()
-        model, boxes, spheres, (x0, glo, ghi, tf) = workload(P, g, cfg, c["B"], 0)
+        if cfg == "5_notebook_tf10":
+            # SURVEY.md 8(d), config 5: "the notebook's own problem (tf = 10) reported separately" -- the config-5 generator at the
+            # notebook's horizon, problem 0 = examples/astrobeeSE3manifold.ipynb cell 1 itself
+            model = g.ASTROBEE_SE3_MANIFOLD
+            (boxes, spheres), (x0, glo, ghi, tf) = P.iss_corner_env(True), P.astrobee_manifold_batch_tf10(c["B"])
+        else:
+            model, boxes, spheres, (x0, glo, ghi, tf) = workload(P, g, cfg, c["B"], 0)
         n, m = g.MODEL_DIMS[model]
         s = g.BatchSolver(model, c["N"], c["B"], hist_cap=MAX_ITER + 34, device=dev_ord, boxes=boxes, spheres=spheres)
         dv = [torch.from_numpy(a).to(torch.device("cuda", dev_ord)) for a in (x0, glo, ghi, tf)]
@@ -241,12 +274,21 @@ def other_configs(P, g, torch, dev_ord, steps=3, warmup=1):
         kkt, scp, conv = int(st["ipm_iters"].sum()), int(st["iterations"].sum()), int(st["converged"].sum())
         alg = b_kkt * kkt + b_lin * scp
         avg = float(np.mean(ms))
-        pmc, src = committed_pmc(cfg)
+        pmc, src = committed_pmc(cfg) if cfg != "5_notebook_tf10" else (None, None)
+        ratio = (pmc or {}).get("traffic_over_algorithmic")
+        if live and cfg != "5_notebook_tf10":      # this run's own counter passes (two child rocprofv3 --pmc runs of the same seeded batch)
+            lp = live_pmc(cfg)
+            if lp:
+                ratio, src = lp["traffic_bytes_per_launch"] / float(alg), "live: two child rocprofv3 --pmc passes in this run"
         out[str(cfg)] = {
-            "workload": c["name"], "steps": steps, "ms_per_step": 1e3 * float(np.mean(wall)), "avg_launch_ms": avg,
+            "workload": c["name"] if cfg != "5_notebook_tf10" else
+                        "astrobeeSE3manifold batch=2048, N=50 at the NOTEBOOK's horizon tf = 10, problem 0 = examples/astrobeeSE3manifold.ipynb cell 1 "
+                        "(SURVEY.md 8(d): reported separately from BASELINE.json configs[4], which runs tf = 40)",
+            "steps": steps, "ms_per_step": 1e3 * float(np.mean(wall)), "avg_launch_ms": avg,
             "value": conv / float(np.mean(wall)), "unit": "converged trajectories/s", "converged": conv, "problems": c["B"],
-            "kkt_solves_per_launch": kkt, "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic_over_algorithmic": (pmc or {}).get("traffic_over_algorithmic"), "traffic_source": src,
+            "kkt_solves_per_launch": kkt, "max_scp_iters": int(st["iterations"].max()), "max_kkt_solves_of_a_problem": int(st["ipm_iters"].max()),
+            "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic_over_algorithmic": ratio, "traffic_source": src, "traffic_kind": TRAFFIC_KIND,
             "setup_s": time.perf_counter() - t0 - float(np.sum(wall)),
         }
     # ... and the second SCP algorithm behind the same seam: TrajOpt on the freeflyerSE2 batch of `bench.py --algo trajopt`
@@ -513,7 +555,7 @@ def main():
         others = None
         if args.config == 2 and not args.batch and dist is None and not args.no_extras and not trajopt and not args.no_other_configs:
             try:
-                others = other_configs(P, g, torch, dev_ord)
+                others = other_configs(P, g, torch, dev_ord, live=not args.no_live_traffic)
             except Exception as e:      # the headline line must come out whatever happens to the side measurements
                 others = {"error": f"{type(e).__name__}: {e}"[:200]}
         out = {
@@ -533,7 +575,10 @@ def main():
                                                          "over RCCL inside every step (N > 1)",
                        "batches_in_flight": D},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": TRAFFIC_KIND,
+                         # (how much of it can be Infinity-Cache hits: the launch's interior point workspace against the 256 MiB)
+                         "workspace_bytes": solver.workspace_bytes(), "infinity_cache_bytes": INFINITY_CACHE_BYTES,
+                         "lds": lds_level(pmc, ipm_iters, avg_ms) if full_batch else None,
                          "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None, "traffic_live": traffic_live,
                          # the issue-side bound next to the memory-side one (the kernels are register / LDS resident): fp64
                          # VALU (+ matrix core) flops of the launch from the committed SQ counters / this run's kernel time
@@ -552,6 +597,7 @@ def main():
             "converged": int(tot[0]), "successful": int(tot[1]), "problems": problems,
             "yield": float(tot[0]) / max(1, problems),
             "mean_scp_iters": tot[2] / max(1, problems), "mean_ipm_iters": tot[3] / max(1, problems),
+            "max_scp_iters": int(st["iterations"].max()), "max_kkt_solves_of_a_problem": int(st["ipm_iters"].max()),
             "pcie_inclusive_traj_per_s": (n_conv / pcie_s) if pcie else None, "pcie_inclusive_note": "SURVEY.md 8(d): set_problems (host) + "
             "solve + get_traj (host), median of 5, one GPU", "overlapped_traj_per_s": overlapped,
             "gathered_problems_per_step": gathered[0] if dist is not None else None, "gather_error": gather_err[0],

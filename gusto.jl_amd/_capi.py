@@ -19,7 +19,7 @@ STOP_REASON = {0: "MaxIter", 1: "Converged", 2: "SubproblemFailed", 3: "OmegaMax
 
 # every symbol include/gusto_hip.h declares
 SYMBOLS = ["gusto_default_params", "gusto_default_ipm_opts", "gusto_model_dims", "gusto_create", "gusto_destroy",
-           "gusto_last_error", "gusto_set_params", "gusto_set_ipm_opts", "gusto_set_env", "gusto_set_env_batch", "gusto_set_schedule", "gusto_set_decomposition",
+           "gusto_last_error", "gusto_set_params", "gusto_set_ipm_opts", "gusto_set_env", "gusto_set_env_batch", "gusto_set_schedule", "gusto_set_decomposition", "gusto_dev_workspace_bytes",
            "gusto_set_stream",
            "gusto_set_problems", "gusto_set_problems_dev", "gusto_solve", "gusto_solve_async", "gusto_set_active", "gusto_wait",
            "gusto_last_solve_ms", "gusto_get_traj",
@@ -125,6 +125,7 @@ def lib():
         L.gusto_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci]
         L.gusto_destroy.argtypes = [vp]
         L.gusto_dev_launch_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+        L.gusto_dev_workspace_bytes.argtypes = [vp, C.POINTER(C.c_longlong)]
         L.gusto_set_params.argtypes = [vp, C.POINTER(ScpParams), C.POINTER(ModelParams)]
         L.gusto_set_ipm_opts.argtypes = [vp, C.POINTER(IpmOpts)]
         L.gusto_set_env.argtypes = [vp, ci, vp, ci, vp]
@@ -389,6 +390,12 @@ class BatchSolver:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         self._chk(self.L.gusto_dev_launch_info(self.h, C.byref(a), C.byref(b), C.byref(c)), "dev_launch_info")
         return a.value, b.value, c.value
+
+    def workspace_bytes(self):
+        """gusto_dev_workspace_bytes: bytes of the handle's interior point workspace in HBM."""
+        v = C.c_longlong()
+        self._chk(self.L.gusto_dev_workspace_bytes(self.h, C.byref(v)), "dev_workspace_bytes")
+        return int(v.value)
 
     def shoot(self, p0=None, substeps=4, max_newton=100, ftol=1e-3, group_pass=True):
         """gusto_shoot + gusto_get_shoot: indirect shooting of every problem from p0 (default: the SCP duals)."""

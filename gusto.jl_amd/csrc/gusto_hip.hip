@@ -421,6 +421,12 @@ int gusto_dev_launch_info(gusto_handle h, int* slots, int* lds_bytes, int* per_c
     return GUSTO_OK;
 }
 
+int gusto_dev_workspace_bytes(gusto_handle h, long long* bytes) {
+    if (!h || !bytes) return GUSTO_ERR_ARG;
+    *bytes = (long long)(h->ws_doubles * sizeof(double));
+    return GUSTO_OK;
+}
+
 int gusto_last_solve_ms(gusto_handle h, double* ms) {
     if (h) { int rcw = gusto_finish(h); if (rcw) return rcw; }
     if (!h || !ms) return GUSTO_ERR_ARG;

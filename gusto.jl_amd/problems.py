@@ -184,6 +184,30 @@ def astrobee_manifold_batch(B, first=0, tf=40.0, eps=1e-4):
     return x0, glo, ghi, np.full(B, tf)
 
 
+def astrobee_manifold_notebook(eps=1e-4):
+    """The notebook's own manifold problem (examples/astrobeeSE3manifold.ipynb cell 1): the small corner maneuver r_init =
+    (11.2, -0.8, 5.6) -> r_goal = (10.9, 3.0, 5.0), q_init = (1, 0, 0, 0) -> q_goal = normalise((1, 0.2, 0.3, 0.4)) as a +-eps
+    BoxGoal, point goals on r, v, w, rest to rest, tf_guess = 10.  Returns (x_init, goal_lo, goal_hi, tf)."""
+    x0, glo, ghi = np.zeros(13), np.zeros(13), np.zeros(13)
+    x0[:3] = [11.2, -0.8, 5.6]
+    x0[6] = 1.0
+    q = np.array([1.0, 0.2, 0.3, 0.4])
+    q /= np.linalg.norm(q)
+    glo[:3] = ghi[:3] = [10.9, 3.0, 5.0]
+    glo[6:10], ghi[6:10] = q - eps, q + eps
+    return x0, glo, ghi, 10.0
+
+
+def astrobee_manifold_batch_tf10(B, first=0):
+    """SURVEY.md 8(d), config 5 "reported separately": the config-5 generator at the NOTEBOOK's horizon tf = 10 (the config itself
+    runs tf = 40), problem 0 of the stream being the notebook's own problem.  At tf = 10 a share of the random start / goal pairs
+    is out of reach of the acceleration limits: those subproblems are infeasible on both sides (device and oracle alike)."""
+    x0, glo, ghi, tf = astrobee_manifold_batch(B, first, tf=10.0)
+    if first == 0 and B > 0:
+        x0[0], glo[0], ghi[0], tf[0] = astrobee_manifold_notebook()
+    return x0, glo, ghi, tf
+
+
 # ---- batches whose problems bring their own obstacle layouts (north_star: "random initial states / obstacle layouts") ----
 def freeflyer_random_layouts(B, first=0, keep=0.6, sphere_prob=0.3):
     """One keep-out set per problem: the four table slabs (always), each of the ten notebook boxes kept with probability

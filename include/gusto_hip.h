@@ -286,6 +286,10 @@ int gusto_dev_get_prof(gusto_handle h, long long* out);
  * LDS bytes per workgroup, workgroups per CU.  GUSTO_ERR_STATE before the first launch.  (The freeflyerSE2 N = 50 kernel
  * is tuned to 4 problems per CU: 40 664 B of the 160 KiB; tests/test_gpu_parity.py guards it.) */
 int gusto_dev_launch_info(gusto_handle h, int* slots, int* lds_bytes, int* per_cu);
+/* Development hook: bytes of the handle's interior point workspace in HBM (resident workgroups x per-slot workspace; what the
+ * kernel re-reads between the phases of a KKT solve -- bench.py sets it against the 256 MiB Infinity Cache next to the
+ * L2 <-> fabric traffic it reports).  No counterpart in the reference (JuMP's model memory). */
+int gusto_dev_workspace_bytes(gusto_handle h, long long* bytes);
 
 #ifdef __cplusplus
 }

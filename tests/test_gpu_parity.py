@@ -399,6 +399,68 @@ def test_scp_parity_astrobee_manifold():
     _scp_parity(g.ASTROBEE_SE3_MANIFOLD, 50, boxes, sph, x0, glo, ghi, tf, max_iter=10, rtol=1e-3)
 
 
+def test_scp_parity_notebook_manifold_problem_tf10():
+    """The notebook's own manifold problem (examples/astrobeeSE3manifold.ipynb cell 1: tf_guess = 10, the corner maneuver) and 63
+    problems of the config-5 generator at that horizon -- BASELINE config 5 itself runs tf = 40 ("reported
+    separately").  Whole solves against the oracle; at tf = 10 some start / goal pairs are out of reach of the acceleration
+    limits and stop as SubproblemFailed at the first trip on both sides."""
+    g, go = _mods()
+    P = g.problems
+    boxes, sph = P.iss_corner_env(True)
+    x0, glo, ghi, tf = P.astrobee_manifold_batch_tf10(64)
+    nb = P.astrobee_manifold_notebook()
+    assert np.array_equal(x0[0], nb[0]) and np.array_equal(glo[0], nb[1]) and tf[0] == 10.0
+    info = _scp_parity(g.ASTROBEE_SE3_MANIFOLD, 50, boxes, sph, x0, glo, ghi, tf, max_iter=30, rtol=1e-3, max_diverged=1)
+    print("scp manifold tf = 10 (notebook problem first):", info)
+    # the notebook's problem itself converges (the reference's notebook run does; the oracle: 7 trips)
+    s = g.BatchSolver(g.ASTROBEE_SE3_MANIFOLD, 50, 1, hist_cap=40, boxes=boxes, spheres=sph)
+    s.set_problems(x0[:1], glo[:1], ghi[:1], tf[:1])
+    s.solve(30)
+    st = s.status()
+    assert bool(st["converged"][0]) and int(st["stop_reason"][0]) == 1
+
+
+@pytest.mark.parametrize("name", ["astrobee_se3", "astrobee_se3_manifold"])
+def test_adjoint_costates_out_of_distribution(name):
+    """The corrector's costates of the one-wave 12 / 13-state kernels come from the adjoint recursion, guarded by three fitted
+    thresholds (factor1w.hpp: GUSTO_ADJ_MAX_IT, GUSTO_ADJ_ACC and, for the MRP kinematics of astrobeeSE3, dt/2 w_max <= 0.65 --
+    measured at tf = 70 only).  Sweep horizons and knot counts on BOTH sides of that switch and away from the BASELINE shapes: the
+    interior point iterations of whole solves must stay within 5 % of the oracle's (whose costates are the backward-stable
+    P | Pi form) and no solve may end ALMOST_LOCALLY_SOLVED where the oracle's does not."""
+    g, go = _mods()
+    P = g.problems
+    boxes, sph = P.iss_corner_env(True)
+    if name == "astrobee_se3":
+        model, gen, grid = g.ASTROBEE_SE3, P.astrobee_se3_batch, [(tf, N) for tf in (35.0, 70.0, 140.0) for N in (28, 44, 50, 64)]
+        hw = go.default_params(go.ASTROBEE_SE3)[1].hard_limit_omega
+    else:
+        model, gen, grid = g.ASTROBEE_SE3_MANIFOLD, P.astrobee_manifold_batch, [(40.0, N) for N in (5, 20, 50)]
+        hw = None
+    B, sides = 12, set()
+    for tf_, N in grid:
+        x0, glo, ghi, tf = gen(B, first=4000, tf=tf_)
+        s = g.BatchSolver(model, N, B, hist_cap=24, boxes=boxes, spheres=sph)
+        s.set_problems(x0, glo, ghi, tf)
+        s.solve(12)
+        st, h = s.status(), s.history()
+        r = go.solve_batch(model, N, boxes, sph, x0, glo, ghi, tf, 12, 0)
+        dev_it, ora_it = int(st["ipm_iters"].sum()), int(r["ipm_iters"].sum())
+        o = go.Oracle(model, N, boxes=boxes, spheres=sph)
+        almost_dev = sum(int((h["solver_status"][b, :h["n_hist"][b]] == 2).sum()) for b in range(B))
+        almost_ora = 0
+        for b in range(B):
+            o.set_problem(x0[b], glo[b], ghi[b], tf[b])
+            almost_ora += int((o.solve(12)["solver_status"] == 2).sum())
+        if hw is not None:
+            sides.add(bool(0.5 * (tf_ / (N - 1)) * hw <= 0.65))
+        print(f"{name} tf = {tf_} N = {N}: interior point iterations device {dev_it} oracle {ora_it}; ALMOST statuses {almost_dev} / {almost_ora}")
+        assert dev_it <= 1.05 * ora_it + 8, (tf_, N, dev_it, ora_it)
+        assert almost_dev <= almost_ora, (tf_, N, almost_dev, almost_ora)
+        assert (st["converged"].astype(bool) == r["converged"].astype(bool)).mean() >= 0.9, (tf_, N)
+    if hw is not None:
+        assert sides == {True, False}       # the sweep really straddles the run-time switch
+
+
 def test_resume_equals_one_shot():
     """solve(5) then solve(25) continues from SCPS exactly like one solve(30) (scp_gusto.jl:67)."""
     g, _ = _mods()
