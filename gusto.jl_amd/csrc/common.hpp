@@ -17,6 +17,7 @@ constexpr int ROW_PEN = 1;      // L1-penalised state inequality, part of the po
 constexpr int ROW_PEN_TR = 2;   // L1-penalised trust region, not part of the post-check         :265-279
 constexpr int ROW_PEN_EQ = 3;   // j=2 half of a penalised equality, |h| < eps post-check        :297-311
 constexpr int ROW_HARD_EQ = 4;  // j=1 half of a penalised equality: 0 <= s1 <= w*h + eps
+constexpr int ROW_EQ = 5;       // hard equality h = 0 (TrajOpt's convex_state_eq rows)                  scp_trajopt.jl:200-208
 GD bool row_is_hard(int kind) { return kind == ROW_HARD || kind == ROW_HARD_EQ; }
 
 // per-row interior point state, stored [var][slot][k] so that lane k's accesses coalesce
@@ -175,9 +176,14 @@ template <> struct MT<GUSTO_TO_ASTROBEE_SE3_MANIFOLD> {
     static constexpr bool Gnz(int i, int j) { return j < G::m ? G::Gnz(i, j) : i == j - G::m; }
     static constexpr bool Hnz(int, int) { return true; }
 };
-// TrajOpt keeps convex_state_eq rows hard (scp_trajopt.jl:200-208): the manifold model's linearised quaternion norm is carried
-// as the hard band |h_k| <= 1e-4 -- the width of the notebook's own BoxGoal on the goal quaternion (the oracle's GO_TRAJOPT_EQ_BAND)
-constexpr double TRAJOPT_EQ_BAND = 1e-4;
+// TrajOpt keeps convex_state_eq rows hard (`== 0`, scp_trajopt.jl:200-208): the manifold model's linearised quaternion norm is an
+// EQUALITY ROW of the interior point method (round 6; rounds 3-5 carried it as the band |h_k| <= 1e-4, which moved the optimum of a
+// subproblem by 7 % of its objective and decided 3 % of whole runs at its edge) -- h(x_k) = 0 with a multiplier eta of either sign
+// and the constraint regularisation delta of a primal-dual method (Ipopt's delta_c):  grad h' dx - delta d_eta = -h, eliminated per
+// row like every other row: H += grad grad' / delta, coefficient eta + h / delta, d_eta = (h + grad' dx) / delta.  No slack, no
+// barrier, no step-length limit, not part of the complementarity measure; |h| is part of the primal residual, so a solve that
+// stops OPTIMAL holds the equality to the 1e-8 stopping tolerance (the oracle's GO_EQ_DELTA, ROW_EQ).
+constexpr double TRAJOPT_EQ_DELTA = 1e-8;   // (1e-6: 39 interior point iterations per subproblem instead of 15; 1e-10: solves at mu = 125 break down)
 
 // Warm start of the interior point method (gusto_ipm_opts: mu_warm, mu_warm_gain, mu_warm_max; gusto_hip.h).  The model
 // defaults, resolved on the host when a launch is prepared (mu_warm < 0 = "the model's"): measured on the BASELINE batches

@@ -114,18 +114,17 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
             quad_row<false, 0, n, GUSTO_FXQ(0)>(op, 0, ROW_HARD, xs, one, c.xp, -c.Delta, 1.0 / c.Delta, 0.0);
         } else {
             // the manifold model registers no trust region row (astrobee_se3_manifold.jl:601); its convex_state_eq row, the
-            // linearised quaternion norm (:308-313), is HARD in TrajOpt (scp_trajopt.jl:200-208): the band |h| <= TRAJOPT_EQ_BAND;
+            // linearised quaternion norm (:308-313), is HARD in TrajOpt (scp_trajopt.jl:200-208): an equality row (ROW_EQ, common.hpp);
             // csi_orientation_sign (:316-319) is penalised like every convex_state_ineq row
             const double* qp = c.xp + 6;
             const double qn = sqrt(qp[0] * qp[0] + qp[1] * qp[1] + qp[2] * qp[2] + qp[3] * qp[3]);
-            double bp[4], bm[4], c0 = qn - 1.0;
+            double bp[4], c0 = qn - 1.0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) { bp[j] = qp[j] / qn; bm[j] = -bp[j]; c0 -= qp[j] * qp[j] / qn; }
-            batch(0, 3, 4, 4);
-            lin_row<false, 6, 4, GUSTO_FXQ(0)>(op, 0, ROW_HARD, xs, bm, -c0, 1.0 / TRAJOPT_EQ_BAND, 1.0);   // (scaled to O(1) like every hard row)
-            lin_row<false, 6, 4, GUSTO_FXQ(1)>(op, 3, ROW_HARD, xs, bp, c0, 1.0 / TRAJOPT_EQ_BAND, 1.0);
+            for (int j = 0; j < 4; j++) { bp[j] = qp[j] / qn; c0 -= qp[j] * qp[j] / qn; }
+            batch(0, 4, 4, 4);
+            lin_row<false, 6, 4, GUSTO_FXQ(0)>(op, 0, ROW_EQ, xs, bp, c0, 1.0, 0.0);
             const double m1 = -1.0;
-            lin_row<false, 6, 1, GUSTO_FXQ(2)>(op, 4, ROW_PEN, xs, &m1, 0.0, kw, 0.0);
+            lin_row<false, 6, 1, GUSTO_FXQ(1)>(op, 4, ROW_PEN, xs, &m1, 0.0, kw, 0.0);
             batch(1, 2, 2, 2);
         }
         quad_row<false, 3, nv, GUSTO_FXQ(man ? 0 : 1)>(op, 1, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
@@ -377,7 +376,9 @@ template <class RST = RowState> struct OpInitT {
     int ncomp = 0;
     GD void obs_load(const int*) {}
     template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>& ev) {
-        if (row_is_hard(kind)) {
+        if (kind == ROW_EQ) {   // (eta = 0; t, s, lamb are not used by an equality row)
+            rs.at(RS_T, slot) = 1.0; rs.at(RS_LAM, slot) = 0.0; rs.at(RS_LAMB, slot) = 0.0; rs.at(RS_S, slot) = 0.0;
+        } else if (row_is_hard(kind)) {
             const double t = fmax(-ev.g, 1e-2), mu0 = (muw > 0) ? muw : 0.01;
             rs.at(RS_T, slot) = t; rs.at(RS_LAM, slot) = mu0 / t; rs.at(RS_LAMB, slot) = 0.0; rs.at(RS_S, slot) = 0.0;
             ncomp += 1;
@@ -438,7 +439,10 @@ template <int n, int m, int NP, bool LRTR = false, class RST = RowState> struct 
             lam += alpha_prev * dl;
             rs.at(RS_T, slot) = t; rs.at(RS_LAM, slot) = lam;
         }
-        if (row_is_hard(kind)) {
+        if (kind == ROW_EQ) {   // (common.hpp: TRAJOPT_EQ_DELTA; lam = the multiplier eta, t is a constant 1)
+            rp = ev.g;
+            sig = 1.0 / TRAJOPT_EQ_DELTA;
+        } else if (row_is_hard(kind)) {
             rp = ev.g + t;
             comp += t * lam;
             sig = lam * rcp_nr(t);
@@ -537,6 +541,24 @@ template <int NP, class RST = RowState, bool HDX = false> struct OpStep {
         double dt, dl, ds;
         double cA = 0, cB = 0;   // (pass 0) corrector coefficient = cA + mu_t cB
         double sig = 0;          // (HDX) the row's weight in the condensed Hessian, as OpResidHess forms it
+        if (kind == ROW_EQ) {    // d_eta = (h + grad' dx) / delta: nothing here has a sign to keep, no step-length test
+            sig = 1.0 / TRAJOPT_EQ_DELTA;
+            dl = sig * (ev.g + w);
+            if constexpr (HDX && !ISU) {
+                const double sw = sig * w;
+#pragma unroll
+                for (int a = 0; a < CNT; a++) hdx[I0 + a] += sw * ev.gr[a];
+            }
+            if (pass == 0) {     // the corrector's coefficient of an equality row has no second-order term and no mu_t
+                rs.at(RS_KA, slot) = 0.0;
+                const double cE = lam + sig * ev.g;
+                double* gA = ISU ? gAu : gAx;
+#pragma unroll
+                for (int a = 0; a < CNT; a++) gA[I0 + a] += cE * ev.gr[a];
+            }
+            if (pass) { rs.at(RS_DT, slot) = 0.0; rs.at(RS_DL, slot) = dl; rs.at(RS_DS, slot) = 0.0; }
+            return;
+        }
         if (row_is_hard(kind)) {
             const double rp = ev.g + t;
             const double rt = rcp_nr(t);
@@ -592,7 +614,7 @@ template <class RST = RowState> struct OpSlackSumT {
     double sum = 0;
     GD void obs_load(const int*) {}
     template <bool ISU, int I0, int CNT, int FX> GD void row(int slot, int kind, const RowEv<CNT>&) {
-        if (!row_is_hard(kind)) sum += rs.at(RS_S, slot);   // (the last residual pass already applied every update)
+        if (!row_is_hard(kind) && kind != ROW_EQ) sum += rs.at(RS_S, slot);   // (the last residual pass already applied every update)
     }
 };
 

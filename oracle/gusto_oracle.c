@@ -32,12 +32,20 @@
  * hard band |h_k| <= 1e-4 (two hard inequality rows): the width the notebook itself uses when it writes the equality on the
  * goal quaternion as a BoxGoal of +-1e-4 (examples/astrobeeSE3manifold.ipynb cell 1).  1e-6 was tried: the barrier weights
  * lambda / t ~ 1e8 on the quaternion block then break the Cholesky of the condensed stage Hessians in 2 of 3 problems. */
-#define GO_TRAJOPT_EQ_BAND 1e-4
+#define GO_TRAJOPT_EQ_BAND 1e-4   /* (rounds 3-5: the equality as a band; kept for the record, unused) */
+/* Round 6: a convex_state_eq row is an EQUALITY ROW of the interior point method -- h(x_k) = 0 with a multiplier eta of either sign
+ * and the constraint regularisation delta of a primal-dual method (Ipopt's delta_c): the Newton system carries  grad h' dx -
+ * delta d_eta = -h, eliminated per row like every other row (H += grad grad' / delta, coefficient eta + h / delta, d_eta =
+ * (h + grad' dx) / delta).  No slack, no barrier, no step-length limit, not part of the complementarity measure; |h| is part of
+ * the primal residual, so a solve that stops OPTIMAL holds the equality to the 1e-8 stopping tolerance.  The band had no such
+ * property: inside it the row was inactive, at its edge its barrier weights (~1e8) decided 3 % of whole runs in the last digits. */
+#define GO_EQ_DELTA 1e-8
 #define ROW_HARD 0     /* hard inequality  (scp_gusto.jl:213-221, 236-245)                  */
 #define ROW_PEN 1      /* L1-penalised state inequality, part of the post-check (:281-295)  */
 #define ROW_PEN_TR 2   /* L1-penalised trust region (:265-279), not part of the post-check  */
 #define ROW_PEN_EQ 3   /* j=2 half of a penalised equality (:297-311), |h|<eps post-check   */
 #define ROW_HARD_EQ 4  /* j=1 half of a penalised equality: 0 <= s1 <= w*h+eps, s1 -> 0     */
+#define ROW_EQ 5       /* hard equality h = 0 (TrajOpt's convex_state_eq rows, scp_trajopt.jl:200-208) */
 
 typedef struct {
     int k, isu, kind, nnz;
@@ -655,16 +663,13 @@ static void assemble_rows_trajopt(go_problem* p, const double* Xp, double s_tr, 
             r->c0 = -s_tr; r->mul = 1.0 / s_tr;
         } else {
             /* cse_quaternion_norm (manifold.jl:308-313), a convex_state_eq row: hard `== 0` here (:200-208), as the band
-             * |h| <= GO_TRAJOPT_EQ_BAND (above);  csi_orientation_sign (:316-319) penalised like every convex_state_ineq row */
+             * ROW_EQ row (GO_EQ_DELTA above);  csi_orientation_sign (:316-319) penalised like every convex_state_ineq row */
             double qn = sqrt(xp[6] * xp[6] + xp[7] * xp[7] + xp[8] * xp[8] + xp[9] * xp[9]);
             double c0 = qn - 1.0;
             for (int j = 0; j < 4; j++) c0 -= xp[6 + j] * xp[6 + j] / qn;
-            r = new_row(p, k, 0, ROW_HARD);
-            for (int j = 0; j < 4; j++) row_add(r, 6 + j, 0.0, 0.0, -xp[6 + j] / qn);
-            r->c0 = -c0; r->mul = 1.0 / GO_TRAJOPT_EQ_BAND; r->off = 1.0;   /* (scaled to O(1) like every hard row) */
-            r = new_row(p, k, 0, ROW_HARD);
+            r = new_row(p, k, 0, ROW_EQ);
             for (int j = 0; j < 4; j++) row_add(r, 6 + j, 0.0, 0.0, xp[6 + j] / qn);
-            r->c0 = c0; r->mul = 1.0 / GO_TRAJOPT_EQ_BAND; r->off = 1.0;
+            r->c0 = c0; r->mul = 1.0;
             r = new_row(p, k, 0, ROW_PEN);
             row_add(r, 6, 0.0, 0.0, -1.0);
             r->mul = kappa * mu;
@@ -1054,7 +1059,9 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
         go_row* r = &p->rows[i];
         const double* v = (r->isu ? U + r->k * m : X + r->k * n);
         double g = r->mul * row_val(r, v) - r->off;
-        if (r->kind == ROW_HARD || r->kind == ROW_HARD_EQ) {
+        if (r->kind == ROW_EQ) {
+            p->rt[i] = 1.0; p->rlam[i] = 0.0; p->rlamb[i] = 0; p->rs[i] = 0;   /* (eta = 0; t, s, lamb unused) */
+        } else if (r->kind == ROW_HARD || r->kind == ROW_HARD_EQ) {
             const double mu0 = (muw > 0) ? muw : 0.01;
             p->rt[i] = fmax(-g, 1e-2); p->rlam[i] = mu0 / p->rt[i]; p->rlamb[i] = 0; p->rs[i] = 0;
             ncomp += 1;
@@ -1099,7 +1106,9 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
             const double* v = (r->isu ? U + r->k * m : X + r->k * n);
             double g = r->mul * row_val(r, v) - r->off;
             p->rg[i] = g;
-            if (r->kind == ROW_HARD || r->kind == ROW_HARD_EQ) {
+            if (r->kind == ROW_EQ) {
+                p->rrp[i] = g;
+            } else if (r->kind == ROW_HARD || r->kind == ROW_HARD_EQ) {
                 p->rrp[i] = g + p->rt[i];
                 comp += p->rt[i] * p->rlam[i];
             } else {
@@ -1182,7 +1191,9 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
             double* H = r->isu ? p->Hu + k * m * m : p->Hx + k * n * n;
             double gr[NX];
             for (int j = 0; j < r->nnz; j++) gr[j] = r->mul * (2 * r->a[j] * (v[r->idx[j]] - r->v0[j]) + r->b[j]);
-            if (r->kind == ROW_HARD || r->kind == ROW_HARD_EQ) {
+            if (r->kind == ROW_EQ) {
+                p->rsig[i] = 1.0 / GO_EQ_DELTA;
+            } else if (r->kind == ROW_HARD || r->kind == ROW_HARD_EQ) {
                 p->rsig[i] = p->rlam[i] / p->rt[i];
             } else {
                 p->rD[i] = p->rt[i] + p->rlam[i] * p->rs[i] / p->rlamb[i];
@@ -1207,7 +1218,9 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
                 const double* v = (r->isu ? U + k * m : X + k * n);
                 double* g = r->isu ? p->gu + k * m : p->gx + k * n;
                 double ka = pass ? p->rka[i] : 0.0, kb = pass ? p->rkb[i] : 0.0, coef;
-                if (r->kind == ROW_HARD || r->kind == ROW_HARD_EQ) {
+                if (r->kind == ROW_EQ) {
+                    coef = p->rlam[i] + p->rrp[i] / GO_EQ_DELTA;
+                } else if (r->kind == ROW_HARD || r->kind == ROW_HARD_EQ) {
                     coef = (mu_t - ka + p->rlam[i] * p->rrp[i]) / p->rt[i];
                 } else {
                     double lb = p->rlamb[i], la = p->rlam[i];
@@ -1230,6 +1243,11 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
                 double ka = pass ? p->rka[i] : 0.0, kb = pass ? p->rkb[i] : 0.0, w = 0;
                 for (int j = 0; j < r->nnz; j++)
                     w += r->mul * (2 * r->a[j] * (v[r->idx[j]] - r->v0[j]) + r->b[j]) * dv[r->idx[j]];
+                if (r->kind == ROW_EQ) {   /* d_eta = (h + grad' dx) / delta; no positivity anywhere: no step-length test */
+                    p->rdt[i] = 0; p->rds[i] = 0;
+                    p->rdl[i] = (p->rrp[i] + w) / GO_EQ_DELTA;
+                    continue;
+                }
                 if (r->kind == ROW_HARD || r->kind == ROW_HARD_EQ) {
                     p->rdt[i] = -p->rrp[i] - w;
                     p->rdl[i] = (mu_t - p->rt[i] * p->rlam[i] - ka - p->rlam[i] * p->rdt[i]) / p->rt[i];
@@ -1248,6 +1266,7 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
                 double ca = 0;
                 for (int i = 0; i < nr; i++) {
                     go_row* r = &p->rows[i];
+                    if (r->kind == ROW_EQ) { p->rka[i] = 0; p->rkb[i] = 0; continue; }
                     double ta = p->rt[i] + a_max * p->rdt[i], la = p->rlam[i] + a_max * p->rdl[i];
                     ca += ta * la;
                     if (!(r->kind == ROW_HARD || r->kind == ROW_HARD_EQ))
@@ -1273,14 +1292,14 @@ static int ipm_solve(go_problem* p, const double* Xp, const double* Up, double D
             go_row* r = &p->rows[i];
             p->rt[i] += alpha * p->rdt[i];
             p->rlam[i] += alpha * p->rdl[i];
-            if (!(r->kind == ROW_HARD || r->kind == ROW_HARD_EQ)) { p->rs[i] += alpha * p->rds[i]; p->rlamb[i] -= alpha * p->rdl[i]; }
+            if (!(r->kind == ROW_HARD || r->kind == ROW_HARD_EQ || r->kind == ROW_EQ)) { p->rs[i] += alpha * p->rds[i]; p->rlamb[i] -= alpha * p->rdl[i]; }
         }
     }
     double obj = 0;
     for (int k = 0; k < N; k++)
         for (int i = 0; i < m; i++) obj += wk[k] * ((i < p->m0) ? 1.0 : GO_TRAJOPT_DEFECT_REG) * U[k * m + i] * U[k * m + i];
     for (int i = 0; i < nr; i++)
-        if (!(p->rows[i].kind == ROW_HARD || p->rows[i].kind == ROW_HARD_EQ)) obj += p->rs[i];
+        if (!(p->rows[i].kind == ROW_HARD || p->rows[i].kind == ROW_HARD_EQ || p->rows[i].kind == ROW_EQ)) obj += p->rs[i];
     info->obj = obj / kappa;
     info->res_p = res_p; info->res_d = res_d; info->mu = mu; info->iters = it; info->status = status;
     p->warm = (status == GO_SOLVER_OPTIMAL);

@@ -41,13 +41,13 @@ def test_subproblem_parity(model, mu, s_tr):
         ro = o.subproblem(X0[b], U0[b], mu, s_tr)
         assert r["status"][b] == ro["status"] and ro["status"] in (1, 2), (b, r["status"][b], ro["status"])
         tol = 5e-5 * max(1.0, mu)
-        # (manifold model: the state is determined only up to its +-1e-4 bands -- BoxGoal on q, quaternion-norm rows -- as in the
+        # (manifold model: the state is determined only up to the +-1e-4 BoxGoal on its goal quaternion -- as in the
         # GuSTO lock-step test of that model: X within 5e-4, the controls and defects at the common tolerance)
         xtol = 10 * tol if model == g.ASTROBEE_SE3_MANIFOLD else tol
         assert np.abs(r["X"][b] - ro["X"]).max() < xtol and np.abs(r["U"][b] - ro["U"]).max() < tol, b
         assert np.abs(r["D"][b] - ro["D"]).max() < tol
         assert abs(r["obj"][b] - ro["obj"]) <= 1e-6 * max(1.0, mu) * max(1.0, abs(ro["obj"]))
-        # (manifold model: x_1 is pinned, so its quaternion-norm band rows of knot 1 are constants and their multipliers free --
+        # (manifold model: x_1 is pinned, so the quaternion-norm row of knot 1 is a constant and its multiplier free --
         # the quaternion components of the init dual are determined to the complementarity tolerance only)
         ed = np.abs(r["dual"][b] - ro["dual"])
         wd = 1e-5 * max(1.0, np.abs(ro["dual"]).max()) * max(1.0, mu)
@@ -90,11 +90,23 @@ def test_subproblem_parity_of_the_multi_wave_phases(model):
     assert marginal <= 1, marginal
 
 
-@pytest.mark.parametrize("model,B", [(g.FREEFLYER_SE2, 48), (g.ASTROBEE_SE3, 24), (g.ASTROBEE_SE3_MANIFOLD, 16)])
+@pytest.mark.parametrize("model,B", [(g.FREEFLYER_SE2, 48), (g.ASTROBEE_SE3, 24), (g.ASTROBEE_SE3_MANIFOLD, 128)])
 def test_whole_runs_match_the_oracle(model, B):
     """solve_trajopt_jump! end to end: identical schedules (number of solves, s_vec, mu_vec, lengths of every vector,
-    converged, stop reason), rho / xtol / ftol / ctol / J histories and the final trajectory."""
+    converged, stop reason) on EVERY problem -- no divergence is allowed --, rho / xtol / ftol / ctol / J histories and the final
+    trajectory.
+
+    Manifold model, round 6: its convex_state_eq row (the linearised quaternion norm) is the hard equality the reference states
+    (scp_trajopt.jl:200-208; an equality row of the interior point method, common.hpp: TRAJOPT_EQ_DELTA) instead of the band
+    |h| <= 1e-4 of rounds 3-5, whose barrier weights decided 4 of these 128 runs in the last digits (SubproblemFailed on one side
+    only).  With the equality every one of the 128 schedules is identical.  What the equality does NOT give is a contracting SCP
+    loop: this model has no trust-region row (astrobee_se3_manifold.jl:601), from the sixth solve on the trust-region ratio turns
+    negative, steps are rejected, and the loop amplifies the last digits of every subproblem solution by ~10x per solve
+    (tools/to_whole_diff.py, worst of 128 runs by solve index: convergence measure 9e-8, 3e-6, 3e-4, 1e-3, 6e-4, 6e-2, 0.2 ...;
+    J_true 5e-8 ... 3e-4).  So the histories of this model are compared tightly over the first three solves, J over the whole run,
+    and the per-trip agreement -- every trip of every problem from the oracle's own state -- is test_lockstep_every_trip."""
     (x0, glo, ghi, tf), boxes, spheres = _setup(model, B)
+    man = model == g.ASTROBEE_SE3_MANIFOLD
     s = g.TrajOptSolver(model, 50, B, boxes=boxes, spheres=spheres)
     s.set_problems(x0, glo, ghi, tf)
     s.solve(125)
@@ -117,64 +129,26 @@ def test_whole_runs_match_the_oracle(model, B):
         soft = (sd != so) & np.isin(sd, (1, 2)) & np.isin(so, (1, 2))
         assert np.array_equal(sd[~soft], so[~soft]), b
         n_soft += int(soft.sum())
-        # (rho is a ratio of differences; the manifold model's states float inside their 1e-4 bands: 1e-3 there, measured 1.1e-4)
-        rt = 1e-3 if model == g.ASTROBEE_SE3_MANIFOLD else 1e-4
-        # (... and where the ratio is one of two small differences -- rho = -43.6 in a run of this set -- 1.3e-3: gated at 3e-3)
-        assert np.allclose(h["rho_vec"][b, :S + 1], R["rho_vec"], rtol=3 * rt if model == g.ASTROBEE_SE3_MANIFOLD else rt, atol=1e-8)
-        for k, ref in (("xtol_vec", R["xtol_vec"]), ("ftol_vec", R["ftol_vec"]), ("ctol_vec", R["ctol_vec"])):
-            assert np.allclose(h[k][b, :len(ref)], ref, rtol=rt, atol=1e-9 if rt == 1e-4 else 1e-6), (b, k)
-        assert np.allclose(h["J_true"][b, :S + 1], R["J_true"], rtol=1e-7 if model != g.ASTROBEE_SE3_MANIFOLD else 2e-5, atol=1e-12)   # (manifold: measured 6.5e-6, its states float inside the 1e-4 bands; beyond this set: 11 of 1024 freeflyerSE2 runs up to 2.4e-5, tools/to_sweep.py)
-        # (manifold model: its states float inside the +-1e-4 bands of the quaternion rows, test_subproblem_parity: the
-        # objective of a solve agrees to 1e-4 (measured 4.4e-5, on the cold first solve of a run), the final X to 5e-4)
-        man = model == g.ASTROBEE_SE3_MANIFOLD
-        assert np.allclose(h["J_full"][b, :S], R["J_full"], rtol=3e-4 if man else 1e-6, atol=1e-9)   # (manifold: measured 1.2e-4 on the second solve of a run)
-        assert np.allclose(h["convergence_measure"][b, 1:S + 1], R["conv"][1:S + 1], rtol=1e-4, atol=1e-9 if not man else 1e-6)
-        assert np.abs(X[b] - R["X"]).max() < (10 if man else 1) * 5e-5 * R["mu_vec"][-1] and np.abs(U[b] - R["U"]).max() < 5e-5 * R["mu_vec"][-1], b
-    assert trips >= 5 * B and n_soft <= 2, (trips, n_soft)
-
-
-def test_manifold_divergences_are_breakdowns_of_the_second_solve():
-    """Whole runs of the first 128 manifold problems (tools/to_sweep.py, profiles/r05_trajopt_parity_sweep.txt: the freeflyerSE2
-    and astrobeeSE3 sweeps have identical schedules on every problem): at least 95 % identical schedules, and every problem
-    that parts does so in ONE way -- both sides solve the FIRST subproblem to the same optimum; the second solve one side
-    finishes (OPTIMAL, ~15 iterations) and the other abandons after ~16 iterations with SOLVER_FAILED -> SubproblemFailed
-    (scp_trajopt.jl:106-109 as built), far from the iteration cap (raising it to 150 changes nothing):
-    the interior point iteration breaks down (a pivot of a condensed stage Hessian that is not positive in floating point, or
-    the complementarity running away from it).  The hard band |h_k| <= 1e-4 of this model's quaternion rows puts barrier
-    weights ~1e8 into those Hessians (section 4: at 1e-6 most solves break down); which side's rounding trips is decided in the
-    last digits and moves with any change of summation order (four problems of 128 in every build so far, not always the same
-    four) -- mostly the oracle's."""
-    B = 128
-    (x0, glo, ghi, tf), boxes, spheres = _setup(g.ASTROBEE_SE3_MANIFOLD, B)
-    s = g.TrajOptSolver(g.ASTROBEE_SE3_MANIFOLD, 50, B, boxes=boxes, spheres=spheres)
-    s.set_problems(x0, glo, ghi, tf)
-    s.solve(125)
-    st, h = s.status(), s.history()
-    o = go.OracleTrajOpt(g.ASTROBEE_SE3_MANIFOLD, 50, boxes=boxes, spheres=spheres)
-    cap = g.default_ipm_opts().max_iter
-    FAILED = 2                                            # GUSTO_STOP_SUBPROBLEM_FAILED (gusto_hip.h)
-    div, dev_failed = [], 0
-    for b in range(B):
-        o.set_problem(x0[b], glo[b], ghi[b], tf[b])
-        R = o.solve_trajopt(125)
-        Sd, So = int(st["iterations"][b]), int(R["solves"])
-        d_stop, o_stop = int(st["stop_reason"][b]), int(R["stop_reason"])
-        if Sd == So and d_stop == o_stop and bool(st["converged"][b]) == R["converged"] and np.array_equal(h["s_vec"][b, :So + 1], R["s_vec"]):
+        if man:   # (see the docstring: the first three solves at 1e-3 / 1e-5, J over the whole run, the final state loosely)
+            E = min(S, 3)
+            assert np.allclose(h["rho_vec"][b, :E + 1], R["rho_vec"][:E + 1], rtol=1e-3, atol=1e-8), b
+            assert np.allclose(h["xtol_vec"][b, :E + 1], R["xtol_vec"][:E + 1], rtol=1e-3, atol=1e-9), b
+            assert np.allclose(h["convergence_measure"][b, 1:E + 1], R["conv"][1:E + 1], rtol=1e-3, atol=1e-9), b
+            assert np.allclose(h["J_true"][b, :E + 1], R["J_true"][:E + 1], rtol=1e-5, atol=1e-12), b
+            assert np.allclose(h["J_full"][b, :E], R["J_full"][:E], rtol=1e-4, atol=1e-9), b
+            assert np.allclose(h["J_true"][b, :S + 1], R["J_true"], rtol=2e-3, atol=1e-12), b          # (measured 2.9e-4)
+            assert np.abs(X[b] - R["X"]).max() < 0.1 * R["mu_vec"][-1], b                                # (measured 2.4e-2)
             continue
-        div.append(b)
-        assert min(Sd, So) == 1 and max(Sd, So) >= 4, (b, Sd, So)                       # one side stops after its first solve
-        assert FAILED in (d_stop, o_stop) and d_stop != o_stop, (b, d_stop, o_stop)
-        # the first solve: the same optimum on both sides
-        assert h["solver_status"][b, 1] in (1, 2) and R["solver_status"][1] in (1, 2)
-        assert abs(h["J_full"][b, 0] - R["J_full"][0]) <= 3e-4 * max(1.0, abs(R["J_full"][0])), b
-        assert abs(int(h["ipm_iters"][b, 1]) - int(R["ipm_iters"][1])) <= 8, b
-        if d_stop == FAILED:                              # the device's second solve broke down, well before the cap
-            dev_failed += 1
-            assert Sd == 1 and int(h["ipm_iters"][b, 2]) < cap - 20 and int(R["ipm_iters"][2]) < cap - 20, b
-        else:                                             # ... or the oracle's did, while the device finished it in a few iterations
-            assert So == 1 and h["solver_status"][b, 2] in (1, 2) and int(h["ipm_iters"][b, 2]) < cap - 20, b
-    print("manifold TrajOpt: problems whose schedules part:", div, "device-side breakdowns:", dev_failed)
-    assert len(div) <= 6 and dev_failed <= 3, (div, dev_failed)
+        rt = 1e-4
+        assert np.allclose(h["rho_vec"][b, :S + 1], R["rho_vec"], rtol=rt, atol=1e-8)
+        for k, ref in (("xtol_vec", R["xtol_vec"]), ("ftol_vec", R["ftol_vec"]), ("ctol_vec", R["ctol_vec"])):
+            assert np.allclose(h[k][b, :len(ref)], ref, rtol=rt, atol=1e-9), (b, k)
+        assert np.allclose(h["J_true"][b, :S + 1], R["J_true"], rtol=1e-7, atol=1e-12)   # (beyond this set: 11 of 1024 freeflyerSE2 runs up to 2.4e-5, tools/to_sweep.py)
+        assert np.allclose(h["J_full"][b, :S], R["J_full"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(h["convergence_measure"][b, 1:S + 1], R["conv"][1:S + 1], rtol=1e-4, atol=1e-9)
+        assert np.abs(X[b] - R["X"]).max() < 5e-5 * R["mu_vec"][-1] and np.abs(U[b] - R["U"]).max() < 5e-5 * R["mu_vec"][-1], b
+    print(f"model {model}: {B} whole runs, {trips} solves, OPTIMAL-against-ALMOST entries {n_soft}")
+    assert trips >= 5 * B and n_soft <= max(2, B // 8), (trips, n_soft)
 
 
 @pytest.mark.parametrize("model,B", [(g.FREEFLYER_SE2, 32), (g.ASTROBEE_SE3, 16), (g.ASTROBEE_SE3_MANIFOLD, 12)])
@@ -208,7 +182,7 @@ def test_lockstep_every_trip(model, B):
             trips += 1
             assert sub["status"][b] == R["solver_status"][i + 1] or {int(sub["status"][b]), int(R["solver_status"][i + 1])} == {1, 2}, (b, t)
             tol = 5e-5 * max(1.0, mu[b])
-            man = model == g.ASTROBEE_SE3_MANIFOLD       # (X inside its +-1e-4 bands, see test_subproblem_parity)
+            man = model == g.ASTROBEE_SE3_MANIFOLD       # (X inside the +-1e-4 BoxGoal of the goal quaternion, see test_subproblem_parity)
             assert np.abs(sub["X"][b] - tr[i]["Xn"]).max() < (10 if man else 1) * tol and np.abs(sub["U"][b] - tr[i]["Un"][:, :m0]).max() < tol, (b, t)
             assert np.abs(sub["D"][b] - tr[i]["Un"][:, m0:]).max() < tol
             assert abs(sub["obj"][b] - R["J_full"][i]) <= (1e-4 if man else 1e-6) * max(1.0, mu[b]) * max(1.0, abs(R["J_full"][i]))

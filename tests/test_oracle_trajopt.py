@@ -173,7 +173,7 @@ def test_manifold_subproblem_rows_as_the_reference_registers_them():
         X, U, D = r["X"], r["U"], r["D"]
         qn = np.linalg.norm(Xp[:, 6:10], axis=1)
         h = qn + ((Xp[:, 6:10] / qn[:, None]) * (X[:, 6:10] - Xp[:, 6:10])).sum(1) - 1.0
-        assert np.abs(h).max() <= 1e-4 * (1 + 1e-6)                                       # cse_quaternion_norm: hard (band)
+        assert np.abs(h).max() <= 1e-7                                                    # cse_quaternion_norm: hard `== 0` (an equality row; round 6)
         assert np.abs(X[0] - x0[b]).max() < 1e-9
         pt = glo[b] == ghi[b]
         assert np.abs(X[-1][pt] - glo[b][pt]).max() < 1e-7
@@ -204,4 +204,7 @@ def test_manifold_subproblem_rows_as_the_reference_registers_them():
         assert S >= 1 and R["stop_reason"] in (0, 1) and len(R["s_vec"]) == S + 1
         for i in range(S):
             assert R["s_vec"][i + 1] == (tp.tau_plus if R["rho_vec"][i + 1] > tp.c else tp.tau_minus) * R["s_vec"][i]
-        assert np.abs(np.linalg.norm(R["X"][:, 6:10], axis=1) - 1.0).max() < 5e-3          # near the unit sphere
+        # (|q_k| - 1 is the SECOND-order term of the last accepted step: every subproblem holds the linearised norm row exactly --
+        # round 6: an equality row, see test_manifold_subproblem... above -- and this model has no trust-region row, so the steps
+        # of a run that ends at its iteration limit are not small; measured 1.8e-3 .. 7e-2 on these problems)
+        assert np.abs(np.linalg.norm(R["X"][:, 6:10], axis=1) - 1.0).max() < 0.15
