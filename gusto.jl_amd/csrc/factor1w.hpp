@@ -594,6 +594,9 @@ template <int MODEL> GD void factor_sweep_pg2(SweepView<MODEL> K, double* fail, 
     // ordering point for LDS traffic between lanes that leaves the ALU work free to move (one wave: the hardware keeps
     // its LDS operations in order, only the compiler has to)
     auto msync = [&]() {
+#ifdef GUSTO_STRICT_SYNC
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (check build, see blk_sync)
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
     // GUSTO_STAGE_PROF (with GUSTO_PROFILE): time stamps INSIDE a stage, read asynchronously -- s_memtime is issued where the

@@ -41,6 +41,11 @@ struct IpmOut {
 // costs and which would drain the operand prefetches of the sequential sweeps at every knot.
 template <bool ONEWAVE> GD void blk_sync() {
     if constexpr (ONEWAVE) {
+#ifdef GUSTO_STRICT_SYNC
+        // (check build, tools/strict_sync.sh: every ordering point of a one-wave problem drains the wave's LDS and memory
+        // operations and passes a real barrier -- results must not move by a bit, profiles/r06_dubins_scan_repro.txt)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     } else {
