@@ -351,12 +351,25 @@ template <int MODEL, bool ONE> struct LdsC {
     static constexpr int KDS = (KDW > NZ * (NZ + 1) / 2) ? KDW : NZ * (NZ + 1) / 2;
     static constexpr bool PHICL_LDS = n <= 8 && !PHI_FROM_K;
 };
+// The KKT solve as two Riccati segments joined by a coarse LQR stage (round 6; seg.hpp): a build switch, off.
+#ifndef GUSTO_SEG2
+#define GUSTO_SEG2 0
+#endif
+// ... for the matrix-core kernels (astrobeeSE3, astrobeeSE3manifold): LDS block behind everything else, offsets relative to LdsLayout::seg
+template <int MODEL> constexpr bool seg2_big() { return GUSTO_SEG2 && MT<MODEL>::MFMA && MT<MODEL>::SWEEP_CALL && MT<MODEL>::NDEF == 0; }
+template <int MODEL> struct SegB {
+    static constexpr int n = MT<MODEL>::n, m = MT<MODEL>::m, NNp = (n * n + 1) & ~1;
+    // the coarse stage's matrices (seg.hpp: seg_coarse_factor_big), its inputs as the factor sweeps leave them, three n-vectors
+    static constexpr int Tt = 0, Sg = NNp, Pa = 2 * NNp, Gci = 3 * NNp, A1 = 4 * NNp, A2 = 5 * NNp, A3 = 6 * NNp, X1 = 7 * NNp, X2 = 8 * NNp,
+                         PB = 9 * NNp, PIB = 10 * NNp, GDA = 11 * NNp, vec = 12 * NNp, XI = vec, PBV = vec + 16, LAM = vec + 32, total = vec + 48;
+};
 struct LdsLayout {
     int total;
     int phicl;  // offset of the LDS copy of Phicl (doubles), -1 if in the global workspace or rebuilt from K
     int kd;     // offset of K | D | S^-1 per knot in LDS (LdsC::KD_LDS), -1 if in the global workspace
     int pg;     // offset of [Phi Gam] per knot in LDS (LdsC::PG_LDS), -1 if in the global workspace
     int lc;     // offset of the linearisation cache (LdsC::LC_LDS: 2 doubles per knot), -1 if none
+    int seg;    // offset of the segmented solve's block (SegB), -1 if none
 };
 template <int MODEL> inline LdsLayout make_lds_layout(int N, bool multi_wave = false) {
     using C1 = LdsC<MODEL, true>;
@@ -372,6 +385,8 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N, bool multi_wave = f
     if (C1::PG_LDS && one) { L.pg = L.total; L.total += N * C1::n * C1::NZ; }
     L.lc = -1;
     if (C1::LC_LDS && one) { L.lc = L.total; L.total += 2 * N; }
+    L.seg = -1;
+    if (seg2_big<MODEL>() && one) { L.seg = L.total; L.total += SegB<MODEL>::total; }
     return L;
 }
 

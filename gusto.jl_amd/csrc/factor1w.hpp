@@ -776,7 +776,12 @@ template <int MODEL> GD bool costate_adjoint_rt(const gusto_model_params& mp, do
 // of their record.
 // (NOPP: no P | Pi records -- the costates come from the adjoint recursion; a template parameter, chosen at run time by the
 // caller, so that the stage loop holds no branch around its stores)
-template <int MODEL, bool NOPP> GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail, Prof& pf) {
+// SEG (round 6, seg.hpp): the sweep over the stages kHi .. kLo of ONE chain of a split horizon.  Chain A (isA: the stages in front of
+// the interface) starts from P = 0, Pi = I -- its end state adjoined as a terminal equality -- and leaves its Gd in the segmented
+// solve's block (SegB::GDA); chain B (kHi = N - 1) is the sweep as it was, but its last stage leaves P_B, Pi_B in that block
+// instead of record kLo - 1, which belongs to chain A.
+template <int MODEL, bool NOPP, bool SEG = false>
+GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail, Prof& pf, int kHi_ = 0, int kLo_ = 0, bool isA = false) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NPG = n * NZ, NN = n * n;
@@ -792,6 +797,7 @@ template <int MODEL, bool NOPP> GD void factor_sweep_mfma(SweepView<MODEL> K, do
 #define FT_(id) pf.tick(id)
 #endif
     const int tid = K.tid, N = K.N;
+    const int kHi = SEG ? kHi_ : N - 1, kLo = SEG ? kLo_ : 0;
     const int mi = tid & 15, mq = tid >> 4;
     constexpr bool adj_rt = NOPP;
 #if defined(GUSTO_PROFILE) && !defined(GUSTO_PROFILE_COARSE)   // finer stamps of a stage (slots 40..47): the value is made a VGPR operand first, so the stamp waits for it
@@ -849,20 +855,20 @@ template <int MODEL, bool NOPP> GD void factor_sweep_mfma(SweepView<MODEL> K, do
 #pragma unroll
         for (int r = 0; r < RT; r++) {
             const int e = tid + 64 * r;
-            if (e < SP::NS) K.sPG[((N - 1) & 1) * NPG + doff[r]] = K.PGS[(size_t)(N - 1) * SP::S + e];
+            if (e < SP::NS) K.sPG[(kHi & 1) * NPG + doff[r]] = K.PGS[(size_t)kHi * SP::S + e];
         }
     } else {
 #pragma unroll
     for (int r = 0; r < RT; r++) {
         const int e = tid + 64 * r;
-        if (e < NPG) K.sPG[((N - 1) & 1) * NPG + e] = K.PGk(N - 1)[e];
+        if (e < NPG) K.sPG[(kHi & 1) * NPG + e] = K.PGk(kHi)[e];
     }
     }
 #pragma unroll
     for (int r = 0; r < RN; r++) {
         const int e = tid + 64 * r;
         if (!adj_rt)
-        if (e < NN) { K.Paft[(size_t)(N - 1) * R::SNN + e] = 0.0; K.Piaft[(size_t)(N - 1) * R::SNN + e] = 0.0; }
+        if (e < NN) { K.Paft[(size_t)kHi * R::SNN + e] = 0.0; K.Piaft[(size_t)kHi * R::SNN + e] = (SEG && isA && e / n == e % n) ? 1.0 : 0.0; }
     }
     double qc[KS + 2 * MS], qn[KS + 2 * MS], pgn[RT];
     auto gather = [&](int kk, double* q) {   // stage cost QQ_kk in the accumulator layout of the H tiles (clamped gathers)
@@ -872,20 +878,26 @@ template <int MODEL, bool NOPP> GD void factor_sweep_mfma(SweepView<MODEL> K, do
 #pragma unroll
         for (int s = 0; s < MS; s++) { q[KS + s] = rec[quy[s] < 0 ? 0 : quy[s]]; q[KS + MS + s] = rec[quu[s] < 0 ? 0 : quu[s]]; }
     };
-    gather(N - 1, qc);
+    gather(kHi, qc);
 #pragma unroll
     for (int r = 0; r < RT; r++) pgn[r] = 0.0;
     v4d Pt = {0, 0, 0, 0}, Pit = {0, 0, 0, 0}, Gdt = {0, 0, 0, 0};
+    if constexpr (SEG) {
+        if (isA) {
+#pragma unroll
+            for (int q = 0; q < KS; q++) Pit[q] = (mq + 4 * q == mi && mi < n) ? 1.0 : 0.0;   // Pi = I behind the chain's last knot
+        }
+    }
     K.sync();
-    for (int k = N - 1; k >= 0; k--) {
+    for (int k = kHi; k >= kLo; k--) {
         const double* PGs = pg_buf<MODEL>(K, k);
-        gather((k > 0) ? k - 1 : 0, qn);
+        gather((k > kLo) ? k - 1 : kLo, qn);
         if constexpr (SPR) {
-            const auto pg = K.PGS + (size_t)((k > 0) ? k - 1 : 0) * SP::S;
+            const auto pg = K.PGS + (size_t)((k > kLo) ? k - 1 : kLo) * SP::S;
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < SP::NS) ? e : SP::NS - 1]; }
         } else {
-            const auto pg = K.PGk((k > 0) ? k - 1 : 0);
+            const auto pg = K.PGk((k > kLo) ? k - 1 : kLo);
 #pragma unroll
             for (int r = 0; r < RT; r++) { const int e = tid + 64 * r; pgn[r] = pg[(e < NPG) ? e : NPG - 1]; }
         }
@@ -1001,8 +1013,10 @@ template <int MODEL, bool NOPP> GD void factor_sweep_mfma(SweepView<MODEL> K, do
         // records (unconditional stores: lanes outside a matrix aim at the padding slot of the record)
         {
             double* phr = K.Phicl + (size_t)k * R::SNN;
-            double* par = K.Paft + (size_t)(k - 1) * R::SNN;    // (record -1 exists for k == 0)
-            double* pir = K.Piaft + (size_t)(k - 1) * R::SNN;
+            // (record -1 exists for k == 0; chain B's record kLo - 1 belongs to chain A: its last stage aims at the junk record -1)
+            const int krec = (SEG && !isA && k == kLo) ? -1 : k - 1;
+            double* par = K.Paft + (size_t)krec * R::SNN;
+            double* pir = K.Piaft + (size_t)krec * R::SNN;
             double* kdr = K.KD + (size_t)k * R::SKD;
 #pragma unroll
             for (int q = 0; q < KS; q++) {
@@ -1012,7 +1026,7 @@ template <int MODEL, bool NOPP> GD void factor_sweep_mfma(SweepView<MODEL> K, do
 #pragma unroll
             for (int s = 0; s < MS; s++) { kdr[oKr[s]] = Kt[s]; kdr[oDr[s]] = Dt[s]; kdr[oSr[s]] = Si[s]; }
         }
-        if (k > 0) {
+        if (k > kLo) {
 #pragma unroll
             for (int r = 0; r < RT; r++) {
                 const int e = tid + 64 * r;
@@ -1025,6 +1039,20 @@ template <int MODEL, bool NOPP> GD void factor_sweep_mfma(SweepView<MODEL> K, do
         FT_(PF_FCD);
     }
     // Gd = sum V^T V for the goal system of the mid phase
+    if constexpr (SEG) {
+        using SB = SegB<MODEL>;
+        const LPtr<double> L = K.lds;
+#pragma unroll
+        for (int q = 0; q < KS; q++) {
+            const int row = mq + 4 * q;
+            if (row < n && mi < n) {
+                if (isA) L[K.seg_off + SB::GDA + row * n + mi] = Gdt[q];
+                else { K.sGd[row * n + mi] = Gdt[q]; L[K.seg_off + SB::PB + row * n + mi] = Pt[q]; L[K.seg_off + SB::PIB + row * n + mi] = Pit[q]; }
+            }
+        }
+        K.sync();
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < KS; q++) { const int row = mq + 4 * q; if (row < n && mi < n) K.sGd[row * n + mi] = Gdt[q]; }
     K.sync();

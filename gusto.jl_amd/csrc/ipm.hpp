@@ -1097,7 +1097,7 @@ template <int MODEL> struct SweepView {
     std::conditional_t<C::PHICL_LDS, LPtr<double>, GPtr<double>> Phicl;
     LPtr<double> kdl;   // K | D | S^-1 per knot in LDS (LdsC::KD_LDS; the double integrator's sweeps rebuild Phicl from it)
     LPtr<double> pgl;   // [Phi Gam] per knot in LDS (LdsC::PG_LDS)
-    int pg_off;
+    int pg_off, seg_off;
     const gusto_model_params* mpp;
     struct PW { const gusto_model_params& mp; } ;
     int tid, N;
@@ -1132,7 +1132,7 @@ template <int MODEL> struct SweepView {
     }
     template <class BLK> GD static SweepView make(const BLK& K) {
         SweepView v;
-        v.N = K.N; v.phicl_off = K.P.ll.phicl; v.kd_off = K.P.ll.kd; v.pg_off = K.P.ll.pg;
+        v.N = K.N; v.phicl_off = K.P.ll.phicl; v.kd_off = K.P.ll.kd; v.pg_off = K.P.ll.pg; v.seg_off = K.P.ll.seg;
         if constexpr (!C::PHICL_LDS) v.Phicl = K.Phicl;   // (LDS copy of the small models: set by rebind_lds)
         v.rebind_lds(K.lds);
         v.PG = K.PG; v.PGS = K.PGS; v.QQ = K.QQ; v.Paft = K.Paft; v.Piaft = K.Piaft; v.KD = K.KD;
@@ -1746,7 +1746,9 @@ template <int MODEL, class BLK> GD void inv_spd_block(BLK& K, double* fail) {
 // The phase between the two vector sweeps of a right-hand side: feed-forward d0 = S^-1 lu, the goal multiplier
 // mu_g = Gd^-1 theta, then d_k = d0 + D_k mu_g and ct_k = c_k - Gam_k d_k.  A function of its own so that the models
 // with MT::SWEEP_CALL can run it as a real call (own register allocation; everything it touches lives in LDS / HBM).
-template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, double hdt, double* red, double* mugn, Prof* pf = nullptr) {
+// SEG (round 6, seg.hpp: the matrix-core kernels' segmented solve): theta is summed per chain, the coarse stage gives mu_g, the
+// interface state xi and the increment dlam on the interface costate, and a knot of chain A takes dlam where one of chain B takes mu_g.
+template <int MODEL, class BLK, bool SEG = false> GD void mid_phase(BLK& K, int k, bool act, double hdt, double* red, double* mugn, Prof* pf = nullptr) {
 #define MT_(i) do { if (pf) pf->tick(i); } while (0)
     MT_(PF_MID);
     using T = MT<MODEL>;
@@ -1874,6 +1876,45 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         }
     }
     MT_(PF_M_TH);
+    [[maybe_unused]] int seg_s = 0;
+    if constexpr (SEG) {
+        // theta of chain A (= a, the end state it reaches for lam0) and of chain B (with the goal terms); then the coarse stage: lane
+        // i < n forms row i, three levels of matrix-vector products, the vectors travel by v_readlane (seg.hpp: mid_phase_seg)
+        using SB = SegB<MODEL>;
+        const LPtr<double> L = K.lds;
+        const int sb = K.P.ll.seg;
+        seg_s = K.N >> 1;
+        double r2[2 * n];
+#pragma unroll
+        for (int j = 0; j < n; j++) { r2[j] = (k < seg_s) ? th[j] : 0.0; r2[n + j] = (k < seg_s) ? 0.0 : th[j]; }
+        wave_reduce_n<2 * n>(r2, OpSum());
+        MT_(PF_M_RED);
+        const int ri = K.tid < n ? K.tid : 0;
+        double ph[n];
+#pragma unroll
+        for (int l = 0; l < n; l++) ph[l] = L[sb + SB::PBV + l] - K.nu[seg_s * n + l];   // p_B - lam0
+        double v1 = 0, v2 = 0, v3 = 0;
+#pragma unroll
+        for (int l = 0; l < n; l++) {
+            v1 += L[sb + SB::Tt + ri * n + l] * r2[l];
+            v2 += L[sb + SB::Sg + ri * n + l] * ph[l];
+            v3 += L[sb + SB::Pa + ri * n + l] * r2[l] + L[sb + SB::Tt + l * n + ri] * ph[l];
+        }
+        const double w1 = v1 - v2;
+        double w1v[n], muv[n];
+#pragma unroll
+        for (int l = 0; l < n; l++) w1v[l] = readlane_f64(w1, l);
+        double mu = 0;
+#pragma unroll
+        for (int l = 0; l < n; l++) mu += L[sb + SB::Gci + ri * n + l] * r2[n + l] + L[sb + SB::A1 + ri * n + l] * w1v[l];
+        mu = K.is_goal(ri) ? mu : 0.0;
+#pragma unroll
+        for (int l = 0; l < n; l++) muv[l] = readlane_f64(mu, l);
+        double xi = w1, dl = v3;
+#pragma unroll
+        for (int l = 0; l < n; l++) { xi -= L[sb + SB::A2 + ri * n + l] * muv[l]; dl += L[sb + SB::A3 + ri * n + l] * muv[l]; }
+        if (K.tid < n) { mugn[K.tid] = mu; L[sb + SB::XI + K.tid] = xi; L[sb + SB::LAM + K.tid] = dl; }
+    } else
     if constexpr (BLK::ONE) {
         if (K.goalmask != 0) wave_reduce_n<n>(th, OpSum());
         else {
@@ -1884,6 +1925,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
 #pragma unroll
     for (int j = 0; j < n; j++) th[j] = (K.goalmask != 0) ? block_reduce<BLK::ONE>(th[j], OpSum(), red) : 0.0;
     }
+    if constexpr (!SEG) {
     MT_(PF_M_RED);
     if constexpr (n > 4) {
         if (k < n) {   // mu_g = Gd^-1 theta, a lane per row (theta is wave-uniform after the reductions): as lane 0's loop it was n^2
@@ -1903,6 +1945,7 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
             mugn[j] = K.is_goal(j) ? s : 0.0;
         }
     }
+    }
     K.sync();
     MT_(PF_M_MU);
     if (act) {  // d_k = d0 + D_k mu_g ; ct_k = c_k - Gam_k d_k
@@ -1911,7 +1954,11 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
         for (int i = 0; i < m; i++) {
             double s = d0[i];
 #pragma unroll
-            for (int j = 0; j < n; j++) s += (KEEP_D ? Dk[i * n + j] : K.kd(k, R::oD + i * n + j)) * mugn[j];
+            for (int j = 0; j < n; j++) {
+                double mlt = mugn[j];
+                if constexpr (SEG) mlt = (k < seg_s) ? K.lds[K.P.ll.seg + SegB<MODEL>::LAM + j] : mlt;
+                s += (KEEP_D ? Dk[i * n + j] : K.kd(k, R::oD + i * n + j)) * mlt;
+            }
             dk[i] = s;
             K.dv_(k, i) = s;
         }
@@ -1949,10 +1996,10 @@ template <int MODEL, class BLK> GD void mid_phase(BLK& K, int k, bool act, doubl
     MT_(PF_M_SYNC);
 #undef MT_
 }
-template <int MODEL, class BLK> __device__ __noinline__ void mid_phase_call(typename BLK::Args a, int k, bool act, double hdt, Prof* pf) {
+template <int MODEL, class BLK, bool SEG = false> __device__ __noinline__ void mid_phase_call(typename BLK::Args a, int k, bool act, double hdt, Prof* pf) {
     BLK K(a, gusto_dyn_lds);
     using C = typename BLK::C;
-    mid_phase<MODEL>(K, k, act, hdt, gusto_dyn_lds + C::misc, gusto_dyn_lds + C::misc + 48, pf);
+    mid_phase<MODEL, BLK, SEG>(K, k, act, hdt, gusto_dyn_lds + C::misc, gusto_dyn_lds + C::misc + 48, pf);
 }
 
 // The phase after the forward sweep of a right-hand side: primal step of this knot, the new costates, row steps and
@@ -2344,9 +2391,6 @@ __device__ __noinline__ ResidOut resid_phase_call(typename BLK::Args a, RowScal 
 
 // The KKT solve as two Riccati segments joined by a coarse LQR stage (round 6; seg.hpp): parity-green, slower on one wave -- the
 // sequential phases are ISSUE-bound, not latency-bound (profiles/r06_two_chains.txt).  A build switch, off.
-#ifndef GUSTO_SEG2
-#define GUSTO_SEG2 0
-#endif
 #if GUSTO_SEG2
 }  // namespace gusto
 #include "seg.hpp"
@@ -2376,7 +2420,8 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     double* mug = K.misc + 32;   // goal multipliers (state-index space)
     double* mugn = K.misc + 48;  // ... of the current Newton step
     // the horizon split into two Riccati segments (seg.hpp): chain A = stages 0 .. seg_s - 1, chain B = seg_s .. N - 1
-    constexpr bool SEG = seg2_model<MODEL>() && BLK::ONE;
+    constexpr bool SEG = (seg2_model<MODEL>() || seg2_big<MODEL>()) && BLK::ONE;
+    constexpr bool SEGB = seg2_big<MODEL>() && BLK::ONE;   // ... of the matrix-core kernels: its phases are real calls
 #if GUSTO_SEG2
     const bool seg = SEG && N >= GUSTO_SEG_MIN_N;
     const int seg_s = seg_split(N);
@@ -2436,6 +2481,9 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     }
     int status = GUSTO_SOLVER_FAILED, it = 0, n_acc = 0;
     bool adj_ok = true;   // the adjoint costates of the 12/13-state kernels are still in use (see below)
+#if GUSTO_SEG2
+    if constexpr (SEGB) adj_ok = !seg;   // (the segmented solve takes its costates from the P | Pi records: record s - 1 = (0 | I))
+#endif
     double res_p = 0, res_d = 0, mu = 0, alpha_prev = 0.0, mu_start = 0.0;
     for (it = 0;; it++) {
         GUSTO_REFRESH_K();
@@ -2506,7 +2554,15 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         // (4) factorise
         bool seg_done = false;
 #if GUSTO_SEG2
-        if constexpr (SEG) {
+        if constexpr (SEGB) {
+            if (seg) {
+                factor_sweep_seg_call<MODEL>(K.args(), &pf);
+                pf.tick(PF_FACTOR);
+                GUSTO_REFRESH_K();
+                coarse_factor_seg_call<MODEL>(K.args());
+                seg_done = true;
+            }
+        } else if constexpr (SEG) {
             if (seg) {
                 factor_sweep_pg2s<MODEL>(SweepView<MODEL>::make(K), fail, pf, seg_s);
                 pf.tick(PF_FACTOR);
@@ -2609,12 +2665,17 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             K.sync();
             pf.tick(PF_RHS);
 #if GUSTO_SEG2
-            if constexpr (SEG) { if (seg) backward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else backward_sweep<MODEL>(K); }
+            if constexpr (SEGB) { if (seg) backward_sweep_seg_call<MODEL>(K.args()); else backward_sweep<MODEL>(K); }
+            else if constexpr (SEG) { if (seg) backward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else backward_sweep<MODEL>(K); }
             else
 #endif
             backward_sweep<MODEL>(K);
             pf.tick(PF_BACK);
             GUSTO_REFRESH_K();
+#if GUSTO_SEG2
+            if constexpr (SEGB) { if (seg) mid_phase_call<MODEL, BLK, true>(K.args(), k, act, hdt, &pf); else mid_phase_call<MODEL, BLK>(K.args(), k, act, hdt, &pf); }
+            else
+#endif
             if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL, BLK>(K.args(), k, act, hdt, &pf);
 #if GUSTO_SEG2
             else if constexpr (SEG) { if (seg) mid_phase_seg<MODEL>(K, k, act, hdt, seg_s, mugn, &pf); else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf); }
@@ -2622,13 +2683,20 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf);
             pf.tick(PF_MID);
 #if GUSTO_SEG2
-            if constexpr (SEG) { if (seg) forward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else forward_sweep<MODEL>(K); }
+            if constexpr (SEGB) { if (seg) forward_sweep_seg_call<MODEL>(K.args()); else forward_sweep<MODEL>(K); }
+            else if constexpr (SEG) { if (seg) forward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else forward_sweep<MODEL>(K); }
             else
 #endif
             forward_sweep<MODEL>(K);
             if constexpr (BLK::ONE && T::SWEEP_CALL)
                 if (!adj_now)
-                if (pass == 1 || ncomp == 0) costate_pass_1w_call<MODEL>(K.args());
+                if (pass == 1 || ncomp == 0) {
+#if GUSTO_SEG2
+                    if constexpr (SEGB) { if (seg) costate_pass_seg_call<MODEL>(K.args()); else costate_pass_1w_call<MODEL>(K.args()); }
+                    else
+#endif
+                    costate_pass_1w_call<MODEL>(K.args());
+                }
             pf.tick(PF_FWD);
             GUSTO_REFRESH_K();
             // primal step of this knot, the new costates, row steps + fraction to the boundary
@@ -2642,7 +2710,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
                 // (segmented solve: the costates of chain A's knots hang on dlam, those of chain B's on mu_g)
                 const double* mult = mugn;
 #if GUSTO_SEG2
-                if constexpr (SEG) mult = (seg && k < seg_s) ? (const double*)(K.misc + (SegC<MODEL>::LAM - BLK::C::misc)) : mult;
+                if constexpr (SEG && !SEGB) mult = (seg && k < seg_s) ? (const double*)(K.misc + (SegC<MODEL>::LAM - BLK::C::misc)) : mult;
 #endif
                 so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mult, gxs);
             }
