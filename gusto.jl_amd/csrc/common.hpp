@@ -351,17 +351,26 @@ template <int MODEL, bool ONE> struct LdsC {
     static constexpr int KDS = (KDW > NZ * (NZ + 1) / 2) ? KDW : NZ * (NZ + 1) / 2;
     static constexpr bool PHICL_LDS = n <= 8 && !PHI_FROM_K;
 };
-// The KKT solve as two Riccati segments joined by a coarse LQR stage (round 6; seg.hpp): a build switch, off.
+// The KKT solve as two Riccati segments joined by a coarse LQR stage (round 6; seg.hpp).
+//   GUSTO_SEG2   (off): both chains interleaved in ONE wave, freeflyerSE2 -- parity-green and slower (profiles/r06_two_chains.txt)
+//   GUSTO_SEG_W2 (on):  a WAVE PER CHAIN for the matrix-core kernels (astrobeeSE3, astrobeeSE3manifold): scp_kernel_w2, launched for
+//                       batches that leave half of the SIMDs idle (launch.hpp: seg_w2_wanted)
 #ifndef GUSTO_SEG2
 #define GUSTO_SEG2 0
 #endif
-// ... for the matrix-core kernels (astrobeeSE3, astrobeeSE3manifold): LDS block behind everything else, offsets relative to LdsLayout::seg
-template <int MODEL> constexpr bool seg2_big() { return GUSTO_SEG2 && MT<MODEL>::MFMA && MT<MODEL>::SWEEP_CALL && MT<MODEL>::NDEF == 0; }
+#ifndef GUSTO_SEG_W2
+#define GUSTO_SEG_W2 1
+#endif
+#define GUSTO_SEG_ANY (GUSTO_SEG2 || GUSTO_SEG_W2)
+template <int MODEL> constexpr bool seg2_big() { return GUSTO_SEG_W2 && MT<MODEL>::MFMA && MT<MODEL>::SWEEP_CALL && MT<MODEL>::NDEF == 0; }
+// LDS block of the segmented solve of these kernels, behind everything else (offsets relative to LdsLayout::seg)
 template <int MODEL> struct SegB {
-    static constexpr int n = MT<MODEL>::n, m = MT<MODEL>::m, NNp = (n * n + 1) & ~1;
-    // the coarse stage's matrices (seg.hpp: seg_coarse_factor_big), its inputs as the factor sweeps leave them, three n-vectors
+    static constexpr int n = MT<MODEL>::n, m = MT<MODEL>::m, NNp = (n * n + 1) & ~1, NPG = n * (n + m);
+    // the coarse stage's matrices (seg.hpp: seg_coarse_factor_big), its inputs as the factor sweeps leave them, three n-vectors,
+    // the helper wave's own [Phi Gam] double buffer and L^-1 scratch (its factor sweep runs beside the main wave's), the mailbox
     static constexpr int Tt = 0, Sg = NNp, Pa = 2 * NNp, Gci = 3 * NNp, A1 = 4 * NNp, A2 = 5 * NNp, A3 = 6 * NNp, X1 = 7 * NNp, X2 = 8 * NNp,
-                         PB = 9 * NNp, PIB = 10 * NNp, GDA = 11 * NNp, vec = 12 * NNp, XI = vec, PBV = vec + 16, LAM = vec + 32, total = vec + 48;
+                         PB = 9 * NNp, PIB = 10 * NNp, GDA = 11 * NNp, vec = 12 * NNp, XI = vec, PBV = vec + 16, LAM = vec + 32,
+                         sPG2 = vec + 48, Lw2 = sPG2 + 2 * NPG, MBX = Lw2 + 64, total = MBX + 8;
 };
 struct LdsLayout {
     int total;
@@ -371,7 +380,7 @@ struct LdsLayout {
     int lc;     // offset of the linearisation cache (LdsC::LC_LDS: 2 doubles per knot), -1 if none
     int seg;    // offset of the segmented solve's block (SegB), -1 if none
 };
-template <int MODEL> inline LdsLayout make_lds_layout(int N, bool multi_wave = false) {
+template <int MODEL> inline LdsLayout make_lds_layout(int N, bool multi_wave = false, bool seg_w2 = false) {
     using C1 = LdsC<MODEL, true>;
     using CM = LdsC<MODEL, false>;
     LdsLayout L;
@@ -386,7 +395,7 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N, bool multi_wave = f
     L.lc = -1;
     if (C1::LC_LDS && one) { L.lc = L.total; L.total += 2 * N; }
     L.seg = -1;
-    if (seg2_big<MODEL>() && one) { L.seg = L.total; L.total += SegB<MODEL>::total; }
+    if (seg2_big<MODEL>() && one && seg_w2) { L.seg = L.total; L.total += SegB<MODEL>::total; }
     return L;
 }
 

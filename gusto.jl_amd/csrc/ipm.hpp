@@ -171,7 +171,8 @@ template <int MODEL, bool ONEWAVE> struct Blk {
         Pk = &P;
         CP* Pc = (CP*)(uintptr_t)Pk;
         b = __builtin_amdgcn_readfirstlane(a.b); slot_ = __builtin_amdgcn_readfirstlane(a.slot);
-        tid = threadIdx.x; NTr = ONEWAVE ? 64 : blockDim.x; N = Pc->N;
+        tid = ONEWAVE ? (threadIdx.x & 63) : threadIdx.x;   // (the helper wave of scp_kernel_w2 runs called phases too: lanes 64..127)
+        NTr = ONEWAVE ? 64 : blockDim.x; N = Pc->N;
         rebind_lds(lds_);
         double* w = Pc->ws + (size_t)slot_ * Pc->wl.total;
         rowstate = w + Pc->wl.rowstate; obs_nh = w + Pc->wl.obs_nh; obs_c0 = w + Pc->wl.obs_c0;
@@ -2391,7 +2392,7 @@ __device__ __noinline__ ResidOut resid_phase_call(typename BLK::Args a, RowScal 
 
 // The KKT solve as two Riccati segments joined by a coarse LQR stage (round 6; seg.hpp): parity-green, slower on one wave -- the
 // sequential phases are ISSUE-bound, not latency-bound (profiles/r06_two_chains.txt).  A build switch, off.
-#if GUSTO_SEG2
+#if GUSTO_SEG_ANY
 }  // namespace gusto
 #include "seg.hpp"
 namespace gusto {
@@ -2403,7 +2404,7 @@ template <int MODEL> constexpr bool seg2_model() { return false; }
 // Register discipline: nothing per-thread stays live across a sequential sweep.  Every stage-parallel block
 // re-reads the iterate (Xw/Uw), the linearisation point (Xp/Up) and the stage matrices it needs from LDS / L2
 // and leaves its results in LDS, so the sweeps get the whole register file for latency hiding.
-template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double omega, double muw, IpmOut& out, Prof& pf) {
+template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, double Delta, double omega, double muw, IpmOut& out, Prof& pf) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NHX = n * (n + 1) / 2, NHU = m * (m + 1) / 2, NQ = NZ * (NZ + 1) / 2;
@@ -2420,9 +2421,9 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     double* mug = K.misc + 32;   // goal multipliers (state-index space)
     double* mugn = K.misc + 48;  // ... of the current Newton step
     // the horizon split into two Riccati segments (seg.hpp): chain A = stages 0 .. seg_s - 1, chain B = seg_s .. N - 1
-    constexpr bool SEG = (seg2_model<MODEL>() || seg2_big<MODEL>()) && BLK::ONE;
-    constexpr bool SEGB = seg2_big<MODEL>() && BLK::ONE;   // ... of the matrix-core kernels: its phases are real calls
-#if GUSTO_SEG2
+    constexpr bool SEGB = seg2_big<MODEL>() && BLK::ONE && W2;   // ... of the matrix-core kernels (scp_kernel_w2: a wave per chain)
+    constexpr bool SEG = (seg2_model<MODEL>() && BLK::ONE) || SEGB;
+#if GUSTO_SEG_ANY
     const bool seg = SEG && N >= GUSTO_SEG_MIN_N;
     const int seg_s = seg_split(N);
 #endif
@@ -2481,7 +2482,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
     }
     int status = GUSTO_SOLVER_FAILED, it = 0, n_acc = 0;
     bool adj_ok = true;   // the adjoint costates of the 12/13-state kernels are still in use (see below)
-#if GUSTO_SEG2
+#if GUSTO_SEG_ANY
     if constexpr (SEGB) adj_ok = !seg;   // (the segmented solve takes its costates from the P | Pi records: record s - 1 = (0 | I))
 #endif
     double res_p = 0, res_d = 0, mu = 0, alpha_prev = 0.0, mu_start = 0.0;
@@ -2553,10 +2554,12 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
         }
         // (4) factorise
         bool seg_done = false;
-#if GUSTO_SEG2
+#if GUSTO_SEG_ANY
         if constexpr (SEGB) {
-            if (seg) {
+            if (seg) {   // chain A on the helper wave, chain B here; then the coarse stage
+                segw_post<MODEL>(K, SEGW_FACTOR);
                 factor_sweep_seg_call<MODEL>(K.args(), &pf);
+                segw_join();
                 pf.tick(PF_FACTOR);
                 GUSTO_REFRESH_K();
                 coarse_factor_seg_call<MODEL>(K.args());
@@ -2664,26 +2667,26 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             }
             K.sync();
             pf.tick(PF_RHS);
-#if GUSTO_SEG2
-            if constexpr (SEGB) { if (seg) backward_sweep_seg_call<MODEL>(K.args()); else backward_sweep<MODEL>(K); }
+#if GUSTO_SEG_ANY
+            if constexpr (SEGB) { if (seg) { segw_post<MODEL>(K, SEGW_BACK); backward_sweep_seg_call<MODEL>(K.args()); segw_join(); } else backward_sweep<MODEL>(K); }
             else if constexpr (SEG) { if (seg) backward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else backward_sweep<MODEL>(K); }
             else
 #endif
             backward_sweep<MODEL>(K);
             pf.tick(PF_BACK);
             GUSTO_REFRESH_K();
-#if GUSTO_SEG2
+#if GUSTO_SEG_ANY
             if constexpr (SEGB) { if (seg) mid_phase_call<MODEL, BLK, true>(K.args(), k, act, hdt, &pf); else mid_phase_call<MODEL, BLK>(K.args(), k, act, hdt, &pf); }
             else
 #endif
             if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL, BLK>(K.args(), k, act, hdt, &pf);
-#if GUSTO_SEG2
+#if GUSTO_SEG_ANY
             else if constexpr (SEG) { if (seg) mid_phase_seg<MODEL>(K, k, act, hdt, seg_s, mugn, &pf); else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf); }
 #endif
             else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf);
             pf.tick(PF_MID);
-#if GUSTO_SEG2
-            if constexpr (SEGB) { if (seg) forward_sweep_seg_call<MODEL>(K.args()); else forward_sweep<MODEL>(K); }
+#if GUSTO_SEG_ANY
+            if constexpr (SEGB) { if (seg) { segw_post<MODEL>(K, SEGW_FWD); forward_sweep_seg_call<MODEL>(K.args()); segw_join(); } else forward_sweep<MODEL>(K); }
             else if constexpr (SEG) { if (seg) forward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else forward_sweep<MODEL>(K); }
             else
 #endif
@@ -2691,7 +2694,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             if constexpr (BLK::ONE && T::SWEEP_CALL)
                 if (!adj_now)
                 if (pass == 1 || ncomp == 0) {
-#if GUSTO_SEG2
+#if GUSTO_SEG_ANY
                     if constexpr (SEGB) { if (seg) costate_pass_seg_call<MODEL>(K.args()); else costate_pass_1w_call<MODEL>(K.args()); }
                     else
 #endif
@@ -2709,7 +2712,7 @@ template <int MODEL, class BLK> GD void ipm_solve(BLK& K, double Delta, double o
             else {
                 // (segmented solve: the costates of chain A's knots hang on dlam, those of chain B's on mu_g)
                 const double* mult = mugn;
-#if GUSTO_SEG2
+#if GUSTO_SEG_ANY
                 if constexpr (SEG && !SEGB) mult = (seg && k < seg_s) ? (const double*)(K.misc + (SegC<MODEL>::LAM - BLK::C::misc)) : mult;
 #endif
                 so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mult, gxs);

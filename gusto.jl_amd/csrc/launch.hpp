@@ -79,15 +79,29 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     if (lds > 160 * 1024) { h->err = "problem does not fit the 160 KiB LDS of a CU"; return GUSTO_ERR_ARG; }
     // a problem with N <= 64 knots runs as one wave per workgroup (no barriers at all)
     auto kern = (NT == 64) ? &scp_kernel<MODEL, true> : &scp_kernel<MODEL, false>;
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // Persistent launch: as many workgroups as the GPU keeps resident (slots), each with its own workspace
     int per_cu = 0, cus = 0;
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NT, lds));
     HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-    int slots = std::max(1, per_cu) * std::max(1, cus);
-    if (const char* e = dev_env("GUSTO_DEV_SLOTS")) slots = std::max(1, atoi(e));   // occupancy experiments
     const bool masked = mode == 0 && h->n_active >= 0;    // gusto_set_active: only the listed problems are handed out
     if (masked) P.n_fresh = h->n_active;
+    int NTL = NT;
+#if GUSTO_SEG_W2
+    // a batch that leaves half of the SIMDs without a wave (one wave per problem, <= 2 problems per CU) runs two waves per
+    // problem: the KKT solve's sequential phases as two Riccati segments side by side (scp_kernel_w2, seg.hpp)
+    if constexpr (seg2_big<MODEL>()) {
+        bool w2 = NT == 64 && h->N >= GUSTO_SEG_MIN_N && P.n_fresh <= 2 * cus;
+        if (const char* e = dev_env("GUSTO_DEV_W2")) w2 = atoi(e) != 0 && NT == 64 && h->N >= GUSTO_SEG_MIN_N;
+        if (w2) {
+            P.ll = make_lds_layout<MODEL>(h->N, false, true);
+            lds = (size_t)P.ll.total * sizeof(double);
+            kern = &scp_kernel_w2<MODEL>; NTL = 128;
+        }
+    }
+#endif
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // Persistent launch: as many workgroups as the GPU keeps resident (slots), each with its own workspace
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NTL, lds));
+    int slots = std::max(1, per_cu) * std::max(1, cus);
+    if (const char* e = dev_env("GUSTO_DEV_SLOTS")) slots = std::max(1, atoi(e));   // occupancy experiments
     slots = std::min(slots, std::max(1, P.n_fresh));
     h->slots = slots; h->lds_bytes = (int)lds; h->per_cu = per_cu;
     {
@@ -142,7 +156,7 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
         fprintf(stderr, "launch: B %d slots %d dyn %d probe %d list_cap %d queue %p lists %p..%p ws %p..%p X %p st_i %p..%p hist Delta %p\n", h->B, slots,
                 (int)dyn, P.probe_visits, P.list_cap, (void*)P.queue, (void*)P.lists, (void*)(P.lists + h->order_ints), (void*)P.ws,
                 (void*)(P.ws + h->ws_doubles), (void*)P.X, (void*)P.st_i, (void*)(P.st_i + (size_t)h->batch_cap * ST_NI), (void*)P.Delta);
-    hipLaunchKernelGGL(kern, dim3(slots), dim3(NT), lds, h->stream, P);
+    hipLaunchKernelGGL(kern, dim3(slots), dim3(NTL), lds, h->stream, P);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->sched_err = 0;

@@ -915,14 +915,63 @@ template <int MODEL> GD void costate_pass_seg(SweepView<MODEL> K, int s) {
     K.sync();
 }
 
-// the called phases of the segmented solve (this version: ONE wave, the chains one after the other)
+// ---- a wave per chain (scp_kernel_w2): the MAIN wave (lanes 0..63 of the workgroup) runs the program of the one-wave kernel and, in
+// the three sequential phases, chain B; the HELPER wave (lanes 64..127) waits at a barrier for a command and runs chain A beside
+// it.  Two workgroup barriers per phase: post (the main wave has written the command and everything the helper reads: drain, barrier)
+// and join (both have drained their stores).  The phases themselves stay barrier-free one-wave code on disjoint knots and LDS.
+constexpr int SEGW_FACTOR = 1, SEGW_BACK = 2, SEGW_FWD = 3, SEGW_EXIT = 9;
+GD void segw_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+GD void segw_join() { segw_barrier(); }
+template <int MODEL, class BLK> GD void segw_post(BLK& K, int cmd) {
+    const LPtr<double> L = K.lds;
+    const int mb = K.P.ll.seg + SegB<MODEL>::MBX;
+    if (K.tid == 0) {
+        const typename BLK::Args a = K.args();
+        L[mb] = (double)cmd;
+        L[mb + 2] = (double)a.b; L[mb + 3] = (double)a.slot; L[mb + 4] = (double)a.goalmask; L[mb + 5] = (double)a.boxmask; L[mb + 6] = a.dt;
+    }
+    segw_barrier();
+}
+// kernel exit of the main wave: release the helper for good (no join: a wave that has ended is not waited for)
+GD void segw_exit(double* lds, int seg_off, int mbx) {
+    if ((threadIdx.x & 63) == 0) lds[seg_off + mbx] = (double)SEGW_EXIT;
+    segw_barrier();
+}
+template <int MODEL> GD void segw_helper(const KParams& P, double* lds) {
+    using SB = SegB<MODEL>;
+    using BLK = Blk<MODEL, true>;
+    using C = LdsC<MODEL, true>;
+    constexpr int n = MT<MODEL>::n;
+    const LPtr<double> L = lds;
+    const int sb = P.ll.seg, mb = sb + SB::MBX;
+    Prof pfd;
+    for (;;) {
+        asm volatile("s_barrier" ::: "memory");
+        const int cmd = (int)L[mb];
+        if (cmd == SEGW_EXIT) return;
+        typename BLK::Args a;
+        a.Pk = (const KParams*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // (inlined into the kernel; KParams is its first argument)
+        a.b = (int)L[mb + 2]; a.slot = (int)L[mb + 3]; a.goalmask = (unsigned)L[mb + 4]; a.boxmask = (unsigned)L[mb + 5]; a.dt = L[mb + 6];
+        BLK B(a, lds);
+        const int N = B.N, s = seg_split(N);
+        if (cmd == SEGW_FACTOR) {
+            SweepView<MODEL> K = SweepView<MODEL>::make(B);
+            K.sPG = lds + sb + SB::sPG2; K.sHh = lds + sb + SB::Lw2;      // its own operand buffers: the main wave's sweep runs beside it
+            factor_sweep_mfma<MODEL, false, true>(K, lds + C::misc + 8, pfd, s - 1, 0, true);
+        } else if (cmd == SEGW_BACK) {
+            backward_sweep_ring_rng<MODEL>(B, s - 1, 1, C::vecs + 5 * N * n + s * n, -1);      // from pt_{s-1} = lam0 = nu_s
+        } else if (cmd == SEGW_FWD) {
+            forward_sweep_ring_rng<MODEL>(B, 0, s - 2, -1);
+        }
+        segw_barrier();
+    }
+}
+
+// the main wave's share of the three sequential phases (chain B), as called phases
 template <int MODEL> __device__ __noinline__ void factor_sweep_seg_call(typename Blk<MODEL, true>::Args a, Prof* pf) {
     Blk<MODEL, true> B(a, gusto_dyn_lds);
     SweepView<MODEL> K = SweepView<MODEL>::make(B);
-    const int s = seg_split(K.N);
-    double* fail = gusto_dyn_lds + LdsC<MODEL, true>::misc + 8;
-#pragma nounroll
-    for (int c = 0; c < 2; c++) factor_sweep_mfma<MODEL, false, true>(K, fail, *pf, c ? s - 1 : K.N - 1, c ? 0 : s, c != 0);   // chain B, then chain A
+    factor_sweep_mfma<MODEL, false, true>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf, K.N - 1, seg_split(K.N), false);
 }
 template <int MODEL> __device__ __noinline__ void coarse_factor_seg_call(typename Blk<MODEL, true>::Args a) {
     Blk<MODEL, true> B(a, gusto_dyn_lds);
@@ -934,14 +983,12 @@ template <int MODEL> __device__ __noinline__ void backward_sweep_seg_call(typena
     constexpr int n = MT<MODEL>::n;
     const int N = B.N, s = seg_split(N);
     backward_sweep_ring_rng<MODEL>(B, N - 1, s, C::vecs + 4 * N * n + (N - 1) * n, B.P.ll.seg + SegB<MODEL>::PBV);
-    backward_sweep_ring_rng<MODEL>(B, s - 1, 1, C::vecs + 5 * N * n + s * n, -1);
 }
 template <int MODEL> __device__ __noinline__ void forward_sweep_seg_call(typename Blk<MODEL, true>::Args a) {
     Blk<MODEL, true> B(a, gusto_dyn_lds);
     constexpr int n = MT<MODEL>::n;
     const int N = B.N, s = seg_split(N), xi = B.P.ll.seg + SegB<MODEL>::XI;
-    forward_sweep_ring_rng<MODEL>(B, 0, s - 2, -1);
-    if (B.tid < n) B.dY[(s - 1) * n + B.tid] = B.lds[xi + B.tid];
+    if (B.tid < n) B.dY[(s - 1) * n + B.tid] = B.lds[xi + B.tid];     // (chain A's end state is xi by construction: its sweep stops at s - 2)
     forward_sweep_ring_rng<MODEL>(B, s, N - 1, xi);
 }
 template <int MODEL> __device__ __noinline__ void costate_pass_seg_call(typename Blk<MODEL, true>::Args a) {
