@@ -359,7 +359,11 @@ template <int MODEL, bool ONE> struct LdsC {
 #define GUSTO_SEG2 0
 #endif
 #ifndef GUSTO_SEG_W2
+#ifdef GUSTO_STRICT_SYNC   // (the check build's ordering points are workgroup barriers: one wave per workgroup only)
+#define GUSTO_SEG_W2 0
+#else
 #define GUSTO_SEG_W2 1
+#endif
 #endif
 #define GUSTO_SEG_ANY (GUSTO_SEG2 || GUSTO_SEG_W2)
 template <int MODEL> constexpr bool seg2_big() { return GUSTO_SEG_W2 && MT<MODEL>::MFMA && MT<MODEL>::SWEEP_CALL && MT<MODEL>::NDEF == 0; }

@@ -1885,21 +1885,35 @@ template <int MODEL, class BLK, bool SEG = false> GD void mid_phase(BLK& K, int 
         const LPtr<double> L = K.lds;
         const int sb = K.P.ll.seg;
         seg_s = K.N >> 1;
+        // (the rows of the coarse stage's matrices are requested a level ahead of their use -- under the reduction, under the
+        // products of the level before -- instead of one dependent LDS round trip per term)
+        const int ri = K.tid < n ? K.tid : 0;
+        double ph[n], rT[n], rS[n], rP[n], cT[n];
+#pragma unroll
+        for (int l = 0; l < n; l++) {
+            ph[l] = L[sb + SB::PBV + l] - K.nu[seg_s * n + l];   // p_B - lam0
+            rT[l] = L[sb + SB::Tt + ri * n + l]; rS[l] = L[sb + SB::Sg + ri * n + l];
+            rP[l] = L[sb + SB::Pa + ri * n + l]; cT[l] = L[sb + SB::Tt + l * n + ri];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         double r2[2 * n];
 #pragma unroll
         for (int j = 0; j < n; j++) { r2[j] = (k < seg_s) ? th[j] : 0.0; r2[n + j] = (k < seg_s) ? 0.0 : th[j]; }
         wave_reduce_n<2 * n>(r2, OpSum());
         MT_(PF_M_RED);
-        const int ri = K.tid < n ? K.tid : 0;
-        double ph[n];
+        double rG[n], rA1[n], rA2[n], rA3[n];
 #pragma unroll
-        for (int l = 0; l < n; l++) ph[l] = L[sb + SB::PBV + l] - K.nu[seg_s * n + l];   // p_B - lam0
+        for (int l = 0; l < n; l++) {
+            rG[l] = L[sb + SB::Gci + ri * n + l]; rA1[l] = L[sb + SB::A1 + ri * n + l];
+            rA2[l] = L[sb + SB::A2 + ri * n + l]; rA3[l] = L[sb + SB::A3 + ri * n + l];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         double v1 = 0, v2 = 0, v3 = 0;
 #pragma unroll
         for (int l = 0; l < n; l++) {
-            v1 += L[sb + SB::Tt + ri * n + l] * r2[l];
-            v2 += L[sb + SB::Sg + ri * n + l] * ph[l];
-            v3 += L[sb + SB::Pa + ri * n + l] * r2[l] + L[sb + SB::Tt + l * n + ri] * ph[l];
+            v1 += rT[l] * r2[l];
+            v2 += rS[l] * ph[l];
+            v3 += rP[l] * r2[l] + cT[l] * ph[l];
         }
         const double w1 = v1 - v2;
         double w1v[n], muv[n];
@@ -1907,13 +1921,13 @@ template <int MODEL, class BLK, bool SEG = false> GD void mid_phase(BLK& K, int 
         for (int l = 0; l < n; l++) w1v[l] = readlane_f64(w1, l);
         double mu = 0;
 #pragma unroll
-        for (int l = 0; l < n; l++) mu += L[sb + SB::Gci + ri * n + l] * r2[n + l] + L[sb + SB::A1 + ri * n + l] * w1v[l];
+        for (int l = 0; l < n; l++) mu += rG[l] * r2[n + l] + rA1[l] * w1v[l];
         mu = K.is_goal(ri) ? mu : 0.0;
 #pragma unroll
         for (int l = 0; l < n; l++) muv[l] = readlane_f64(mu, l);
         double xi = w1, dl = v3;
 #pragma unroll
-        for (int l = 0; l < n; l++) { xi -= L[sb + SB::A2 + ri * n + l] * muv[l]; dl += L[sb + SB::A3 + ri * n + l] * muv[l]; }
+        for (int l = 0; l < n; l++) { xi -= rA2[l] * muv[l]; dl += rA3[l] * muv[l]; }
         if (K.tid < n) { mugn[K.tid] = mu; L[sb + SB::XI + K.tid] = xi; L[sb + SB::LAM + K.tid] = dl; }
     } else
     if constexpr (BLK::ONE) {
@@ -1951,13 +1965,19 @@ template <int MODEL, class BLK, bool SEG = false> GD void mid_phase(BLK& K, int 
     MT_(PF_M_MU);
     if (act) {  // d_k = d0 + D_k mu_g ; ct_k = c_k - Gam_k d_k
         double dk[m];
+        double ml[SEG ? n : 1];   // (segmented solve: the multiplier of this knot's chain, taken once)
+        if constexpr (SEG) {
+#pragma unroll
+            for (int j = 0; j < n; j++) { const double a_ = K.lds[K.P.ll.seg + SegB<MODEL>::LAM + j], b_ = mugn[j]; ml[j] = (k < seg_s) ? a_ : b_; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < m; i++) {
             double s = d0[i];
 #pragma unroll
             for (int j = 0; j < n; j++) {
-                double mlt = mugn[j];
-                if constexpr (SEG) mlt = (k < seg_s) ? K.lds[K.P.ll.seg + SegB<MODEL>::LAM + j] : mlt;
+                double mlt;
+                if constexpr (SEG) mlt = ml[j]; else mlt = mugn[j];
                 s += (KEEP_D ? Dk[i * n + j] : K.kd(k, R::oD + i * n + j)) * mlt;
             }
             dk[i] = s;
@@ -2006,7 +2026,29 @@ template <int MODEL, class BLK, bool SEG = false> __device__ __noinline__ void m
 // The phase after the forward sweep of a right-hand side: primal step of this knot, the new costates, row steps and
 // the fraction to the boundary (before the workgroup reductions).  A function of its own for MT::SWEEP_CALL models.
 struct StepOut { double amax, c0, c1, c2; };
-template <int MODEL, class BLK>
+// x_1 stationarity, gx_0 + nu_0 + F_0^T nu_1 = 0: the costate of the first knot from the one behind it (ONE lane's work: lane 0 of
+// the step phase, or of the helper wave's costate pass)
+template <int MODEL, class BLK> GD void costate_close_x1(BLK& K, double hdt, const double* gxs) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n, m = T::m;
+    double Ad[n * n], x0[n], u0[m];
+#pragma unroll
+    for (int i = 0; i < n; i++) x0[i] = K.Xp[i];
+#pragma unroll
+    for (int i = 0; i < m; i++) u0[i] = K.Up[i];
+    if constexpr (BLK::C::LC_LDS) {
+        const double c2[2] = {K.lcl[0], K.lcl[1]};
+        Dyn<MODEL>::A_cached(c2, Ad);
+    } else Dyn<MODEL>::A(K.P.mp, x0, u0, Ad);
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        double s = gxs[i] + K.nun[n + i];
+#pragma unroll
+        for (int j = 0; j < n; j++) if (T::Anz(j, i)) s += hdt * Ad[j * n + i] * K.nun[n + j];
+        K.nun[i] = -s;
+    }
+}
+template <int MODEL, class BLK, bool CLOSE = true>
 GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int k, bool act, int pass, int ncomp, double hdt,
                       double tau, double mu_t, const double* mugn, const double* gxs) {
     using T = MT<MODEL>;
@@ -2124,25 +2166,10 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         }
     }
     K.sync();
-    // (adjoint costates: nu_1 is known after the sweep; adjoint_sweep_1w_call closes with this block)
-    if (!(ADJ && adj_rt) && k == 0 && (pass == 1 || ncomp == 0)) {  // x_1 stationarity: gx_0 + nu_0 + F_0^T nu_1 = 0
-        double Ad[n * n], x0[n], u0[m];
-#pragma unroll
-        for (int i = 0; i < n; i++) x0[i] = K.Xp[i];
-#pragma unroll
-        for (int i = 0; i < m; i++) u0[i] = K.Up[i];
-        if constexpr (BLK::C::LC_LDS) {
-            const double c2[2] = {K.lcl[0], K.lcl[1]};
-            Dyn<MODEL>::A_cached(c2, Ad);
-        } else Dyn<MODEL>::A(K.P.mp, x0, u0, Ad);
-#pragma unroll
-        for (int i = 0; i < n; i++) {
-            double s = gxs[i] + K.nun[n + i];
-#pragma unroll
-            for (int j = 0; j < n; j++) if (T::Anz(j, i)) s += hdt * Ad[j * n + i] * K.nun[n + j];
-            K.nun[i] = -s;
-        }
-    }
+    // (adjoint costates: nu_1 is known after the sweep; adjoint_sweep_1w_call closes with this block.  Two waves per problem, CLOSE =
+    // false: the helper wave's costate pass runs beside this phase and closes itself -- seg.hpp: segw_helper)
+    if constexpr (CLOSE)
+    if (!(ADJ && adj_rt) && k == 0 && (pass == 1 || ncomp == 0)) costate_close_x1<MODEL>(K, hdt, gxs);
     return StepOut{l_amax, l_c0, l_c1, l_c2};
 }
 // the row context of knot k, as ipm_solve builds it (the called phases rebuild theirs from three numbers)
@@ -2155,7 +2182,7 @@ GD void make_row_ctx(const BLK& K, int k, bool act, double kappa, double omega, 
     rs = RowState{K.rowstate, K.P.wl.nslot, K.N, act ? k : 0};
 }
 struct RowScal { double kappa, omega, Delta; };
-template <int MODEL, class BLK>
+template <int MODEL, class BLK, bool CLOSE = true>
 __device__ __noinline__ StepOut step_phase_call(typename BLK::Args a, RowScal sc, int k, bool act, int pass, int ncomp,
                                                 double hdt, double tau, double mu_t, Prof* pf) {
     BLK K(a, gusto_dyn_lds);
@@ -2166,8 +2193,8 @@ __device__ __noinline__ StepOut step_phase_call(typename BLK::Args a, RowScal sc
 #ifdef GUSTO_PROFILE
     ctx.pf = pf; ctx.pfb = PF_S0;
 #endif
-    return step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, gusto_dyn_lds + C::misc + 48,
-                             gusto_dyn_lds + C::misc + 16);
+    return step_phase<MODEL, BLK, CLOSE>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, gusto_dyn_lds + C::misc + 48,
+                                         gusto_dyn_lds + C::misc + 16);
 }
 
 // The residual phase of an interior point iteration: residuals, condensed Hessian blocks, dual residual, the predictor's
@@ -2424,8 +2451,9 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
     constexpr bool SEGB = seg2_big<MODEL>() && BLK::ONE && W2;   // ... of the matrix-core kernels (scp_kernel_w2: a wave per chain)
     constexpr bool SEG = (seg2_model<MODEL>() && BLK::ONE) || SEGB;
 #if GUSTO_SEG_ANY
-    const bool seg = SEG && N >= GUSTO_SEG_MIN_N;
+    const bool seg = SEG && (SEGB || N >= GUSTO_SEG_MIN_N);   // (launch_scp starts the two-wave kernel for N >= GUSTO_SEG_MIN_N only)
     const int seg_s = seg_split(N);
+    if constexpr (SEGB) segw_open<MODEL>(K);
 #endif
 
     RowCtx<MODEL> ctx;
@@ -2555,16 +2583,17 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
         // (4) factorise
         bool seg_done = false;
 #if GUSTO_SEG_ANY
+        [[maybe_unused]] bool seg_fail = false;
         if constexpr (SEGB) {
-            if (seg) {   // chain A on the helper wave, chain B here; then the coarse stage
-                segw_post<MODEL>(K, SEGW_FACTOR);
-                factor_sweep_seg_call<MODEL>(K.args(), &pf);
-                segw_join();
-                pf.tick(PF_FACTOR);
-                GUSTO_REFRESH_K();
-                coarse_factor_seg_call<MODEL>(K.args());
-                seg_done = true;
-            }
+            // chain A on the helper wave, chain B here; after the join the helper goes on with the coarse stage while this wave
+            // builds the predictor's right-hand side -- the second join waits in front of the first backward sweep
+            segw_post<MODEL>(K, SEGW_FACTOR);
+            factor_sweep_seg_call<MODEL>(K.args(), &pf);
+            segw_join();
+            pf.tick(PF_FACTOR);
+            GUSTO_REFRESH_K();
+            seg_done = true;
+            if (*fail != 0.0) { segw_join(); break; }   // (the barriers of the two waves stay paired)
         } else if constexpr (SEG) {
             if (seg) {
                 factor_sweep_pg2s<MODEL>(SweepView<MODEL>::make(K), fail, pf, seg_s);
@@ -2600,8 +2629,10 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
         }
         if constexpr (n > 8) inv_spd_block<MODEL>(K, fail);   // (the whole workgroup: one lane took 170 k cycles for n = 12)
         }
+        if constexpr (!SEGB) {
         K.sync();
         if (*fail != 0.0) break;
+        }
         pf.tick(PF_POSTF);
 
         // (5) predictor (mu_t = 0) and centred corrector share the factorisation
@@ -2668,7 +2699,13 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
             K.sync();
             pf.tick(PF_RHS);
 #if GUSTO_SEG_ANY
-            if constexpr (SEGB) { if (seg) { segw_post<MODEL>(K, SEGW_BACK); backward_sweep_seg_call<MODEL>(K.args()); segw_join(); } else backward_sweep<MODEL>(K); }
+            if constexpr (SEGB) {
+                if (pass == 0) {   // the coarse stage of this factorisation is done
+                    segw_join();
+                    if (*fail != 0.0) { seg_fail = true; break; }
+                }
+                segw_post<MODEL>(K, SEGW_BACK); backward_sweep_seg_call<MODEL>(K.args()); segw_join();
+            }
             else if constexpr (SEG) { if (seg) backward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else backward_sweep<MODEL>(K); }
             else
 #endif
@@ -2676,7 +2713,7 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
             pf.tick(PF_BACK);
             GUSTO_REFRESH_K();
 #if GUSTO_SEG_ANY
-            if constexpr (SEGB) { if (seg) mid_phase_call<MODEL, BLK, true>(K.args(), k, act, hdt, &pf); else mid_phase_call<MODEL, BLK>(K.args(), k, act, hdt, &pf); }
+            if constexpr (SEGB) mid_phase_call<MODEL, BLK, true>(K.args(), k, act, hdt, &pf);
             else
 #endif
             if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL, BLK>(K.args(), k, act, hdt, &pf);
@@ -2686,20 +2723,14 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
             else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf);
             pf.tick(PF_MID);
 #if GUSTO_SEG_ANY
-            if constexpr (SEGB) { if (seg) { segw_post<MODEL>(K, SEGW_FWD); forward_sweep_seg_call<MODEL>(K.args()); segw_join(); } else forward_sweep<MODEL>(K); }
+            if constexpr (SEGB) { segw_post<MODEL>(K, SEGW_FWD); forward_sweep_seg_call<MODEL>(K.args()); segw_join(); }
             else if constexpr (SEG) { if (seg) forward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else forward_sweep<MODEL>(K); }
             else
 #endif
             forward_sweep<MODEL>(K);
-            if constexpr (BLK::ONE && T::SWEEP_CALL)
+            if constexpr (BLK::ONE && T::SWEEP_CALL && !SEGB)
                 if (!adj_now)
-                if (pass == 1 || ncomp == 0) {
-#if GUSTO_SEG_ANY
-                    if constexpr (SEGB) { if (seg) costate_pass_seg_call<MODEL>(K.args()); else costate_pass_1w_call<MODEL>(K.args()); }
-                    else
-#endif
-                    costate_pass_1w_call<MODEL>(K.args());
-                }
+                if (pass == 1 || ncomp == 0) costate_pass_1w_call<MODEL>(K.args());
             pf.tick(PF_FWD);
             GUSTO_REFRESH_K();
             // primal step of this knot, the new costates, row steps + fraction to the boundary
@@ -2708,6 +2739,12 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
 #ifdef GUSTO_PROFILE
             ctx.pf = &pf; ctx.pfb = PF_S0;
 #endif
+            if constexpr (SEGB) {   // the new costates (P | Pi records) on the helper wave, beside the step phase
+                const bool cs = pass == 1 || ncomp == 0;
+                if (cs) segw_post<MODEL>(K, SEGW_COSTATE);
+                so = step_phase_call<MODEL, BLK, false>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
+                if (cs) segw_join();
+            } else
             if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL, BLK>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
             else {
                 // (segmented solve: the costates of chain A's knots hang on dlam, those of chain B's on mu_g)
@@ -2735,6 +2772,9 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
                 if (ncomp == 0) break;  // equality-constrained QP: the predictor already is the Newton step
             }
         }
+#if GUSTO_SEG_ANY
+        if (seg_fail) break;
+#endif
         pf.tick(PF_STEP);
         // (6) update
         GUSTO_REFRESH_K();

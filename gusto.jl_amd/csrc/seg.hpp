@@ -919,17 +919,21 @@ template <int MODEL> GD void costate_pass_seg(SweepView<MODEL> K, int s) {
 // the three sequential phases, chain B; the HELPER wave (lanes 64..127) waits at a barrier for a command and runs chain A beside
 // it.  Two workgroup barriers per phase: post (the main wave has written the command and everything the helper reads: drain, barrier)
 // and join (both have drained their stores).  The phases themselves stay barrier-free one-wave code on disjoint knots and LDS.
-constexpr int SEGW_FACTOR = 1, SEGW_BACK = 2, SEGW_FWD = 3, SEGW_EXIT = 9;
+constexpr int SEGW_FACTOR = 1, SEGW_BACK = 2, SEGW_FWD = 3, SEGW_COSTATE = 4, SEGW_EXIT = 9;
 GD void segw_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 GD void segw_join() { segw_barrier(); }
-template <int MODEL, class BLK> GD void segw_post(BLK& K, int cmd) {
+// mailbox: [0] the command, [2..6] what the helper needs to rebuild the problem's view (written once per interior point solve)
+template <int MODEL, class BLK> GD void segw_open(BLK& K) {
     const LPtr<double> L = K.lds;
     const int mb = K.P.ll.seg + SegB<MODEL>::MBX;
     if (K.tid == 0) {
         const typename BLK::Args a = K.args();
-        L[mb] = (double)cmd;
         L[mb + 2] = (double)a.b; L[mb + 3] = (double)a.slot; L[mb + 4] = (double)a.goalmask; L[mb + 5] = (double)a.boxmask; L[mb + 6] = a.dt;
     }
+}
+template <int MODEL, class BLK> GD void segw_post(BLK& K, int cmd) {
+    const LPtr<double> L = K.lds;
+    if (K.tid == 0) L[K.P.ll.seg + SegB<MODEL>::MBX] = (double)cmd;
     segw_barrier();
 }
 // kernel exit of the main wave: release the helper for good (no join: a wave that has ended is not waited for)
@@ -937,6 +941,13 @@ GD void segw_exit(double* lds, int seg_off, int mbx) {
     if ((threadIdx.x & 63) == 0) lds[seg_off + mbx] = (double)SEGW_EXIT;
     segw_barrier();
 }
+// The helper wave.  What it runs, each beside the main wave's work named in brackets:
+//   FACTOR   chain A's factor sweep [chain B's]; join; the coarse stage [the predictor's right-hand side]; join
+//   BACK     chain A's backward vector sweep [chain B's]; join
+//   FWD      chain A's forward sweep [chain B's]; join
+//   COSTATE  the new costates of every knot from the P | Pi records and the first knot's closing equation [the step phase]; join
+// The view of the problem (some 45 base pointers, scalar loads from the kernel arguments) is rebuilt when the problem changes, not
+// per command: it sat on the critical path of every phase.
 template <int MODEL> GD void segw_helper(const KParams& P, double* lds) {
     using SB = SegB<MODEL>;
     using BLK = Blk<MODEL, true>;
@@ -945,25 +956,35 @@ template <int MODEL> GD void segw_helper(const KParams& P, double* lds) {
     const LPtr<double> L = lds;
     const int sb = P.ll.seg, mb = sb + SB::MBX;
     Prof pfd;
-    for (;;) {
-        asm volatile("s_barrier" ::: "memory");
-        const int cmd = (int)L[mb];
-        if (cmd == SEGW_EXIT) return;
+    asm volatile("s_barrier" ::: "memory");
+    int cmd = (int)L[mb];
+    while (cmd != SEGW_EXIT) {
         typename BLK::Args a;
         a.Pk = (const KParams*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // (inlined into the kernel; KParams is its first argument)
-        a.b = (int)L[mb + 2]; a.slot = (int)L[mb + 3]; a.goalmask = (unsigned)L[mb + 4]; a.boxmask = (unsigned)L[mb + 5]; a.dt = L[mb + 6];
+        const double pb = L[mb + 2];
+        a.b = (int)pb; a.slot = (int)L[mb + 3]; a.goalmask = (unsigned)L[mb + 4]; a.boxmask = (unsigned)L[mb + 5]; a.dt = L[mb + 6];
         BLK B(a, lds);
         const int N = B.N, s = seg_split(N);
-        if (cmd == SEGW_FACTOR) {
-            SweepView<MODEL> K = SweepView<MODEL>::make(B);
-            K.sPG = lds + sb + SB::sPG2; K.sHh = lds + sb + SB::Lw2;      // its own operand buffers: the main wave's sweep runs beside it
-            factor_sweep_mfma<MODEL, false, true>(K, lds + C::misc + 8, pfd, s - 1, 0, true);
-        } else if (cmd == SEGW_BACK) {
-            backward_sweep_ring_rng<MODEL>(B, s - 1, 1, C::vecs + 5 * N * n + s * n, -1);      // from pt_{s-1} = lam0 = nu_s
-        } else if (cmd == SEGW_FWD) {
-            forward_sweep_ring_rng<MODEL>(B, 0, s - 2, -1);
-        }
-        segw_barrier();
+        double* fail = lds + C::misc + 8;
+        do {
+            if (cmd == SEGW_FACTOR) {
+                SweepView<MODEL> K = SweepView<MODEL>::make(B);
+                K.sPG = lds + sb + SB::sPG2; K.sHh = lds + sb + SB::Lw2;      // its own operand buffers: the main wave's sweep runs beside it
+                factor_sweep_mfma<MODEL, false, true>(K, fail, pfd, s - 1, 0, true);
+                segw_barrier();
+                seg_coarse_factor_big<MODEL>(B, fail);
+            } else if (cmd == SEGW_BACK) {
+                backward_sweep_ring_rng<MODEL>(B, s - 1, 1, C::vecs + 5 * N * n + s * n, -1);      // from pt_{s-1} = lam0 = nu_s
+            } else if (cmd == SEGW_FWD) {
+                forward_sweep_ring_rng<MODEL>(B, 0, s - 2, -1);
+            } else if (cmd == SEGW_COSTATE) {
+                costate_pass_seg<MODEL>(SweepView<MODEL>::make(B), s);
+                if (B.tid == 0) costate_close_x1<MODEL>(B, 0.5 * B.dt, lds + C::misc + 16);
+            }
+            segw_barrier();
+            asm volatile("s_barrier" ::: "memory");
+            cmd = (int)L[mb];
+        } while (cmd != SEGW_EXIT && L[mb + 2] == pb);
     }
 }
 
@@ -972,10 +993,6 @@ template <int MODEL> __device__ __noinline__ void factor_sweep_seg_call(typename
     Blk<MODEL, true> B(a, gusto_dyn_lds);
     SweepView<MODEL> K = SweepView<MODEL>::make(B);
     factor_sweep_mfma<MODEL, false, true>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf, K.N - 1, seg_split(K.N), false);
-}
-template <int MODEL> __device__ __noinline__ void coarse_factor_seg_call(typename Blk<MODEL, true>::Args a) {
-    Blk<MODEL, true> B(a, gusto_dyn_lds);
-    seg_coarse_factor_big<MODEL>(B, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8);
 }
 template <int MODEL> __device__ __noinline__ void backward_sweep_seg_call(typename Blk<MODEL, true>::Args a) {
     Blk<MODEL, true> B(a, gusto_dyn_lds);
@@ -990,10 +1007,6 @@ template <int MODEL> __device__ __noinline__ void forward_sweep_seg_call(typenam
     const int N = B.N, s = seg_split(N), xi = B.P.ll.seg + SegB<MODEL>::XI;
     if (B.tid < n) B.dY[(s - 1) * n + B.tid] = B.lds[xi + B.tid];     // (chain A's end state is xi by construction: its sweep stops at s - 2)
     forward_sweep_ring_rng<MODEL>(B, s, N - 1, xi);
-}
-template <int MODEL> __device__ __noinline__ void costate_pass_seg_call(typename Blk<MODEL, true>::Args a) {
-    Blk<MODEL, true> B(a, gusto_dyn_lds);
-    costate_pass_seg<MODEL>(SweepView<MODEL>::make(B), seg_split(B.N));
 }
 
 }  // namespace gusto
