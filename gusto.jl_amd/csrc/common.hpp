@@ -366,16 +366,46 @@ template <int MODEL, bool ONE> struct LdsC {
 #endif
 #endif
 #define GUSTO_SEG_ANY (GUSTO_SEG2 || GUSTO_SEG_W2)
+#ifndef GUSTO_SEG_MIN_N
+#define GUSTO_SEG_MIN_N 4       // stages per chain at least (a chain of two or three stages is barely controllable)
+#endif
+__host__ __device__ constexpr int seg_split(int N) { return N >> 1; }   // two chains: A = stages 0 .. s-1, B = s .. N-1 (one stage longer for odd N)
 template <int MODEL> constexpr bool seg2_big() { return GUSTO_SEG_W2 && MT<MODEL>::MFMA && MT<MODEL>::SWEEP_CALL && MT<MODEL>::NDEF == 0; }
-// LDS block of the segmented solve of these kernels, behind everything else (offsets relative to LdsLayout::seg)
-template <int MODEL> struct SegB {
-    static constexpr int n = MT<MODEL>::n, m = MT<MODEL>::m, NNp = (n * n + 1) & ~1, NPG = n * (n + m);
-    // the coarse stage's matrices (seg.hpp: seg_coarse_factor_big), its inputs as the factor sweeps leave them, three n-vectors,
-    // the helper wave's own [Phi Gam] double buffer and L^-1 scratch (its factor sweep runs beside the main wave's), the mailbox
-    static constexpr int Tt = 0, Sg = NNp, Pa = 2 * NNp, Gci = 3 * NNp, A1 = 4 * NNp, A2 = 5 * NNp, A3 = 6 * NNp, X1 = 7 * NNp, X2 = 8 * NNp,
-                         PB = 9 * NNp, PIB = 10 * NNp, GDA = 11 * NNp, vec = 12 * NNp, XI = vec, PBV = vec + 16, LAM = vec + 32,
-                         sPG2 = vec + 48, Lw2 = sPG2 + 2 * NPG, MBX = Lw2 + 64, total = MBX + 8;
+// LDS block of the segmented solve of these kernels, behind everything else (offsets relative to LdsLayout::seg).  NCH chains
+// (= waves per problem, 2 or 4): chain c covers the stages seg_lo(c) .. seg_lo(c + 1) - 1, interface j sits between chain j and
+// what lies behind it -- the chains j + 1 .. NCH - 1 FOLDED into one (seg.hpp: seg_fold_factor).
+__host__ __device__ constexpr int seg_lo(int c, int N, int NCH) { return (int)((long)N * c / NCH); }
+template <int MODEL, int NCH> struct SegB {
+    static constexpr int n = MT<MODEL>::n, m = MT<MODEL>::m, NNp = (n * n + 1) & ~1, NPG = n * (n + m), NI = NCH - 1;
+    // per interface: Ta', Sig, Pa = Ta Pc, A2 = Sig Pic, A3 = Ta Pic and the folded rear part's (Pc, Pic) -- the last chain's own sweep
+    // leaves its P, Pi in the last interface's pair, a fold writes the pair of the interface in front
+    static constexpr int IFB = 7 * NNp, Tt = 0, Sg = NNp, Pa = 2 * NNp, A2 = 3 * NNp, A3 = 4 * NNp, Pc = 5 * NNp, PIc = 6 * NNp;
+    static constexpr int IF(int j) { return j * IFB; }
+    // per chain in front of the last: what its factor sweep leaves (P, Pi in front of its first stage, its Gd)
+    static constexpr int CHB = 3 * NNp, Pf = 0, Pif = NNp, Gdf = 2 * NNp;
+    static constexpr int CH(int c) { return NI * IFB + c * CHB; }
+    static constexpr int COM = NI * (IFB + CHB), Gci = COM, A1 = COM + NNp, X1 = COM + 2 * NNp, X2 = COM + 3 * NNp;
+    // n-vectors (16-double slots): interface state and costate increment per interface, the front costate offset of the chains c >= 1
+    static constexpr int vec = COM + 4 * NNp;
+    static constexpr int XI(int j) { return vec + 16 * j; }
+    static constexpr int LAM(int j) { return vec + 16 * NI + 16 * j; }
+    static constexpr int PBV(int c) { return vec + 32 * NI + 16 * (c - 1); }
+    // a helper wave's own [Phi Gam] double buffer and L^-1 scratch (its factor sweep runs beside the others'), the mailbox
+    static constexpr int hlp = vec + 48 * NI, HLB = 2 * NPG + 64;
+    static constexpr int sPG2(int h) { return hlp + h * HLB; }
+    static constexpr int Lw2(int h) { return hlp + h * HLB + 2 * NPG; }
+    static constexpr int MBX = hlp + NI * HLB, total = MBX + 8;
 };
+// where a knot's costate (and its control's feed-forward) takes its multiplier from: the costate increment of the interface behind its
+// chain, mu_g for the last chain (offset from the base of the dynamic LDS)
+template <int MODEL, int NCH> GD int seg_mult_off(int k, int N, int seg_base) {
+    using SB = SegB<MODEL, NCH>;
+    int c = 0;
+#pragma unroll
+    for (int j = 1; j < NCH; j++) c += (k >= seg_lo(j, N, NCH)) ? 1 : 0;
+    return (c < NCH - 1) ? seg_base + SB::LAM(0) + 16 * c : LdsC<MODEL, true>::misc + 48;
+}
+
 struct LdsLayout {
     int total;
     int phicl;  // offset of the LDS copy of Phicl (doubles), -1 if in the global workspace or rebuilt from K
@@ -384,7 +414,7 @@ struct LdsLayout {
     int lc;     // offset of the linearisation cache (LdsC::LC_LDS: 2 doubles per knot), -1 if none
     int seg;    // offset of the segmented solve's block (SegB), -1 if none
 };
-template <int MODEL> inline LdsLayout make_lds_layout(int N, bool multi_wave = false, bool seg_w2 = false) {
+template <int MODEL> inline LdsLayout make_lds_layout(int N, bool multi_wave = false, int seg_nch = 0) {
     using C1 = LdsC<MODEL, true>;
     using CM = LdsC<MODEL, false>;
     LdsLayout L;
@@ -399,7 +429,7 @@ template <int MODEL> inline LdsLayout make_lds_layout(int N, bool multi_wave = f
     L.lc = -1;
     if (C1::LC_LDS && one) { L.lc = L.total; L.total += 2 * N; }
     L.seg = -1;
-    if (seg2_big<MODEL>() && one && seg_w2) { L.seg = L.total; L.total += SegB<MODEL>::total; }
+    if (seg2_big<MODEL>() && one && seg_nch > 0) { L.seg = L.total; L.total += (seg_nch == 4) ? SegB<MODEL, 4>::total : SegB<MODEL, 2>::total; }
     return L;
 }
 

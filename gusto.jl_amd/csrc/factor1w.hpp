@@ -776,12 +776,14 @@ template <int MODEL> GD bool costate_adjoint_rt(const gusto_model_params& mp, do
 // of their record.
 // (NOPP: no P | Pi records -- the costates come from the adjoint recursion; a template parameter, chosen at run time by the
 // caller, so that the stage loop holds no branch around its stores)
-// SEG (round 6, seg.hpp): the sweep over the stages kHi .. kLo of ONE chain of a split horizon.  Chain A (isA: the stages in front of
-// the interface) starts from P = 0, Pi = I -- its end state adjoined as a terminal equality -- and leaves its Gd in the segmented
-// solve's block (SegB::GDA); chain B (kHi = N - 1) is the sweep as it was, but its last stage leaves P_B, Pi_B in that block
-// instead of record kLo - 1, which belongs to chain A.
+// SEG (round 6, seg.hpp): the sweep over the stages kHi .. kLo of ONE chain of a split horizon.  A chain in front of an interface
+// (isA) starts from P = 0, Pi = I -- its end state adjoined as a terminal equality; the last chain (kHi = N - 1) starts as the sweep
+// always did.  Every chain leaves the P, Pi in front of its first stage and its Gd in the segmented solve's LDS block (offsets oP,
+// oPi, oGd from the base of the dynamic LDS; oGd < 0: sGd), and a chain with kLo > 0 does not write record kLo - 1, which belongs to
+// the chain in front of it.
 template <int MODEL, bool NOPP, bool SEG = false>
-GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail, Prof& pf, int kHi_ = 0, int kLo_ = 0, bool isA = false) {
+GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail, Prof& pf, int kHi_ = 0, int kLo_ = 0, bool isA = false, int oP = 0, int oPi = 0,
+                          int oGd = -1) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NPG = n * NZ, NN = n * n;
@@ -1014,7 +1016,7 @@ GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail, Prof& pf, int kHi_ =
         {
             double* phr = K.Phicl + (size_t)k * R::SNN;
             // (record -1 exists for k == 0; chain B's record kLo - 1 belongs to chain A: its last stage aims at the junk record -1)
-            const int krec = (SEG && !isA && k == kLo) ? -1 : k - 1;
+            const int krec = (SEG && kLo > 0 && k == kLo) ? -1 : k - 1;
             double* par = K.Paft + (size_t)krec * R::SNN;
             double* pir = K.Piaft + (size_t)krec * R::SNN;
             double* kdr = K.KD + (size_t)k * R::SKD;
@@ -1040,14 +1042,13 @@ GD void factor_sweep_mfma(SweepView<MODEL> K, double* fail, Prof& pf, int kHi_ =
     }
     // Gd = sum V^T V for the goal system of the mid phase
     if constexpr (SEG) {
-        using SB = SegB<MODEL>;
         const LPtr<double> L = K.lds;
 #pragma unroll
         for (int q = 0; q < KS; q++) {
             const int row = mq + 4 * q;
             if (row < n && mi < n) {
-                if (isA) L[K.seg_off + SB::GDA + row * n + mi] = Gdt[q];
-                else { K.sGd[row * n + mi] = Gdt[q]; L[K.seg_off + SB::PB + row * n + mi] = Pt[q]; L[K.seg_off + SB::PIB + row * n + mi] = Pit[q]; }
+                if (oGd < 0) K.sGd[row * n + mi] = Gdt[q]; else L[oGd + row * n + mi] = Gdt[q];
+                L[oP + row * n + mi] = Pt[q]; L[oPi + row * n + mi] = Pit[q];
             }
         }
         K.sync();

@@ -1747,9 +1747,11 @@ template <int MODEL, class BLK> GD void inv_spd_block(BLK& K, double* fail) {
 // The phase between the two vector sweeps of a right-hand side: feed-forward d0 = S^-1 lu, the goal multiplier
 // mu_g = Gd^-1 theta, then d_k = d0 + D_k mu_g and ct_k = c_k - Gam_k d_k.  A function of its own so that the models
 // with MT::SWEEP_CALL can run it as a real call (own register allocation; everything it touches lives in LDS / HBM).
-// SEG (round 6, seg.hpp: the matrix-core kernels' segmented solve): theta is summed per chain, the coarse stage gives mu_g, the
-// interface state xi and the increment dlam on the interface costate, and a knot of chain A takes dlam where one of chain B takes mu_g.
-template <int MODEL, class BLK, bool SEG = false> GD void mid_phase(BLK& K, int k, bool act, double hdt, double* red, double* mugn, Prof* pf = nullptr) {
+// NCH > 0 (round 6, segw.hpp: the matrix-core kernels' segmented solve): theta is summed per chain, the chains' vectors are folded from
+// the back, the first interface gives mu_g, then every interface its state xi and the increment dlam on its costate, front to back;
+// a knot in front of an interface takes that interface's dlam where one of the last chain takes mu_g.
+template <int MODEL, class BLK, int NCH = 0> GD void mid_phase(BLK& K, int k, bool act, double hdt, double* red, double* mugn, Prof* pf = nullptr) {
+    constexpr bool SEG = NCH > 0;
 #define MT_(i) do { if (pf) pf->tick(i); } while (0)
     MT_(PF_MID);
     using T = MT<MODEL>;
@@ -1877,58 +1879,98 @@ template <int MODEL, class BLK, bool SEG = false> GD void mid_phase(BLK& K, int 
         }
     }
     MT_(PF_M_TH);
-    [[maybe_unused]] int seg_s = 0;
     if constexpr (SEG) {
-        // theta of chain A (= a, the end state it reaches for lam0) and of chain B (with the goal terms); then the coarse stage: lane
-        // i < n forms row i, three levels of matrix-vector products, the vectors travel by v_readlane (seg.hpp: mid_phase_seg)
-        using SB = SegB<MODEL>;
+        // lane i < n forms row i of every matrix-vector product; a vector travels to all lanes by v_readlane.  The rows a level
+        // needs are requested together, ahead of the products (one LDS round trip per level, not one per term).
+        using SB = SegB<MODEL, NCH>;
+        constexpr int NI = NCH - 1;
         const LPtr<double> L = K.lds;
         const int sb = K.P.ll.seg;
-        seg_s = K.N >> 1;
-        // (the rows of the coarse stage's matrices are requested a level ahead of their use -- under the reduction, under the
-        // products of the level before -- instead of one dependent LDS round trip per term)
         const int ri = K.tid < n ? K.tid : 0;
-        double ph[n], rT[n], rS[n], rP[n], cT[n];
+        int ck = 0;
 #pragma unroll
-        for (int l = 0; l < n; l++) {
-            ph[l] = L[sb + SB::PBV + l] - K.nu[seg_s * n + l];   // p_B - lam0
-            rT[l] = L[sb + SB::Tt + ri * n + l]; rS[l] = L[sb + SB::Sg + ri * n + l];
-            rP[l] = L[sb + SB::Pa + ri * n + l]; cT[l] = L[sb + SB::Tt + l * n + ri];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        double r2[2 * n];
+        for (int c = 1; c < NCH; c++) ck += (k >= seg_lo(c, N, NCH)) ? 1 : 0;
+        double r[NCH * n];   // theta per chain (the last chain's with the goal terms)
 #pragma unroll
-        for (int j = 0; j < n; j++) { r2[j] = (k < seg_s) ? th[j] : 0.0; r2[n + j] = (k < seg_s) ? 0.0 : th[j]; }
-        wave_reduce_n<2 * n>(r2, OpSum());
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int j = 0; j < n; j++) r[c * n + j] = (ck == c) ? th[j] : 0.0;
+        wave_reduce_n<NCH * n>(r, OpSum());
         MT_(PF_M_RED);
-        double rG[n], rA1[n], rA2[n], rA3[n];
+        auto row = [&](int o, double* v) {
 #pragma unroll
-        for (int l = 0; l < n; l++) {
-            rG[l] = L[sb + SB::Gci + ri * n + l]; rA1[l] = L[sb + SB::A1 + ri * n + l];
-            rA2[l] = L[sb + SB::A2 + ri * n + l]; rA3[l] = L[sb + SB::A3 + ri * n + l];
+            for (int l = 0; l < n; l++) v[l] = L[o + ri * n + l];
+        };
+        auto col = [&](int o, double* v) {
+#pragma unroll
+            for (int l = 0; l < n; l++) v[l] = L[o + l * n + ri];
+        };
+        auto bcast = [&](double x, double* v) {
+#pragma unroll
+            for (int l = 0; l < n; l++) v[l] = readlane_f64(x, l);
+        };
+        auto dot = [&](const double* a, const double* x) {
+            double s = 0;
+#pragma unroll
+            for (int l = 0; l < n; l++) s += a[l] * x[l];
+            return s;
+        };
+        // p_hat of interface j = the costate offset in front of what lies behind it, seen from the costate iterate lam0 there
+        double pcU[n], thcU[n], uD[NI > 1 ? NI : 1], wD[NI > 1 ? NI : 1];
+#pragma unroll
+        for (int l = 0; l < n; l++) { pcU[l] = L[sb + SB::PBV(NI) + l]; thcU[l] = r[NI * n + l]; }
+        static_for<1, NI>([&](auto JJ) {   // fold the vectors from the back: interfaces NI - 1 .. 1
+            constexpr int j = NI - decltype(JJ)::value;
+            const int I = sb + SB::IF(j), lam0 = seg_lo(j + 1, N, NCH) * n;
+            double ph[n], rT[n], rS[n], rP[n], cT[n], cPi[n], rPj[n];
+            row(I + SB::Tt, rT); row(I + SB::Sg, rS); row(I + SB::Pa, rP); col(I + SB::Tt, cT);
+            col(I + SB::PIc, cPi); row(sb + SB::CH(j) + SB::Pif, rPj);
+#pragma unroll
+            for (int l = 0; l < n; l++) ph[l] = pcU[l] - K.nu[lam0 + l];
+            const double pfj = L[sb + SB::PBV(j) + ri];
+            __builtin_amdgcn_sched_barrier(0);
+            const double u = dot(rT, r + j * n) - dot(rS, ph), w = dot(rP, r + j * n) + dot(cT, ph);
+            uD[j] = u; wD[j] = w;
+            double uU[n], wU[n];
+            bcast(u, uU); bcast(w, wU);
+            double te = 0;   // (thcU is the same in every lane: this lane's entry of it)
+#pragma unroll
+            for (int l = 0; l < n; l++) te = (ri == l) ? thcU[l] : te;
+            const double thn = te + dot(cPi, uU), pcn = pfj + dot(rPj, wU);
+            bcast(thn, thcU); bcast(pcn, pcU);
+        });
+        double xiv, dlv, mu;
+        double muU[n];
+        {   // the first interface: mu_g, then its state and costate increment
+            const int I = sb + SB::IF(0), lam0 = seg_lo(1, N, NCH) * n;
+            double ph[n], rT[n], rS[n], rP[n], cT[n], rG[n], rA1[n], rA2[n], rA3[n];
+            row(I + SB::Tt, rT); row(I + SB::Sg, rS); row(I + SB::Pa, rP); col(I + SB::Tt, cT);
+            row(sb + SB::Gci, rG); row(sb + SB::A1, rA1); row(I + SB::A2, rA2); row(I + SB::A3, rA3);
+#pragma unroll
+            for (int l = 0; l < n; l++) ph[l] = pcU[l] - K.nu[lam0 + l];
+            __builtin_amdgcn_sched_barrier(0);
+            const double w1 = dot(rT, r) - dot(rS, ph), v3 = dot(rP, r) + dot(cT, ph);
+            double w1U[n];
+            bcast(w1, w1U);
+            mu = dot(rG, thcU) + dot(rA1, w1U);
+            mu = K.is_goal(ri) ? mu : 0.0;
+            bcast(mu, muU);
+            xiv = w1 - dot(rA2, muU); dlv = v3 + dot(rA3, muU);
+            if (K.tid < n) { mugn[K.tid] = mu; L[sb + SB::XI(0) + K.tid] = xiv; L[sb + SB::LAM(0) + K.tid] = dlv; }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        double v1 = 0, v2 = 0, v3 = 0;
-#pragma unroll
-        for (int l = 0; l < n; l++) {
-            v1 += rT[l] * r2[l];
-            v2 += rS[l] * ph[l];
-            v3 += rP[l] * r2[l] + cT[l] * ph[l];
-        }
-        const double w1 = v1 - v2;
-        double w1v[n], muv[n];
-#pragma unroll
-        for (int l = 0; l < n; l++) w1v[l] = readlane_f64(w1, l);
-        double mu = 0;
-#pragma unroll
-        for (int l = 0; l < n; l++) mu += rG[l] * r2[n + l] + rA1[l] * w1v[l];
-        mu = K.is_goal(ri) ? mu : 0.0;
-#pragma unroll
-        for (int l = 0; l < n; l++) muv[l] = readlane_f64(mu, l);
-        double xi = w1, dl = v3;
-#pragma unroll
-        for (int l = 0; l < n; l++) { xi -= rA2[l] * muv[l]; dl += rA3[l] * muv[l]; }
-        if (K.tid < n) { mugn[K.tid] = mu; L[sb + SB::XI + K.tid] = xi; L[sb + SB::LAM + K.tid] = dl; }
+        static_for<1, NI>([&](auto JJ) {   // the other interfaces, front to back: y = the state at the interface in front
+            constexpr int j = decltype(JJ)::value;
+            const int I = sb + SB::IF(j);
+            double cPj[n], rT[n], rP[n], rA2[n], rA3[n], xiU[n], zU[n];
+            col(sb + SB::CH(j) + SB::Pif, cPj); row(I + SB::Tt, rT); row(I + SB::Pa, rP); row(I + SB::A2, rA2); row(I + SB::A3, rA3);
+            __builtin_amdgcn_sched_barrier(0);
+            bcast(xiv, xiU);
+            const double z = dot(cPj, xiU);    // Pi_j' xi_{j-1}
+            bcast(z, zU);
+            xiv = uD[j] + dot(rT, zU) - dot(rA2, muU);
+            dlv = wD[j] + dot(rP, zU) + dot(rA3, muU);
+            if (K.tid < n) { L[sb + SB::XI(j) + K.tid] = xiv; L[sb + SB::LAM(j) + K.tid] = dlv; }
+        });
     } else
     if constexpr (BLK::ONE) {
         if (K.goalmask != 0) wave_reduce_n<n>(th, OpSum());
@@ -1967,8 +2009,9 @@ template <int MODEL, class BLK, bool SEG = false> GD void mid_phase(BLK& K, int 
         double dk[m];
         double ml[SEG ? n : 1];   // (segmented solve: the multiplier of this knot's chain, taken once)
         if constexpr (SEG) {
+            const int mo = seg_mult_off<MODEL, NCH>(k, N, K.P.ll.seg);
 #pragma unroll
-            for (int j = 0; j < n; j++) { const double a_ = K.lds[K.P.ll.seg + SegB<MODEL>::LAM + j], b_ = mugn[j]; ml[j] = (k < seg_s) ? a_ : b_; }
+            for (int j = 0; j < n; j++) ml[j] = K.lds[mo + j];
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -2017,10 +2060,10 @@ template <int MODEL, class BLK, bool SEG = false> GD void mid_phase(BLK& K, int 
     MT_(PF_M_SYNC);
 #undef MT_
 }
-template <int MODEL, class BLK, bool SEG = false> __device__ __noinline__ void mid_phase_call(typename BLK::Args a, int k, bool act, double hdt, Prof* pf) {
+template <int MODEL, class BLK, int NCH = 0> __device__ __noinline__ void mid_phase_call(typename BLK::Args a, int k, bool act, double hdt, Prof* pf) {
     BLK K(a, gusto_dyn_lds);
     using C = typename BLK::C;
-    mid_phase<MODEL, BLK, SEG>(K, k, act, hdt, gusto_dyn_lds + C::misc, gusto_dyn_lds + C::misc + 48, pf);
+    mid_phase<MODEL, BLK, NCH>(K, k, act, hdt, gusto_dyn_lds + C::misc, gusto_dyn_lds + C::misc + 48, pf);
 }
 
 // The phase after the forward sweep of a right-hand side: primal step of this knot, the new costates, row steps and
@@ -2417,21 +2460,25 @@ __device__ __noinline__ ResidOut resid_phase_call(typename BLK::Args a, RowScal 
     return resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, gusto_dyn_lds + C::misc + 32);
 }
 
-// The KKT solve as two Riccati segments joined by a coarse LQR stage (round 6; seg.hpp): parity-green, slower on one wave -- the
-// sequential phases are ISSUE-bound, not latency-bound (profiles/r06_two_chains.txt).  A build switch, off.
-#if GUSTO_SEG_ANY
+// The KKT solve as Riccati segments joined by coarse LQR stages (round 6).  seg.hpp (-DGUSTO_SEG2=1, off): two chains interleaved
+// in ONE wave, freeflyerSE2 -- parity-green, slower: the sequential phases are ISSUE-bound, not latency-bound
+// (profiles/r06_two_chains.txt).  segw.hpp (on): a WAVE per chain, the matrix-core kernels.
 }  // namespace gusto
+#if GUSTO_SEG2
 #include "seg.hpp"
-namespace gusto {
 #else
-template <int MODEL> constexpr bool seg2_model() { return false; }
+namespace gusto { template <int MODEL> constexpr bool seg2_model() { return false; } }
 #endif
+#if GUSTO_SEG_W2
+#include "segw.hpp"
+#endif
+namespace gusto {
 
 // ---- the interior point method ---------------------------------------------------------------------
 // Register discipline: nothing per-thread stays live across a sequential sweep.  Every stage-parallel block
 // re-reads the iterate (Xw/Uw), the linearisation point (Xp/Up) and the stage matrices it needs from LDS / L2
 // and leaves its results in LDS, so the sweeps get the whole register file for latency hiding.
-template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, double Delta, double omega, double muw, IpmOut& out, Prof& pf) {
+template <int MODEL, class BLK, int NCH = 0> GD void ipm_solve(BLK& K, double Delta, double omega, double muw, IpmOut& out, Prof& pf) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m, NZ = n + m, NHX = n * (n + 1) / 2, NHU = m * (m + 1) / 2, NQ = NZ * (NZ + 1) / 2;
@@ -2447,13 +2494,14 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
     double* gxs = K.misc + 16;   // gx of knot 0 (n values)
     double* mug = K.misc + 32;   // goal multipliers (state-index space)
     double* mugn = K.misc + 48;  // ... of the current Newton step
-    // the horizon split into two Riccati segments (seg.hpp): chain A = stages 0 .. seg_s - 1, chain B = seg_s .. N - 1
-    constexpr bool SEGB = seg2_big<MODEL>() && BLK::ONE && W2;   // ... of the matrix-core kernels (scp_kernel_w2: a wave per chain)
+    // the horizon split into Riccati segments: NCH chains, a wave each (segw.hpp: scp_kernel_w2, the matrix-core kernels; launch_scp
+    // starts it for N >= NCH GUSTO_SEG_MIN_N only), or two chains in the one wave (seg.hpp: A = stages 0 .. seg_s - 1, B = seg_s .. N - 1)
+    constexpr bool SEGB = seg2_big<MODEL>() && BLK::ONE && NCH > 0;
     constexpr bool SEG = (seg2_model<MODEL>() && BLK::ONE) || SEGB;
-#if GUSTO_SEG_ANY
-    const bool seg = SEG && (SEGB || N >= GUSTO_SEG_MIN_N);   // (launch_scp starts the two-wave kernel for N >= GUSTO_SEG_MIN_N only)
-    const int seg_s = seg_split(N);
-    if constexpr (SEGB) segw_open<MODEL>(K);
+    [[maybe_unused]] const bool seg = SEG && (SEGB || N >= 2 * GUSTO_SEG_MIN_N);
+    [[maybe_unused]] const int seg_s = seg_split(N);
+#if GUSTO_SEG_W2
+    if constexpr (SEGB) segw_open<MODEL, NCH>(K);
 #endif
 
     RowCtx<MODEL> ctx;
@@ -2510,9 +2558,7 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
     }
     int status = GUSTO_SOLVER_FAILED, it = 0, n_acc = 0;
     bool adj_ok = true;   // the adjoint costates of the 12/13-state kernels are still in use (see below)
-#if GUSTO_SEG_ANY
-    if constexpr (SEGB) adj_ok = !seg;   // (the segmented solve takes its costates from the P | Pi records: record s - 1 = (0 | I))
-#endif
+    if constexpr (SEGB) adj_ok = false;   // (the segmented solve takes its costates from the P | Pi records: a record (0 | I) in front of every interface)
     double res_p = 0, res_d = 0, mu = 0, alpha_prev = 0.0, mu_start = 0.0;
     for (it = 0;; it++) {
         GUSTO_REFRESH_K();
@@ -2582,19 +2628,22 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
         }
         // (4) factorise
         bool seg_done = false;
-#if GUSTO_SEG_ANY
         [[maybe_unused]] bool seg_fail = false;
+#if GUSTO_SEG_W2
         if constexpr (SEGB) {
             // chain A on the helper wave, chain B here; after the join the helper goes on with the coarse stage while this wave
             // builds the predictor's right-hand side -- the second join waits in front of the first backward sweep
-            segw_post<MODEL>(K, SEGW_FACTOR);
-            factor_sweep_seg_call<MODEL>(K.args(), &pf);
+            segw_post<MODEL, NCH>(K, SEGW_FACTOR);
+            factor_sweep_seg_call<MODEL, NCH>(K.args(), &pf);
             segw_join();
             pf.tick(PF_FACTOR);
             GUSTO_REFRESH_K();
             seg_done = true;
-            if (*fail != 0.0) { segw_join(); break; }   // (the barriers of the two waves stay paired)
-        } else if constexpr (SEG) {
+            if (*fail != 0.0) { segw_join(); break; }   // (the barriers of the waves stay paired)
+        }
+#endif
+#if GUSTO_SEG2
+        if constexpr (SEG && !SEGB) {
             if (seg) {
                 factor_sweep_pg2s<MODEL>(SweepView<MODEL>::make(K), fail, pf, seg_s);
                 pf.tick(PF_FACTOR);
@@ -2698,36 +2747,46 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
             }
             K.sync();
             pf.tick(PF_RHS);
-#if GUSTO_SEG_ANY
+            // the two vector sweeps of this right-hand side and the phase between them: the chains' waves side by side (segw.hpp), two
+            // chains in the one wave (seg.hpp), or the sequential recursion
+            bool swp = false;
+#if GUSTO_SEG_W2
             if constexpr (SEGB) {
-                if (pass == 0) {   // the coarse stage of this factorisation is done
+                if (pass == 0) {   // the fold of this factorisation is done
                     segw_join();
                     if (*fail != 0.0) { seg_fail = true; break; }
                 }
-                segw_post<MODEL>(K, SEGW_BACK); backward_sweep_seg_call<MODEL>(K.args()); segw_join();
+                segw_post<MODEL, NCH>(K, SEGW_BACK); backward_sweep_seg_call<MODEL, NCH>(K.args()); segw_join();
+                pf.tick(PF_BACK);
+                GUSTO_REFRESH_K();
+                mid_phase_call<MODEL, BLK, NCH>(K.args(), k, act, hdt, &pf);
+                pf.tick(PF_MID);
+                segw_post<MODEL, NCH>(K, SEGW_FWD); forward_sweep_seg_call<MODEL, NCH>(K.args()); segw_join();
+                swp = true;
             }
-            else if constexpr (SEG) { if (seg) backward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else backward_sweep<MODEL>(K); }
-            else
 #endif
+#if GUSTO_SEG2
+            if constexpr (SEG && !SEGB) {
+                if (seg) {
+                    backward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s);
+                    pf.tick(PF_BACK);
+                    GUSTO_REFRESH_K();
+                    mid_phase_seg<MODEL>(K, k, act, hdt, seg_s, mugn, &pf);
+                    pf.tick(PF_MID);
+                    forward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s);
+                    swp = true;
+                }
+            }
+#endif
+            if (!swp) {
             backward_sweep<MODEL>(K);
             pf.tick(PF_BACK);
             GUSTO_REFRESH_K();
-#if GUSTO_SEG_ANY
-            if constexpr (SEGB) mid_phase_call<MODEL, BLK, true>(K.args(), k, act, hdt, &pf);
-            else
-#endif
             if constexpr (T::SWEEP_CALL) mid_phase_call<MODEL, BLK>(K.args(), k, act, hdt, &pf);
-#if GUSTO_SEG_ANY
-            else if constexpr (SEG) { if (seg) mid_phase_seg<MODEL>(K, k, act, hdt, seg_s, mugn, &pf); else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf); }
-#endif
             else mid_phase<MODEL>(K, k, act, hdt, red, mugn, &pf);
             pf.tick(PF_MID);
-#if GUSTO_SEG_ANY
-            if constexpr (SEGB) { segw_post<MODEL>(K, SEGW_FWD); forward_sweep_seg_call<MODEL>(K.args()); segw_join(); }
-            else if constexpr (SEG) { if (seg) forward_sweep_seg<MODEL>(SweepView<MODEL>::make(K), seg_s); else forward_sweep<MODEL>(K); }
-            else
-#endif
             forward_sweep<MODEL>(K);
+            }
             if constexpr (BLK::ONE && T::SWEEP_CALL && !SEGB)
                 if (!adj_now)
                 if (pass == 1 || ncomp == 0) costate_pass_1w_call<MODEL>(K.args());
@@ -2739,17 +2798,19 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
 #ifdef GUSTO_PROFILE
             ctx.pf = &pf; ctx.pfb = PF_S0;
 #endif
-            if constexpr (SEGB) {   // the new costates (P | Pi records) on the helper wave, beside the step phase
+#if GUSTO_SEG_W2
+            if constexpr (SEGB) {   // the new costates (P | Pi records) on a helper wave, beside the step phase
                 const bool cs = pass == 1 || ncomp == 0;
-                if (cs) segw_post<MODEL>(K, SEGW_COSTATE);
+                if (cs) segw_post<MODEL, NCH>(K, SEGW_COSTATE);
                 so = step_phase_call<MODEL, BLK, false>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
                 if (cs) segw_join();
             } else
+#endif
             if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL, BLK>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
             else {
                 // (segmented solve: the costates of chain A's knots hang on dlam, those of chain B's on mu_g)
                 const double* mult = mugn;
-#if GUSTO_SEG_ANY
+#if GUSTO_SEG2
                 if constexpr (SEG && !SEGB) mult = (seg && k < seg_s) ? (const double*)(K.misc + (SegC<MODEL>::LAM - BLK::C::misc)) : mult;
 #endif
                 so = step_phase<MODEL>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, mult, gxs);
@@ -2772,9 +2833,7 @@ template <int MODEL, class BLK, bool W2 = false> GD void ipm_solve(BLK& K, doubl
                 if (ncomp == 0) break;  // equality-constrained QP: the predictor already is the Newton step
             }
         }
-#if GUSTO_SEG_ANY
         if (seg_fail) break;
-#endif
         pf.tick(PF_STEP);
         // (6) update
         GUSTO_REFRESH_K();

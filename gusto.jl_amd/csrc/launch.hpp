@@ -85,15 +85,18 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     if (masked) P.n_fresh = h->n_active;
     int NTL = NT;
 #if GUSTO_SEG_W2
-    // a batch that leaves half of the SIMDs without a wave (one wave per problem, <= 2 problems per CU) runs two waves per
-    // problem: the KKT solve's sequential phases as two Riccati segments side by side (scp_kernel_w2, seg.hpp)
+    // a batch that leaves SIMDs without a wave runs several waves per problem, the KKT solve's sequential phases as Riccati segments
+    // side by side (scp_kernel_w2, segw.hpp): four waves while every problem has a CU of its own, two up to the batch size where
+    // the one-wave kernel's three problems per CU win (measured: astrobeeSE3 4096, astrobeeSE3manifold 2048 .. 4096)
     if constexpr (seg2_big<MODEL>()) {
-        bool w2 = NT == 64 && h->N >= GUSTO_SEG_MIN_N && P.n_fresh <= 2 * cus;
-        if (const char* e = dev_env("GUSTO_DEV_W2")) w2 = atoi(e) != 0 && NT == 64 && h->N >= GUSTO_SEG_MIN_N;
-        if (w2) {
-            P.ll = make_lds_layout<MODEL>(h->N, false, true);
+        int nch = 0;
+        if (NT == 64 && P.n_fresh <= cus && h->N >= 4 * GUSTO_SEG_MIN_N) nch = 4;
+        else if (NT == 64 && P.n_fresh <= 8 * cus && h->N >= 2 * GUSTO_SEG_MIN_N) nch = 2;
+        if (const char* e = dev_env("GUSTO_DEV_W2")) { nch = atoi(e); if (nch == 1) nch = 2; if ((nch != 2 && nch != 4) || NT != 64 || h->N < nch * GUSTO_SEG_MIN_N) nch = 0; }
+        if (nch) {
+            P.ll = make_lds_layout<MODEL>(h->N, false, nch);
             lds = (size_t)P.ll.total * sizeof(double);
-            kern = &scp_kernel_w2<MODEL>; NTL = 128;
+            kern = (nch == 4) ? &scp_kernel_w2<MODEL, 4> : &scp_kernel_w2<MODEL, 2>; NTL = 64 * nch;
         }
     }
 #endif

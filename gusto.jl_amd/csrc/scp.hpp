@@ -79,7 +79,7 @@ template <class BLK> GD void store_traj(BLK& K, const double* Xs, const double* 
 // One time slice of one problem: the body of the persistent kernel below.  `cont` = the problem has run before in this
 // gusto_solve call (no new leading history entries), `trips` = how many GuSTO trips this slice may take.  Returns the
 // penalty level of the problem (number of omega raises so far) if it has to come back for another slice, -1 if it stopped.
-template <int MODEL, bool ONEWAVE, bool W2 = false> GD int scp_problem(const KParams& P, double* lds, int b_, int slot, bool cont, int trips) {
+template <int MODEL, bool ONEWAVE, int NCH = 0> GD int scp_problem(const KParams& P, double* lds, int b_, int slot, bool cont, int trips) {
     using T = MT<MODEL>;
     constexpr int n = T::n, m = T::m;
     Blk<MODEL, ONEWAVE> K(P, lds, b_, slot);
@@ -123,7 +123,7 @@ template <int MODEL, bool ONEWAVE, bool W2 = false> GD int scp_problem(const KPa
         linearize<MODEL>(K, toggle);                       // :95  update_model_params!
         pf.tick(PF_LIN);
         IpmOut io;
-        ipm_solve<MODEL, Blk<MODEL, ONEWAVE>, W2>(K, Delta, omega, (warm && !hook) ? warm_mu(P.io, conv_prev) : 0.0, io, pf);  // :96-104
+        ipm_solve<MODEL, Blk<MODEL, ONEWAVE>, NCH>(K, Delta, omega, (warm && !hook) ? warm_mu(P.io, conv_prev) : 0.0, io, pf);  // :96-104
         if (hook) {
             pf.flush(P.prof, b, cont);
             store_traj(K, K.Xw, K.Uw, P.sub_X + (size_t)b * N * n, P.sub_U + (size_t)b * N * m);
@@ -331,8 +331,8 @@ GD int sched_pop(const KParams& P, bool& cont, int& from) {   // from: the level
 }
 
 // the persistent loop of a resident workgroup: problems from the scheduler until it has none left
-// (W2: the main wave of scp_kernel_w2 -- the one-wave program, its sequential phases shared with the helper wave)
-template <int MODEL, bool ONEWAVE, bool W2> GD void scp_kernel_body(const KParams& P, double* lds) {
+// (NCH > 0: the main wave of scp_kernel_w2 -- the one-wave program, its sequential phases shared with the helper waves)
+template <int MODEL, bool ONEWAVE, int NCH> GD void scp_kernel_body(const KParams& P, double* lds) {
     const int slot = blockIdx.x;
     for (;;) {
         int b = 0, ci = 0, from = 0;
@@ -374,7 +374,7 @@ template <int MODEL, bool ONEWAVE, bool W2> GD void scp_kernel_body(const KParam
         // a problem that starts its last slice will not be pushed again (SQ_PROBING: the problems that still may be)
         if (sliced && trips == (1 << 30) && threadIdx.x == 0)
             __hip_atomic_fetch_sub(P.queue + SQ_PROBING, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const int lvl = scp_problem<MODEL, ONEWAVE, W2>(P, lds, b, slot, cont, trips);
+        const int lvl = scp_problem<MODEL, ONEWAVE, NCH>(P, lds, b, slot, cont, trips);
         blk_sync<ONEWAVE>();               // the next problem reuses this workgroup's LDS and workspace slot
         if constexpr (!ONEWAVE) __syncthreads();
         if (threadIdx.x == 0) {
@@ -404,23 +404,23 @@ scp_kernel(const KParams P) {
     if (threadIdx.x == 0) gusto_dbg_lds_limit() = __builtin_amdgcn_groupstaticsize() + (unsigned)P.ll.total * 8u;
     __syncthreads();
 #endif
-    scp_kernel_body<MODEL, ONEWAVE, false>(P, lds);
+    scp_kernel_body<MODEL, ONEWAVE, 0>(P, lds);
 }
 
 #if GUSTO_SEG_W2
-// A WAVE PER CHAIN of the segmented KKT solve (seg.hpp), for batches that leave SIMDs idle: two waves per problem.  Wave 0 is the
-// one-wave kernel above, unchanged but for the three sequential phases, where it takes the rear half of the horizon; wave 1
-// sleeps at a barrier between them and takes the front half.
-template <int MODEL> __global__ void __launch_bounds__(128, 1) scp_kernel_w2(const KParams P) {
+// A WAVE PER CHAIN of the segmented KKT solve (segw.hpp), for batches that leave SIMDs idle: NCH = 2 or 4 waves per problem.  Wave 0
+// is the one-wave kernel above, unchanged but for the sequential phases, where it takes the last chain of the horizon; the other waves
+// sleep at a barrier between those phases and take a chain each.
+template <int MODEL, int NCH> __global__ void __launch_bounds__(64 * NCH, 1) scp_kernel_w2(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
 #ifdef GUSTO_DEBUG_LDS
     if (threadIdx.x == 0) gusto_dbg_lds_limit() = __builtin_amdgcn_groupstaticsize() + (unsigned)P.ll.total * 8u;
     __syncthreads();
 #endif
     if constexpr (seg2_big<MODEL>()) {
-        if (threadIdx.x >= 64) { segw_helper<MODEL>(P, lds); return; }
-        scp_kernel_body<MODEL, true, true>(P, lds);
-        segw_exit(lds, P.ll.seg, SegB<MODEL>::MBX);
+        if (threadIdx.x >= 64) { segw_helper<MODEL, NCH>(P, lds); return; }
+        scp_kernel_body<MODEL, true, NCH>(P, lds);
+        segw_exit(lds, P.ll.seg + SegB<MODEL, NCH>::MBX);
     }
 }
 #endif

@@ -23,9 +23,6 @@
 
 namespace gusto {
 
-#ifndef GUSTO_SEG_MIN_N
-#define GUSTO_SEG_MIN_N 8       // shorter horizons keep the sequential recursion (a segment of two or three stages is barely controllable)
-#endif
 #ifndef GUSTO_SEG_PIV
 #define GUSTO_SEG_PIV 1e-13     // pivot floor of chol(Gd_A), relative to its largest diagonal entry (prototype: 1e-12 .. 1e-14 alike, 1e-16 fails)
 #endif
@@ -34,7 +31,6 @@ namespace gusto {
 template <int MODEL> constexpr bool seg2_model() {
     return GUSTO_SEG2 && MT<MODEL>::PG2 && MT<MODEL>::LTI && MT<MODEL>::NDEF == 0 && LdsC<MODEL, true>::KD_LDS && !MT<MODEL>::SWEEP_CALL;
 }
-GD int seg_split(int N) { return N >> 1; }   // chain A = stages 0 .. s-1, chain B = s .. N-1 (one stage longer for odd N)
 
 // LDS map of the segmented solve (offsets in doubles from the base of the dynamic LDS).  Chain A's working set of the factor
 // sweep lives in the [Phi Gam] staging buffers the PG2 sweep never uses; the coarse stage's matrices take the place of the
@@ -677,336 +673,6 @@ template <int MODEL, class BLK> GD void mid_phase_seg(BLK& K, int k, bool act, d
     K.sync();
     MT_(PF_M_SYNC);
 #undef MT_
-}
-
-// =====================================================================================================================
-// The matrix-core kernels (astrobeeSE3, astrobeeSE3manifold: MT::MFMA, phases as real calls).  Same algorithm; the block of
-// the segmented solve sits behind everything else in LDS (common.hpp: SegB, LdsLayout::seg).  Costates come from the P | Pi
-// records (costate_pass_seg): record s - 1 = (0 | I), so nu_s = lam0 + dlam falls out of the same formula.
-// =====================================================================================================================
-
-// the coarse stage's matrices for n > 8 (n^2 > 64: entries in rounds of 64 lanes); Gdc^-1 by inv_spd_block (sGd -> sP)
-template <int MODEL, class BLK> GD void seg_coarse_factor_big(BLK& K, double* fail) {
-    using SB = SegB<MODEL>;
-    constexpr int n = SB::n, NN = n * n, RN = (NN + 63) / 64;
-    const LPtr<double> L = K.lds;
-    const int tid = K.tid, sb = K.P.ll.seg;
-    int ei[RN], ej[RN];
-    bool on[RN];
-#pragma unroll
-    for (int r = 0; r < RN; r++) { const int e = tid + 64 * r; on[r] = e < NN; ei[r] = on[r] ? e / n : 0; ej[r] = on[r] ? e % n : 0; }
-    auto rm = [&](int off) { return [=](int r_, int c_) { return sb + off + r_ * n + c_; }; };
-    auto tr = [&](int off) { return [=](int r_, int c_) { return sb + off + c_ * n + r_; }; };
-    // dst(i, j) = add(i, j) + sum_l A(i, l) B(l, j); every round of entries computed, then stored
-    auto prod = [&](int dst, auto A, auto B, auto add) {
-        double acc[RN];
-#pragma unroll
-        for (int r = 0; r < RN; r++) {
-            double a = add(ei[r], ej[r]);
-#pragma unroll
-            for (int l = 0; l < n; l++) a += L[A(ei[r], l)] * L[B(l, ej[r])];
-            acc[r] = a;
-        }
-#pragma unroll
-        for (int r = 0; r < RN; r++) if (on[r]) L[sb + dst + ei[r] * n + ej[r]] = acc[r];
-    };
-    auto zero = [](int, int) { return 0.0; };
-    bool ok = true;
-    // X = I + P_B Gd_A -> X1, inverted in place by Gauss-Jordan (no pivoting, see seg_coarse_factor)
-    prod(SB::X1, rm(SB::PB), rm(SB::GDA), [](int i_, int j_) { return (i_ == j_) ? 1.0 : 0.0; });
-    K.sync();
-    for (int c = 0; c < n; c++) {
-        const double piv = L[sb + SB::X1 + c * n + c];
-        if (!(fabs(piv) > 0.0) || !isfinite(piv)) ok = false;
-        const double d = rcp_nr(piv);
-        double w[RN];
-#pragma unroll
-        for (int r = 0; r < RN; r++) {
-            const int i = ei[r], j = ej[r];
-            const double wij = L[sb + SB::X1 + i * n + j], wcj = L[sb + SB::X1 + c * n + j], wic = L[sb + SB::X1 + i * n + c];
-            const double rowc = (j == c) ? d : wcj * d;
-            const double other = (j == c) ? -(wic * d) : wij - wic * (wcj * d);
-            w[r] = (i == c) ? rowc : other;
-        }
-        K.sync();
-#pragma unroll
-        for (int r = 0; r < RN; r++) if (on[r]) L[sb + SB::X1 + ei[r] * n + ej[r]] = w[r];
-        K.sync();
-    }
-    // X1 = Y = (I + P_B Gd_A)^-1:  Tt = Y', Sig = Gd_A Y, Pa = Y P_B, A3 = Y Pi_B
-#pragma unroll
-    for (int r = 0; r < RN; r++) if (on[r]) L[sb + SB::Tt + ej[r] * n + ei[r]] = L[sb + SB::X1 + ei[r] * n + ej[r]];
-    prod(SB::Sg, rm(SB::GDA), rm(SB::X1), zero);
-    prod(SB::Pa, rm(SB::X1), rm(SB::PB), zero);
-    prod(SB::A3, rm(SB::X1), rm(SB::PIB), zero);
-    K.sync();
-    {   // Sig is symmetric in exact arithmetic: both triangles from one mean
-        double sm[RN];
-#pragma unroll
-        for (int r = 0; r < RN; r++) sm[r] = 0.5 * (L[sb + SB::Sg + ei[r] * n + ej[r]] + L[sb + SB::Sg + ej[r] * n + ei[r]]);
-        K.sync();
-#pragma unroll
-        for (int r = 0; r < RN; r++) if (on[r]) L[sb + SB::Sg + ei[r] * n + ej[r]] = sm[r];
-        K.sync();
-    }
-    prod(SB::A2, rm(SB::Sg), rm(SB::PIB), zero);                 // A2 = Sig Pi_B
-    K.sync();
-    {   // Gdc = Gd_B + Pi_B' A2 -> sGd, then its inverse -> sP (inv_spd_block: identity on the coordinates without a point goal)
-        double g[RN];
-#pragma unroll
-        for (int r = 0; r < RN; r++) {
-            double a = K.sGd[on[r] ? ei[r] * n + ej[r] : 0];
-#pragma unroll
-            for (int l = 0; l < n; l++) a += L[sb + SB::PIB + l * n + ei[r]] * L[sb + SB::A2 + l * n + ej[r]];
-            g[r] = a;
-        }
-        K.sync();
-#pragma unroll
-        for (int r = 0; r < RN; r++) if (on[r]) K.sGd[ei[r] * n + ej[r]] = g[r];
-        K.sync();
-    }
-    inv_spd_block<MODEL>(K, fail);
-    K.sync();
-#pragma unroll
-    for (int r = 0; r < RN; r++) if (on[r]) L[sb + SB::Gci + ei[r] * n + ej[r]] = K.sP[ei[r] * n + ej[r]];
-    K.sync();
-    prod(SB::A1, rm(SB::Gci), tr(SB::PIB), zero);                // A1 = Gdc^-1 Pi_B'
-    if (!ok) *fail = 1.0;
-    K.sync();
-}
-
-// ---- the ring-buffered one-wave vector sweeps of ipm.hpp over a RANGE of knots (operands from the global Phicl records) ----
-template <int MODEL, class BLK> GD void backward_sweep_ring_rng(const BLK& K, int khi, int klo, int start, int last_out) {
-    constexpr int n = BLK::n, C = 64 / n, PS = 4, RING = GUSTO_SWEEP_RING;
-    const LPtr<double> L = K.lds;
-    const int tid = K.tid;
-    const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
-    const int pvo = LdsC<MODEL, true>::vecs + 2 * K.N * n;
-    auto fetch = [&](int k0, double* c, double& q) {
-        const int kk = (k0 - g >= klo) ? k0 - g : klo;
-#pragma unroll
-        for (int l = 0; l < n; l++) c[l] = K.Phicl[(size_t)kk * BLK::SPH + l * n + i];
-        q = K.pv[kk * n + i];
-    };
-    double cb[RING][n], qb[RING];
-#pragma unroll
-    for (int d = 0; d < RING - 1; d++) fetch(khi - d * C, cb[d], qb[d]);
-    double pval = L[start + i];
-    K.sync();
-    if (tid < n) K.pv[khi * n + tid] = pval;
-    for (int kb = khi; kb >= klo; kb -= RING * C) {
-        static_for<0, RING>([&](auto DD) {
-            constexpr int d = decltype(DD)::value;
-            const int k0 = kb - d * C;
-            fetch(k0 - (RING - 1) * C, cb[(d + RING - 1) % RING], qb[(d + RING - 1) % RING]);
-            if (k0 >= klo) {
-#pragma unroll
-                for (int gs = 0; gs < C; gs++) {
-                    if (k0 - gs >= klo) {
-                        const int sg = (gs == 0) ? C - 1 : gs - 1;
-                        double acc[PS];
-#pragma unroll
-                        for (int q = 0; q < PS; q++) acc[q] = (q == 0) ? qb[d] : 0.0;
-                        double pb[n];
-#pragma unroll
-                        for (int l = 0; l < n; l++) pb[l] = readlane_f64(pval, sg * n + l);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int l = 0; l < n; l++) acc[l % PS] += cb[d][l] * pb[l];
-                        const double sacc = (acc[0] + acc[1]) + (acc[2] + acc[PS - 1]);
-                        pval = (g == gs) ? sacc : pval;
-                    }
-                }
-                const int kk = k0 - g;
-                if (tid < C * n && kk >= klo) {
-                    const int dst = (kk == klo && last_out >= 0) ? last_out + i : pvo + (kk - 1) * n + i;
-                    L[dst] = pval;
-                }
-            }
-        });
-    }
-    K.sync();
-}
-template <int MODEL, class BLK> GD void forward_sweep_ring_rng(const BLK& K, int klo, int khi, int start) {
-    constexpr int n = BLK::n, C = 64 / n, PS = 4, RING = GUSTO_SWEEP_RING;
-    const LPtr<double> L = K.lds;
-    const int tid = K.tid;
-    const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
-    auto fetch = [&](int k0, double* r, double& c) {
-        const int kk = (k0 + g <= khi) ? k0 + g : khi;
-#pragma unroll
-        for (int l = 0; l < n; l++) r[l] = K.Phicl[(size_t)kk * BLK::SPH + i * n + l];
-        c = K.dY[kk * n + i];
-    };
-    double rb[RING][n], qb[RING];
-#pragma unroll
-    for (int d = 0; d < RING - 1; d++) fetch(klo + d * C, rb[d], qb[d]);
-    double yval = (start >= 0) ? L[start + i] : 0.0;
-    K.sync();
-    for (int kb = klo; kb <= khi; kb += RING * C) {
-        static_for<0, RING>([&](auto DD) {
-            constexpr int d = decltype(DD)::value;
-            const int k0 = kb + d * C;
-            fetch(k0 + (RING - 1) * C, rb[(d + RING - 1) % RING], qb[(d + RING - 1) % RING]);
-            if (k0 <= khi) {
-#pragma unroll
-                for (int gs = 0; gs < C; gs++) {
-                    if (k0 + gs <= khi) {
-                        const int sg = (gs == 0) ? C - 1 : gs - 1;
-                        double acc[PS];
-#pragma unroll
-                        for (int q = 0; q < PS; q++) acc[q] = (q == 0) ? qb[d] : 0.0;
-                        double pb[n];
-#pragma unroll
-                        for (int l = 0; l < n; l++) pb[l] = readlane_f64(yval, sg * n + l);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int l = 0; l < n; l++) acc[l % PS] += rb[d][l] * pb[l];
-                        const double sacc = (acc[0] + acc[1]) + (acc[2] + acc[PS - 1]);
-                        yval = (g == gs) ? sacc : yval;
-                    }
-                }
-                const int kk = k0 + g;
-                if (tid < C * n && kk <= khi) K.dY[kk * n + i] = yval;
-            }
-        });
-    }
-    K.sync();
-}
-
-// costate_pass_1w of the segmented solve: nu_{k+1} = P_k dy_k + p_k + Pi_k mult, mult = dlam for the knots of chain A, mu_g for chain B's
-template <int MODEL> GD void costate_pass_seg(SweepView<MODEL> K, int s) {
-    using T = MT<MODEL>;
-    using R = Rec<MODEL>;
-    using SB = SegB<MODEL>;
-    constexpr int n = T::n, C = 64 / n;
-    const LPtr<double> L = K.lds;
-    const int tid = K.tid, N = K.N;
-    const int g = (tid < C * n) ? tid / n : C - 1, i = (tid < C * n) ? tid % n : 0;
-    double mg[n], lm[n];
-#pragma unroll
-    for (int l = 0; l < n; l++) { mg[l] = L[LdsC<MODEL, true>::misc + 48 + l]; lm[l] = L[K.seg_off + SB::LAM + l]; }
-    constexpr int RING = GUSTO_SWEEP_RING;
-    double pr[RING][n], pi[RING][n];
-    auto fetch = [&](int k0, double* a, double* b) {
-        const int k = (k0 + g + 1 < N) ? k0 + g : N - 2;
-        const double* pa = K.Paft + (size_t)k * R::SNN + i;     // (records stored transposed by factor_sweep_mfma)
-        const double* pb = K.Piaft + (size_t)k * R::SNN + i;
-#pragma unroll
-        for (int l = 0; l < n; l++) { a[l] = pa[l * n]; b[l] = pb[l * n]; }
-    };
-#pragma unroll
-    for (int d = 0; d < RING - 1; d++) fetch(d * C, pr[d], pi[d]);
-    for (int kb = 0; kb + 1 < N; kb += RING * C) {
-        static_for<0, RING>([&](auto DD) {
-            constexpr int d = decltype(DD)::value;
-            const int k0 = kb + d * C;
-            fetch(k0 + (RING - 1) * C, pr[(d + RING - 1) % RING], pi[(d + RING - 1) % RING]);
-            if (k0 + 1 < N) {
-                const bool ok = tid < C * n && k0 + g + 1 < N;
-                const int k = (k0 + g + 1 < N) ? k0 + g : N - 2;
-                double sacc = K.pv[k * n + i] - K.rv[k * n + i];
-#pragma unroll
-                for (int l = 0; l < n; l++) sacc += pr[d][l] * K.dY[k * n + l] + pi[d][l] * ((k < s) ? lm[l] : mg[l]);
-                if (ok) K.nun[(k + 1) * n + i] = sacc;
-            }
-        });
-    }
-    K.sync();
-}
-
-// ---- a wave per chain (scp_kernel_w2): the MAIN wave (lanes 0..63 of the workgroup) runs the program of the one-wave kernel and, in
-// the three sequential phases, chain B; the HELPER wave (lanes 64..127) waits at a barrier for a command and runs chain A beside
-// it.  Two workgroup barriers per phase: post (the main wave has written the command and everything the helper reads: drain, barrier)
-// and join (both have drained their stores).  The phases themselves stay barrier-free one-wave code on disjoint knots and LDS.
-constexpr int SEGW_FACTOR = 1, SEGW_BACK = 2, SEGW_FWD = 3, SEGW_COSTATE = 4, SEGW_EXIT = 9;
-GD void segw_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-GD void segw_join() { segw_barrier(); }
-// mailbox: [0] the command, [2..6] what the helper needs to rebuild the problem's view (written once per interior point solve)
-template <int MODEL, class BLK> GD void segw_open(BLK& K) {
-    const LPtr<double> L = K.lds;
-    const int mb = K.P.ll.seg + SegB<MODEL>::MBX;
-    if (K.tid == 0) {
-        const typename BLK::Args a = K.args();
-        L[mb + 2] = (double)a.b; L[mb + 3] = (double)a.slot; L[mb + 4] = (double)a.goalmask; L[mb + 5] = (double)a.boxmask; L[mb + 6] = a.dt;
-    }
-}
-template <int MODEL, class BLK> GD void segw_post(BLK& K, int cmd) {
-    const LPtr<double> L = K.lds;
-    if (K.tid == 0) L[K.P.ll.seg + SegB<MODEL>::MBX] = (double)cmd;
-    segw_barrier();
-}
-// kernel exit of the main wave: release the helper for good (no join: a wave that has ended is not waited for)
-GD void segw_exit(double* lds, int seg_off, int mbx) {
-    if ((threadIdx.x & 63) == 0) lds[seg_off + mbx] = (double)SEGW_EXIT;
-    segw_barrier();
-}
-// The helper wave.  What it runs, each beside the main wave's work named in brackets:
-//   FACTOR   chain A's factor sweep [chain B's]; join; the coarse stage [the predictor's right-hand side]; join
-//   BACK     chain A's backward vector sweep [chain B's]; join
-//   FWD      chain A's forward sweep [chain B's]; join
-//   COSTATE  the new costates of every knot from the P | Pi records and the first knot's closing equation [the step phase]; join
-// The view of the problem (some 45 base pointers, scalar loads from the kernel arguments) is rebuilt when the problem changes, not
-// per command: it sat on the critical path of every phase.
-template <int MODEL> GD void segw_helper(const KParams& P, double* lds) {
-    using SB = SegB<MODEL>;
-    using BLK = Blk<MODEL, true>;
-    using C = LdsC<MODEL, true>;
-    constexpr int n = MT<MODEL>::n;
-    const LPtr<double> L = lds;
-    const int sb = P.ll.seg, mb = sb + SB::MBX;
-    Prof pfd;
-    asm volatile("s_barrier" ::: "memory");
-    int cmd = (int)L[mb];
-    while (cmd != SEGW_EXIT) {
-        typename BLK::Args a;
-        a.Pk = (const KParams*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // (inlined into the kernel; KParams is its first argument)
-        const double pb = L[mb + 2];
-        a.b = (int)pb; a.slot = (int)L[mb + 3]; a.goalmask = (unsigned)L[mb + 4]; a.boxmask = (unsigned)L[mb + 5]; a.dt = L[mb + 6];
-        BLK B(a, lds);
-        const int N = B.N, s = seg_split(N);
-        double* fail = lds + C::misc + 8;
-        do {
-            if (cmd == SEGW_FACTOR) {
-                SweepView<MODEL> K = SweepView<MODEL>::make(B);
-                K.sPG = lds + sb + SB::sPG2; K.sHh = lds + sb + SB::Lw2;      // its own operand buffers: the main wave's sweep runs beside it
-                factor_sweep_mfma<MODEL, false, true>(K, fail, pfd, s - 1, 0, true);
-                segw_barrier();
-                seg_coarse_factor_big<MODEL>(B, fail);
-            } else if (cmd == SEGW_BACK) {
-                backward_sweep_ring_rng<MODEL>(B, s - 1, 1, C::vecs + 5 * N * n + s * n, -1);      // from pt_{s-1} = lam0 = nu_s
-            } else if (cmd == SEGW_FWD) {
-                forward_sweep_ring_rng<MODEL>(B, 0, s - 2, -1);
-            } else if (cmd == SEGW_COSTATE) {
-                costate_pass_seg<MODEL>(SweepView<MODEL>::make(B), s);
-                if (B.tid == 0) costate_close_x1<MODEL>(B, 0.5 * B.dt, lds + C::misc + 16);
-            }
-            segw_barrier();
-            asm volatile("s_barrier" ::: "memory");
-            cmd = (int)L[mb];
-        } while (cmd != SEGW_EXIT && L[mb + 2] == pb);
-    }
-}
-
-// the main wave's share of the three sequential phases (chain B), as called phases
-template <int MODEL> __device__ __noinline__ void factor_sweep_seg_call(typename Blk<MODEL, true>::Args a, Prof* pf) {
-    Blk<MODEL, true> B(a, gusto_dyn_lds);
-    SweepView<MODEL> K = SweepView<MODEL>::make(B);
-    factor_sweep_mfma<MODEL, false, true>(K, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, *pf, K.N - 1, seg_split(K.N), false);
-}
-template <int MODEL> __device__ __noinline__ void backward_sweep_seg_call(typename Blk<MODEL, true>::Args a) {
-    Blk<MODEL, true> B(a, gusto_dyn_lds);
-    using C = LdsC<MODEL, true>;
-    constexpr int n = MT<MODEL>::n;
-    const int N = B.N, s = seg_split(N);
-    backward_sweep_ring_rng<MODEL>(B, N - 1, s, C::vecs + 4 * N * n + (N - 1) * n, B.P.ll.seg + SegB<MODEL>::PBV);
-}
-template <int MODEL> __device__ __noinline__ void forward_sweep_seg_call(typename Blk<MODEL, true>::Args a) {
-    Blk<MODEL, true> B(a, gusto_dyn_lds);
-    constexpr int n = MT<MODEL>::n;
-    const int N = B.N, s = seg_split(N), xi = B.P.ll.seg + SegB<MODEL>::XI;
-    if (B.tid < n) B.dY[(s - 1) * n + B.tid] = B.lds[xi + B.tid];     // (chain A's end state is xi by construction: its sweep stops at s - 2)
-    forward_sweep_ring_rng<MODEL>(B, s, N - 1, xi);
 }
 
 }  // namespace gusto
