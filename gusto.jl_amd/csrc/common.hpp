@@ -375,6 +375,8 @@ template <int MODEL> constexpr bool seg2_big() { return GUSTO_SEG_W2 && MT<MODEL
 // (= waves per problem, 2 or 4): chain c covers the stages seg_lo(c) .. seg_lo(c + 1) - 1, interface j sits between chain j and
 // what lies behind it -- the chains j + 1 .. NCH - 1 FOLDED into one (seg.hpp: seg_fold_factor).
 __host__ __device__ constexpr int seg_lo(int c, int N, int NCH) { return (int)((long)N * c / NCH); }
+constexpr int SEGW_FACTOR = 1, SEGW_BACK = 2, SEGW_FWD = 3, SEGW_ROWS_R = 5, SEGW_STEP = 6, SEGW_STEP_CS = 7, SEGW_EXIT = 9;   // commands to the helper waves (segw.hpp)
+constexpr int SEG_RP = 15;   // values per knot a wave leaves of its share of a row pass (segw.hpp: RowPartR, RowPartS)
 template <int MODEL, int NCH> struct SegB {
     static constexpr int n = MT<MODEL>::n, m = MT<MODEL>::m, NNp = (n * n + 1) & ~1, NPG = n * (n + m), NI = NCH - 1;
     // per interface: Ta', Sig, Pa = Ta Pc, A2 = Sig Pic, A3 = Ta Pic and the folded rear part's (Pc, Pic) -- the last chain's own sweep
@@ -390,12 +392,19 @@ template <int MODEL, int NCH> struct SegB {
     static constexpr int XI(int j) { return vec + 16 * j; }
     static constexpr int LAM(int j) { return vec + 16 * NI + 16 * j; }
     static constexpr int PBV(int c) { return vec + 32 * NI + 16 * (c - 1); }
-    // a helper wave's own [Phi Gam] double buffer and L^-1 scratch (its factor sweep runs beside the others'), the mailbox
-    static constexpr int hlp = vec + 48 * NI, HLB = 2 * NPG + 64;
+    // a helper wave's block: its own [Phi Gam] double buffer and L^-1 scratch in the factor sweep (which runs beside the others'),
+    // the partial sums of its share of the obstacle rows in the row passes (SEG_RP values per knot, [value][lane]); the mailbox
+    static constexpr int hlp = vec + 48 * NI, HLB = (2 * NPG + 64 > SEG_RP * 64) ? 2 * NPG + 64 : SEG_RP * 64;
     static constexpr int sPG2(int h) { return hlp + h * HLB; }
     static constexpr int Lw2(int h) { return hlp + h * HLB + 2 * NPG; }
-    static constexpr int MBX = hlp + NI * HLB, total = MBX + 8;
+    static constexpr int MBX = hlp + NI * HLB, total = MBX + 24;
 };
+// the obstacles of wave `rank` when `nshare` waves share a knot's obstacle rows (by obstacle index: bit i of the knot's active mask)
+__host__ __device__ constexpr unsigned long long seg_obs_share(int rank, int nshare) {
+    unsigned long long p = 0;
+    for (int i = rank; i < 64; i += (nshare > 0 ? nshare : 1)) p |= 1ull << i;
+    return p;
+}
 // where a knot's costate (and its control's feed-forward) takes its multiplier from: the costate increment of the interface behind its
 // chain, mu_g for the last chain (offset from the base of the dynamic LDS)
 template <int MODEL, int NCH> GD int seg_mult_off(int k, int N, int seg_base) {
@@ -502,7 +511,8 @@ struct Prof {
     // (a problem runs in several time slices under the scheduler: the first one overwrites, the others accumulate)
     GD void flush(long long* out, int b, bool cont = false) {
         if (out && threadIdx.x == 0)
-            for (int i = 0; i < PROF_N; i++) out[(size_t)b * PROF_N + i] = (cont ? out[(size_t)b * PROF_N + i] : 0) + acc[i];
+            for (int i = 0; i < PROF_N; i++)
+                if (i < 29 || i > 31) out[(size_t)b * PROF_N + i] = (cont ? out[(size_t)b * PROF_N + i] : 0) + acc[i];   // (29 .. 31: a helper wave's, segw.hpp)
     }
 #else
     GD void tick(int) {}

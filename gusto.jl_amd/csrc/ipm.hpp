@@ -2069,6 +2069,12 @@ template <int MODEL, class BLK, int NCH = 0> __device__ __noinline__ void mid_ph
 // The phase after the forward sweep of a right-hand side: primal step of this knot, the new costates, row steps and
 // the fraction to the boundary (before the workgroup reductions).  A function of its own for MT::SWEEP_CALL models.
 struct StepOut { double amax, c0, c1, c2; };
+#if GUSTO_SEG_W2   // (segw.hpp, included further down: the row passes below share a knot's obstacle rows with the helper waves)
+template <int MODEL, int NCH, class BLK> GD void segw_post_rows(BLK& K, int cmd, double a0, double kappa, double omega, double Delta, double mu_t, double tau);
+template <int MODEL, int NCH, class Op> GD void segw_rows_resid_add(const LPtr<double> L, int sb, int k, int nhelp, Op& op, double* Hx, double* rdx, double* gx0);
+template <int MODEL, int NCH, class Op> GD void segw_rows_step_add(const LPtr<double> L, int sb, int k, int h0, Op& op, double* gAx, double* gBx);
+GD void segw_join();
+#endif
 // x_1 stationarity, gx_0 + nu_0 + F_0^T nu_1 = 0: the costate of the first knot from the one behind it (ONE lane's work: lane 0 of
 // the step phase, or of the helper wave's costate pass)
 template <int MODEL, class BLK> GD void costate_close_x1(BLK& K, double hdt, const double* gxs) {
@@ -2091,13 +2097,13 @@ template <int MODEL, class BLK> GD void costate_close_x1(BLK& K, double hdt, con
         K.nun[i] = -s;
     }
 }
-template <int MODEL, class BLK, bool CLOSE = true>
+template <int MODEL, class BLK, bool CLOSE = true, int NCH = 0>
 GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int k, bool act, int pass, int ncomp, double hdt,
                       double tau, double mu_t, const double* mugn, const double* gxs) {
     using T = MT<MODEL>;
     using R = Rec<MODEL>;
     constexpr int n = T::n, m = T::m;
-    constexpr bool ADJ = costate_adjoint<MODEL>() && BLK::ONE;   // new costates by the adjoint recursion (adjoint_sweep_1w)
+    constexpr bool ADJ = costate_adjoint<MODEL>() && BLK::ONE && NCH == 0;   // new costates by the adjoint recursion (adjoint_sweep_1w; never with a wave per chain)
     bool adj_rt = false;   // ... unless the horizon is too coarse for it or the solve has run long (P | Pi records then)
     if constexpr (ADJ) adj_rt = costate_adjoint_now<MODEL>();
     const int N = K.N;
@@ -2176,6 +2182,20 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
         for (int i = 0; i < (ADJ ? n : 1); i++) hdx[i] = 0;
         OpStep<NP, RowState, ADJ> op{rs, dxs, dus, pass, mu_t, tau, gAx, gAu, gBx, gBu, &pre, hdx};
         ctx.tick(0);
+#if GUSTO_SEG_W2
+        if constexpr (NCH > 0) {
+            // the knot's obstacle rows shared with the helper waves (segw.hpp); a pass that ends with new costates gives helper 1 those
+            // instead.  (The step dxs / dus is in the workspace: the post drains this wave's stores.)
+            const bool cs = pass == 1 || ncomp == 0;
+            const int nshare = cs ? NCH - 1 : NCH;
+            segw_post_rows<MODEL, NCH>(K, cs ? SEGW_STEP_CS : SEGW_STEP, (double)pass, ctx.kappa, ctx.omega, ctx.Delta, mu_t, tau);
+            RowCtx<MODEL> cm = ctx;
+            cm.mask &= seg_obs_share(0, nshare);
+            visit_rows<MODEL>(cm, xs, us, op);
+            segw_join();
+            segw_rows_step_add<MODEL, NCH>(K.lds, K.P.ll.seg, k, cs ? 1 : 0, op, gAx, gBx);
+        } else
+#endif
         visit_rows<MODEL>(ctx, xs, us, op);
         ctx.tick(3);
         if constexpr (ADJ) {
@@ -2225,7 +2245,7 @@ GD void make_row_ctx(const BLK& K, int k, bool act, double kappa, double omega, 
     rs = RowState{K.rowstate, K.P.wl.nslot, K.N, act ? k : 0};
 }
 struct RowScal { double kappa, omega, Delta; };
-template <int MODEL, class BLK, bool CLOSE = true>
+template <int MODEL, class BLK, bool CLOSE = true, int NCH = 0>
 __device__ __noinline__ StepOut step_phase_call(typename BLK::Args a, RowScal sc, int k, bool act, int pass, int ncomp,
                                                 double hdt, double tau, double mu_t, Prof* pf) {
     BLK K(a, gusto_dyn_lds);
@@ -2236,15 +2256,15 @@ __device__ __noinline__ StepOut step_phase_call(typename BLK::Args a, RowScal sc
 #ifdef GUSTO_PROFILE
     ctx.pf = pf; ctx.pfb = PF_S0;
 #endif
-    return step_phase<MODEL, BLK, CLOSE>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, gusto_dyn_lds + C::misc + 48,
-                                         gusto_dyn_lds + C::misc + 16);
+    return step_phase<MODEL, BLK, CLOSE, NCH>(K, ctx, rs, k, act, pass, ncomp, hdt, tau, mu_t, gusto_dyn_lds + C::misc + 48,
+                                              gusto_dyn_lds + C::misc + 16);
 }
 
 // The residual phase of an interior point iteration: residuals, condensed Hessian blocks, dual residual, the predictor's
 // row sums and the LQR stage cost QQ_k of this knot (before the workgroup reductions).  A function of its own for
 // MT::SWEEP_CALL models.
 struct ResidOut { double resp, resd, comp, numax; };
-template <int MODEL, class BLK>
+template <int MODEL, class BLK, int NCH = 0>
 GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int k, bool act, double hdt, double wk,
                         double alpha_prev, const double* mug) {
     using T = MT<MODEL>;
@@ -2308,6 +2328,16 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
         constexpr bool LRTR = MODEL == GUSTO_ASTROBEE_SE3;   // (the manifold model has no trust region row)
         OpResidHess<n, m, NP, LRTR> op{rs, Hx, Hu, rdx, rdu, gx0, gu0, alpha_prev, &pre};
         ctx.tick(0);   // (profile builds: PF_R0.. = prologue | fixed rows | obstacle rows | control rows | stage cost)
+#if GUSTO_SEG_W2
+        if constexpr (NCH > 0) {   // the knot's obstacle rows shared with the helper waves (segw.hpp)
+            segw_post_rows<MODEL, NCH>(K, SEGW_ROWS_R, alpha_prev, ctx.kappa, ctx.omega, ctx.Delta, 0.0, 0.0);
+            RowCtx<MODEL> cm = ctx;
+            cm.mask &= seg_obs_share(0, NCH);
+            visit_rows<MODEL>(cm, xs, us, op);
+            segw_join();
+            segw_rows_resid_add<MODEL, NCH>(K.lds, K.P.ll.seg, k, NCH - 1, op, Hx, rdx, gx0);
+        } else
+#endif
         visit_rows<MODEL>(ctx, xs, us, op);
         ctx.tick(3);
         // row part of the predictor right-hand side, parked in the (currently free) step arrays
@@ -2446,7 +2476,7 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
     }
     return ResidOut{l_resp, l_resd, l_comp, l_numax};
 }
-template <int MODEL, class BLK>
+template <int MODEL, class BLK, int NCH = 0>
 __device__ __noinline__ ResidOut resid_phase_call(typename BLK::Args a, RowScal sc, int k, bool act, double hdt, double wk,
                                                   double alpha_prev, Prof* pf) {
     BLK K(a, gusto_dyn_lds);
@@ -2457,7 +2487,7 @@ __device__ __noinline__ ResidOut resid_phase_call(typename BLK::Args a, RowScal 
 #ifdef GUSTO_PROFILE
     ctx.pf = pf; ctx.pfb = PF_R0;
 #endif
-    return resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, gusto_dyn_lds + C::misc + 32);
+    return resid_phase<MODEL, BLK, NCH>(K, ctx, rs, k, act, hdt, wk, alpha_prev, gusto_dyn_lds + C::misc + 32);
 }
 
 // The KKT solve as Riccati segments joined by coarse LQR stages (round 6).  seg.hpp (-DGUSTO_SEG2=1, off): two chains interleaved
@@ -2595,7 +2625,7 @@ template <int MODEL, class BLK, int NCH = 0> GD void ipm_solve(BLK& K, double De
 #ifdef GUSTO_PROFILE
         ctx.pf = &pf; ctx.pfb = PF_R0;
 #endif
-        if constexpr (T::SWEEP_CALL) ro = resid_phase_call<MODEL, BLK>(K.args(), RowScal{kappa, omega, Delta}, k, act, hdt, wk, alpha_prev, &pf);
+        if constexpr (T::SWEEP_CALL) ro = resid_phase_call<MODEL, BLK, (SEGB ? NCH : 0)>(K.args(), RowScal{kappa, omega, Delta}, k, act, hdt, wk, alpha_prev, &pf);
         else ro = resid_phase<MODEL>(K, ctx, rs, k, act, hdt, wk, alpha_prev, mug);
         const double l_resp = ro.resp, l_resd = ro.resd, l_comp = ro.comp, l_numax = ro.numax;
         res_p = block_reduce<BLK::ONE>(l_resp, OpNanMax(), red);
@@ -2754,6 +2784,7 @@ template <int MODEL, class BLK, int NCH = 0> GD void ipm_solve(BLK& K, double De
             if constexpr (SEGB) {
                 if (pass == 0) {   // the fold of this factorisation is done
                     segw_join();
+                    pf.tick(PF_POSTF);   // (the wait for it)
                     if (*fail != 0.0) { seg_fail = true; break; }
                 }
                 segw_post<MODEL, NCH>(K, SEGW_BACK); backward_sweep_seg_call<MODEL, NCH>(K.args()); segw_join();
@@ -2799,12 +2830,9 @@ template <int MODEL, class BLK, int NCH = 0> GD void ipm_solve(BLK& K, double De
             ctx.pf = &pf; ctx.pfb = PF_S0;
 #endif
 #if GUSTO_SEG_W2
-            if constexpr (SEGB) {   // the new costates (P | Pi records) on a helper wave, beside the step phase
-                const bool cs = pass == 1 || ncomp == 0;
-                if (cs) segw_post<MODEL, NCH>(K, SEGW_COSTATE);
-                so = step_phase_call<MODEL, BLK, false>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
-                if (cs) segw_join();
-            } else
+            if constexpr (SEGB)   // (the helper waves take obstacle rows and, in the pass that ends with them, the new costates: step_phase)
+                so = step_phase_call<MODEL, BLK, false, NCH>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
+            else
 #endif
             if constexpr (T::SWEEP_CALL) so = step_phase_call<MODEL, BLK>(K.args(), RowScal{kappa, omega, Delta}, k, act, pass, ncomp, hdt, tau, mu_t, &pf);
             else {

@@ -82,6 +82,42 @@ GD void lin_row(Op& op, int slot, int kind, const double* v, const double* b, do
     op.template row<ISU, I0, CNT, FX>(slot, kind, ev);
 }
 
+// ncsi_*_obstacle_avoidance_*_convexified (freeflyer_se2.jl:265-288): clearance - (d + nhat.(r - r0)), the rows of the obstacles in
+// `mk` (the knot's active set, or one wave's share of it: segw.hpp).
+// The rows of one knot are walked in batches of OBS_BATCH: every load of a batch (normal, offset AND the row state
+// the Op needs, Op::obs_load) is issued before the first row of the batch is processed.  One row at a time, each
+// row's loads wait behind the stores of the row before it and a pass pays one memory round trip per active
+// obstacle (3-8 per knot for the freeflyer table, 15-25 in the ISS corner) -- four passes per interior point
+// iteration.  Lanes with fewer rows left aim the spare positions at their last row and skip them.
+template <int MODEL, class Op> GD void visit_obs_rows(const RowCtx<MODEL>& c, const double* xs, Op& op, uint64_t mk) {
+    using T = MT<MODEL>;
+    const double kw = c.kappa * c.omega;
+    const int slot_obs = T::NFIX;
+    while (mk) {
+        int oi[OBS_BATCH], oslot[OBS_BATCH];
+        bool ov[OBS_BATCH];
+        int last = 0;
+#pragma unroll
+        for (int q = 0; q < OBS_BATCH; q++) {
+            ov[q] = mk != 0;
+            if (ov[q]) { last = __ffsll((unsigned long long)mk) - 1; mk &= mk - 1; }
+            oi[q] = last; oslot[q] = slot_obs + last;
+        }
+        double ob[OBS_BATCH][T::WS], oc[OBS_BATCH];
+#pragma unroll
+        for (int q = 0; q < OBS_BATCH; q++) {
+#pragma unroll
+            for (int j = 0; j < T::WS; j++) ob[q][j] = -(c.obs_nh + (size_t)(oi[q] * T::WS + j) * (size_t)c.N)[c.k];
+            oc[q] = (c.obs_c0 + (size_t)oi[q] * (size_t)c.N)[c.k];
+        }
+        op.obs_load(oslot);
+        static_for<0, OBS_BATCH>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            if (ov[q]) lin_row<false, 0, T::WS, FX_OBS + q>(op, oslot[q], ROW_PEN, xs, ob[q], oc[q], kw, 0.0);
+        });
+    }
+}
+
 // ---- the row programs ------------------------------------------------------------------------------
 template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const double* xs, const double* us, Op& op) {
     using T = MT<MODEL>;
@@ -226,37 +262,8 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
         // csi_translational_velocity_bound / csi_angular_velocity_bound (freeflyer_se2.jl:225-233)
         quad_row<false, 3, nv, GUSTO_FXB(T::NFIX - 2, T::NFIX - 2)>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_vel * mp.hard_limit_vel, kw, 0.0);
         quad_row<false, iw, nw, GUSTO_FXB(T::NFIX - 1, T::NFIX - 1)>(op, slot++, ROW_PEN, xs, one, nullptr, -mp.hard_limit_omega * mp.hard_limit_omega, kw, 0.0);
-        // ncsi_*_obstacle_avoidance_*_convexified (freeflyer_se2.jl:265-288): clearance - (d + nhat.(r - r0))
-        // The rows of one knot are walked in batches of OBS_BATCH: every load of a batch (normal, offset AND the row state
-        // the Op needs, Op::obs_load) is issued before the first row of the batch is processed.  One row at a time, each
-        // row's loads wait behind the stores of the row before it and a pass pays one memory round trip per active
-        // obstacle (3-8 per knot for the freeflyer table, 15-25 in the ISS corner) -- four passes per interior point
-        // iteration.  Lanes with fewer rows left aim the spare positions at their last row and skip them.
-        c.tick(1);   // fixed state rows
-        uint64_t mk = c.mask;
-        while (mk) {
-            int oi[OBS_BATCH], oslot[OBS_BATCH];
-            bool ov[OBS_BATCH];
-            int last = 0;
-#pragma unroll
-            for (int q = 0; q < OBS_BATCH; q++) {
-                ov[q] = mk != 0;
-                if (ov[q]) { last = __ffsll((unsigned long long)mk) - 1; mk &= mk - 1; }
-                oi[q] = last; oslot[q] = slot_obs + last;
-            }
-            double ob[OBS_BATCH][T::WS], oc[OBS_BATCH];
-#pragma unroll
-            for (int q = 0; q < OBS_BATCH; q++) {
-#pragma unroll
-                for (int j = 0; j < T::WS; j++) ob[q][j] = -(c.obs_nh + (size_t)(oi[q] * T::WS + j) * (size_t)c.N)[c.k];
-                oc[q] = (c.obs_c0 + (size_t)oi[q] * (size_t)c.N)[c.k];
-            }
-            op.obs_load(oslot);
-            static_for<0, OBS_BATCH>([&](auto Q) {
-                constexpr int q = decltype(Q)::value;
-                if (ov[q]) lin_row<false, 0, T::WS, FX_OBS + q>(op, oslot[q], ROW_PEN, xs, ob[q], oc[q], kw, 0.0);
-            });
-        }
+        c.tick(1);   // fixed state rows; then the obstacle rows (visit_obs_rows)
+        visit_obs_rows<MODEL>(c, xs, op, c.mask);
         c.tick(2);   // obstacle rows
         if (c.k < c.N - 1) {  // cci_*_accel_bound on k = 1..N-1 only (freeflyer_se2.jl:236-245,380-381)
             constexpr int nf = is2 ? 2 : 3, im = is2 ? 2 : 3, nm = is2 ? 1 : 3;

@@ -85,6 +85,9 @@ template <int MODEL, bool ONEWAVE, int NCH = 0> GD int scp_problem(const KParams
     Blk<MODEL, ONEWAVE> K(P, lds, b_, slot);
     Prof pf;
     const int b = K.b, tid = K.tid, N = K.N, k = tid;
+#ifdef GUSTO_PROFILE
+    if (NCH > 0 && !cont && tid < 3 && P.prof) P.prof[(size_t)b * PROF_N + 29 + tid] = 0;
+#endif
     double* Xg = P.X + (size_t)b * N * n;
     double* Ug = P.U + (size_t)b * N * m;
 

@@ -26,8 +26,12 @@
 //   BACK     every wave its chain's backward vector sweep; join.  The main wave's mid phase then folds the vectors, gets mu_g and
 //            every interface's (xi, dlam)
 //   FWD      every wave its chain's forward sweep; join
-//   COSTATE  helper 1: the new costates of all knots from the P | Pi records (record seg_lo(c) - 1 = (0 | I): nu behind an interface
-//            = lam0 + dlam falls out of the same formula) and the first knot's closing equation, beside the main wave's step phase; join
+//   ROWS_R   the residual pass: every wave 1 / NCH of each knot's obstacle rows (15 - 25 of a knot's ~30 rows in the ISS corner), the
+//            main wave the other rows as well; join; the main wave adds the helpers' partial sums (segw_rows_*)
+//   STEP     the step pass of the predictor, likewise
+//   STEP_CS  the step pass that ends with new costates: helper 1 computes them for all knots from the P | Pi records (record
+//            seg_lo(c) - 1 = (0 | I): nu behind an interface = lam0 + dlam falls out of the same formula) with the first knot's
+//            closing equation, the OTHER waves share the obstacle rows; join
 // A command is a word in LDS and two workgroup barriers (post: the main wave has drained what the helpers read; join: everybody has
 // drained its stores); the phases themselves stay barrier-free one-wave code on disjoint knots and LDS.
 #pragma once
@@ -314,10 +318,11 @@ template <int MODEL, int NCH> GD void costate_pass_seg(SweepView<MODEL> K) {
 }
 
 // ---- commands ---------------------------------------------------------------------------------------------------------------
-constexpr int SEGW_FACTOR = 1, SEGW_BACK = 2, SEGW_FWD = 3, SEGW_COSTATE = 4, SEGW_EXIT = 9;
+// (the command words: common.hpp, SEGW_*)
 GD void segw_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 GD void segw_join() { segw_barrier(); }
-// mailbox: [0] the command, [2..6] what a helper needs to rebuild the problem's view (written once per interior point solve)
+// mailbox: [0] the command, [2..6] what a helper needs to rebuild the problem's view (written once per interior point solve),
+// [8..13] the scalars of a row pass: alpha_prev | pass, kappa, omega, Delta, mu_t, tau
 template <int MODEL, int NCH, class BLK> GD void segw_open(BLK& K) {
     const LPtr<double> L = K.lds;
     const int mb = K.P.ll.seg + SegB<MODEL, NCH>::MBX;
@@ -331,10 +336,120 @@ template <int MODEL, int NCH, class BLK> GD void segw_post(BLK& K, int cmd) {
     if (K.tid == 0) L[K.P.ll.seg + SegB<MODEL, NCH>::MBX] = (double)cmd;
     segw_barrier();
 }
+template <int MODEL, int NCH, class BLK>
+GD void segw_post_rows(BLK& K, int cmd, double a0, double kappa, double omega, double Delta, double mu_t, double tau) {
+    const LPtr<double> L = K.lds;
+    const int mb = K.P.ll.seg + SegB<MODEL, NCH>::MBX;
+    if (K.tid == 0) {
+        L[mb] = (double)cmd;
+        L[mb + 8] = a0; L[mb + 9] = kappa; L[mb + 10] = omega; L[mb + 11] = Delta; L[mb + 12] = mu_t; L[mb + 13] = tau;
+    }
+    segw_barrier();
+}
 // kernel exit of the main wave: release the helpers for good (no join: a wave that has ended is not waited for)
 GD void segw_exit(double* lds, int mbx) {
     if ((threadIdx.x & 63) == 0) lds[mbx] = (double)SEGW_EXIT;
     segw_barrier();
+}
+
+// ---- a knot's obstacle rows shared between the waves ------------------------------------------------------------------------------
+// An obstacle row touches the position coordinates only (window 0 .. WS - 1): what a wave's share contributes to the knot's sums is
+// SEG_RP numbers, left in the wave's LDS block as [value][lane] and added by the main wave in the order of the waves.
+//   residual pass: comp, max |r_p|, r_dx[WS], gx0[WS], the upper triangle of H_x on the window
+//   step pass:     the step-length fraction (an, ad), c0 c1 c2, gA_x[WS], gB_x[WS]
+template <int MODEL, int NCH> GD void segw_rows_resid_helper(Blk<MODEL, true>& B, int hi, int rank, int nshare) {
+    using T = MT<MODEL>;
+    using SB = SegB<MODEL, NCH>;
+    constexpr int n = T::n, m = T::m, WS = T::WS, NHX = n * (n + 1) / 2;
+    static_assert(2 + 2 * WS + WS * (WS + 1) / 2 <= SEG_RP && 5 + 2 * WS <= SEG_RP, "row partials");
+    const LPtr<double> L = B.lds;
+    const int sb = B.P.ll.seg, mb = sb + SB::MBX, k = B.tid;
+    const bool act = k < B.N;
+    const double alpha_prev = L[mb + 8], kappa = L[mb + 9], omega = L[mb + 10], Delta = L[mb + 11];
+    RowCtx<MODEL> ctx;
+    RowState rs;
+    make_row_ctx<MODEL>(B, k, act, kappa, omega, Delta, ctx, rs);
+    double xs[n], Hx[NHX], Hu[1] = {0}, rdx[n], rdu[1] = {0}, gx0[n], gu0[1] = {0};
+#pragma unroll
+    for (int i = 0; i < n; i++) { xs[i] = act ? B.Xw[k * n + i] : 0.0; rdx[i] = 0; gx0[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < NHX; i++) Hx[i] = 0;
+    RowPre<0> pre;
+    OpResidHess<n, m, 0, false> op{rs, Hx, Hu, rdx, rdu, gx0, gu0, alpha_prev, &pre};
+    visit_obs_rows<MODEL>(ctx, xs, op, ctx.mask & seg_obs_share(rank, nshare));
+    const int o = sb + SB::sPG2(hi) + k;
+    L[o] = op.comp; L[o + 64] = op.maxrp;
+    int v = 2;
+#pragma unroll
+    for (int a = 0; a < WS; a++) { L[o + 64 * v] = rdx[a]; L[o + 64 * (v + WS)] = gx0[a]; v++; }
+    v += WS;
+#pragma unroll
+    for (int a = 0; a < WS; a++)
+#pragma unroll
+        for (int b = a; b < WS; b++) { L[o + 64 * v] = Hx[sidx(a, b, n)]; v++; }
+}
+template <int MODEL, int NCH, class Op> GD void segw_rows_resid_add(const LPtr<double> L, int sb, int k, int nhelp, Op& op, double* Hx, double* rdx, double* gx0) {
+    using T = MT<MODEL>;
+    using SB = SegB<MODEL, NCH>;
+    constexpr int n = T::n, WS = T::WS;
+#pragma unroll
+    for (int hi = 0; hi < NCH - 1; hi++) {
+        if (hi < nhelp) {
+            const int o = sb + SB::sPG2(hi) + k;
+            op.comp += L[o]; op.maxrp = nanmax(op.maxrp, L[o + 64]);
+            int v = 2;
+#pragma unroll
+            for (int a = 0; a < WS; a++) { rdx[a] += L[o + 64 * v]; gx0[a] += L[o + 64 * (v + WS)]; v++; }
+            v += WS;
+#pragma unroll
+            for (int a = 0; a < WS; a++)
+#pragma unroll
+                for (int b = a; b < WS; b++) { Hx[sidx(a, b, n)] += L[o + 64 * v]; v++; }
+        }
+    }
+}
+// (cs: helper 1 is busy with the costates -- the sharers are the main wave and the helpers behind it)
+template <int MODEL, int NCH> GD void segw_rows_step_helper(Blk<MODEL, true>& B, int hi, int rank, int nshare) {
+    using T = MT<MODEL>;
+    using SB = SegB<MODEL, NCH>;
+    constexpr int n = T::n, WS = T::WS;
+    const LPtr<double> L = B.lds;
+    const int sb = B.P.ll.seg, mb = sb + SB::MBX, k = B.tid;
+    const bool act = k < B.N;
+    const int pass = (int)L[mb + 8];
+    const double kappa = L[mb + 9], omega = L[mb + 10], Delta = L[mb + 11], mu_t = L[mb + 12], tau = L[mb + 13];
+    RowCtx<MODEL> ctx;
+    RowState rs;
+    make_row_ctx<MODEL>(B, k, act, kappa, omega, Delta, ctx, rs);
+    double xs[n], dxs[n], dus[1] = {0}, gAx[n], gBx[n], gAu[1] = {0}, gBu[1] = {0};
+#pragma unroll
+    for (int i = 0; i < n; i++) { xs[i] = act ? B.Xw[k * n + i] : 0.0; gAx[i] = 0; gBx[i] = 0; dxs[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < WS; i++) dxs[i] = act ? B.dXs[k * n + i] : 0.0;   // (the main wave's step phase has stored the primal step)
+    RowPre<0> pre;
+    OpStep<0, RowState, false> op{rs, dxs, dus, pass, mu_t, tau, gAx, gAu, gBx, gBu, &pre, nullptr};
+    visit_obs_rows<MODEL>(ctx, xs, op, ctx.mask & seg_obs_share(rank, nshare));
+    const int o = sb + SB::sPG2(hi) + k;
+    L[o] = op.amax.an; L[o + 64] = op.amax.ad; L[o + 128] = op.c0; L[o + 192] = op.c1; L[o + 256] = op.c2;
+#pragma unroll
+    for (int a = 0; a < WS; a++) { L[o + 64 * (5 + a)] = gAx[a]; L[o + 64 * (5 + WS + a)] = gBx[a]; }
+}
+template <int MODEL, int NCH, class Op> GD void segw_rows_step_add(const LPtr<double> L, int sb, int k, int h0, Op& op, double* gAx, double* gBx) {
+    using T = MT<MODEL>;
+    using SB = SegB<MODEL, NCH>;
+    constexpr int WS = T::WS;
+#pragma unroll
+    for (int hi = 0; hi < NCH - 1; hi++) {
+        if (hi >= h0) {
+            const int o = sb + SB::sPG2(hi) + k;
+            const double an = L[o], ad = L[o + 64];
+            const bool take = an * op.amax.ad < op.amax.an * ad;   // (StepFrac::test: both denominators are positive)
+            op.amax.an = take ? an : op.amax.an; op.amax.ad = take ? ad : op.amax.ad;
+            op.c0 += L[o + 128]; op.c1 += L[o + 192]; op.c2 += L[o + 256];
+#pragma unroll
+            for (int a = 0; a < WS; a++) { gAx[a] += L[o + 64 * (5 + a)]; gBx[a] += L[o + 64 * (5 + WS + a)]; }
+        }
+    }
 }
 
 // one chain's share of the three sequential phases (c = NCH - 1: the main wave's, as called phases below)
@@ -387,18 +502,44 @@ template <int MODEL, int NCH> GD void segw_helper(const KParams& P, double* lds)
             if (cmd == SEGW_FACTOR) {
                 SweepView<MODEL> K = SweepView<MODEL>::make(B);
                 K.sPG = lds + sb + SB::sPG2(0) + c * SB::HLB; K.sHh = lds + sb + SB::Lw2(0) + c * SB::HLB;   // its own operand buffers
+#ifdef GUSTO_PROFILE   // (slots 29 .. 31, helper 1: its factor sweep, its wait at the join, the fold)
+                const long long t0 = clock64();
+#endif
                 seg_chain_factor<MODEL, NCH>(K, c, fail, pfd);
+#ifdef GUSTO_PROFILE
+                const long long t1 = clock64();
+#endif
                 segw_barrier();
+#ifdef GUSTO_PROFILE
+                const long long t2 = clock64();
+#endif
                 if (h == 1) seg_fold_factor<MODEL, NCH>(B, fail);
+#ifdef GUSTO_PROFILE
+                if (h == 1 && B.tid == 0 && P.prof) {
+                    const long long t3 = clock64();
+                    long long* o = P.prof + (size_t)B.b * PROF_N;
+                    o[29] += t1 - t0; o[31] += t3 - t2;
+                }
+#endif
             } else if (cmd == SEGW_BACK) {
+#ifdef GUSTO_PROFILE
+                const long long t0 = clock64();
+#endif
                 seg_chain_backward<MODEL, NCH>(B, c);
+#ifdef GUSTO_PROFILE
+                if (h == 1 && B.tid == 0 && P.prof) P.prof[(size_t)B.b * PROF_N + 30] += clock64() - t0;   // (slot 30: helper 1's backward sweeps)
+#endif
             } else if (cmd == SEGW_FWD) {
                 seg_chain_forward<MODEL, NCH>(B, c);
-            } else if (cmd == SEGW_COSTATE) {
+            } else if (cmd == SEGW_ROWS_R) {
+                segw_rows_resid_helper<MODEL, NCH>(B, c, h, NCH);
+            } else if (cmd == SEGW_STEP) {
+                segw_rows_step_helper<MODEL, NCH>(B, c, h, NCH);
+            } else if (cmd == SEGW_STEP_CS) {
                 if (h == 1) {
                     costate_pass_seg<MODEL, NCH>(SweepView<MODEL>::make(B));
                     if (B.tid == 0) costate_close_x1<MODEL>(B, 0.5 * B.dt, lds + C::misc + 16);
-                }
+                } else segw_rows_step_helper<MODEL, NCH>(B, c, h - 1, NCH - 1);
             }
             segw_barrier();
             asm volatile("s_barrier" ::: "memory");

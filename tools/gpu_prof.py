@@ -23,7 +23,7 @@ print(f"B={B} kernel {s.last_solve_ms():.1f} ms conv {st['converged'].sum()} tra
 prof = np.zeros((B, 48), dtype=np.int64)
 s.L.gusto_dev_get_prof.argtypes = [C.c_void_p, C.c_void_p]
 rc = s.L.gusto_dev_get_prof(s.h, prof.ctypes.data)
-names = ["RESID","BUILD","FACTOR","POSTF","RHS","BACK","MID","FWD","STEP","UPDATE","LIN","SCP","INIT","F:pre","F:AB","F:CD","F1:H","F2:Z","F3:r","F4:chol","F5:ld","F6:solve","F7:store","F8","M:th","M:reduce","M:mu+sync","M:dk/ct","M:sync2","-","-","-"]
+names = ["RESID","BUILD","FACTOR","POSTF","RHS","BACK","MID","FWD","STEP","UPDATE","LIN","SCP","INIT","F:pre","F:AB","F:CD","F1:H","F2:Z","F3:r","F4:chol","F5:ld","F6:solve","F7:store","F8","M:th","M:reduce","M:mu+sync","M:dk/ct","M:sync2","H1:sweep","H1:back","H1:fold"]
 names += ["R:prolog", "R:fixrows", "R:obsrows", "R:ctlrows", "S:prolog", "S:fixrows", "S:obsrows", "S:ctlrows",
           "FX:lds-ops", "FX:T", "FX:H,Z", "FX:Linv-lds", "FX:W,V", "FX:P'..S", "FX:Phicl", "-"]
 names[0] = "R:stagecost"; names[8] = "S:tail+red"; names[16] = "F1(+S:tail p0)"
