@@ -2187,10 +2187,9 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
             // the knot's obstacle rows shared with the helper waves (segw.hpp); a pass that ends with new costates gives helper 1 those
             // instead.  (The step dxs / dus is in the workspace: the post drains this wave's stores.)
             const bool cs = pass == 1 || ncomp == 0;
-            const int nshare = cs ? NCH - 1 : NCH;
             segw_post_rows<MODEL, NCH>(K, cs ? SEGW_STEP_CS : SEGW_STEP, (double)pass, ctx.kappa, ctx.omega, ctx.Delta, mu_t, tau);
             RowCtx<MODEL> cm = ctx;
-            cm.mask &= seg_obs_share(0, nshare);
+            if (!(cs && NCH == 2)) cm.mask = 0;   // (the helpers take all obstacle rows -- unless the only one is busy with the costates)
             visit_rows<MODEL>(cm, xs, us, op);
             segw_join();
             segw_rows_step_add<MODEL, NCH>(K.lds, K.P.ll.seg, k, cs ? 1 : 0, op, gAx, gBx);
@@ -2332,7 +2331,7 @@ GD ResidOut resid_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, in
         if constexpr (NCH > 0) {   // the knot's obstacle rows shared with the helper waves (segw.hpp)
             segw_post_rows<MODEL, NCH>(K, SEGW_ROWS_R, alpha_prev, ctx.kappa, ctx.omega, ctx.Delta, 0.0, 0.0);
             RowCtx<MODEL> cm = ctx;
-            cm.mask &= seg_obs_share(0, NCH);
+            cm.mask = 0;   // (the helpers take all obstacle rows)
             visit_rows<MODEL>(cm, xs, us, op);
             segw_join();
             segw_rows_resid_add<MODEL, NCH>(K.lds, K.P.ll.seg, k, NCH - 1, op, Hx, rdx, gx0);

@@ -26,12 +26,12 @@
 //   BACK     every wave its chain's backward vector sweep; join.  The main wave's mid phase then folds the vectors, gets mu_g and
 //            every interface's (xi, dlam)
 //   FWD      every wave its chain's forward sweep; join
-//   ROWS_R   the residual pass: every wave 1 / NCH of each knot's obstacle rows (15 - 25 of a knot's ~30 rows in the ISS corner), the
-//            main wave the other rows as well; join; the main wave adds the helpers' partial sums (segw_rows_*)
+//   ROWS_R   the residual pass: the helpers share each knot's obstacle rows (15 - 25 of a knot's ~30 rows in the ISS corner), the main
+//            wave has the other rows and the stage cost; join; the main wave adds the helpers' partial sums (segw_rows_*)
 //   STEP     the step pass of the predictor, likewise
 //   STEP_CS  the step pass that ends with new costates: helper 1 computes them for all knots from the P | Pi records (record
 //            seg_lo(c) - 1 = (0 | I): nu behind an interface = lam0 + dlam falls out of the same formula) with the first knot's
-//            closing equation, the OTHER waves share the obstacle rows; join
+//            closing equation, the other helpers share the obstacle rows (two waves: the main wave keeps them); join
 // A command is a word in LDS and two workgroup barriers (post: the main wave has drained what the helpers read; join: everybody has
 // drained its stores); the phases themselves stay barrier-free one-wave code on disjoint knots and LDS.
 #pragma once
@@ -531,15 +531,15 @@ template <int MODEL, int NCH> GD void segw_helper(const KParams& P, double* lds)
 #endif
             } else if (cmd == SEGW_FWD) {
                 seg_chain_forward<MODEL, NCH>(B, c);
-            } else if (cmd == SEGW_ROWS_R) {
-                segw_rows_resid_helper<MODEL, NCH>(B, c, h, NCH);
+            } else if (cmd == SEGW_ROWS_R) {         // (the helpers take ALL obstacle rows: the main wave has the other rows and the stage cost)
+                segw_rows_resid_helper<MODEL, NCH>(B, c, h - 1, NCH - 1);
             } else if (cmd == SEGW_STEP) {
-                segw_rows_step_helper<MODEL, NCH>(B, c, h, NCH);
+                segw_rows_step_helper<MODEL, NCH>(B, c, h - 1, NCH - 1);
             } else if (cmd == SEGW_STEP_CS) {
                 if (h == 1) {
                     costate_pass_seg<MODEL, NCH>(SweepView<MODEL>::make(B));
                     if (B.tid == 0) costate_close_x1<MODEL>(B, 0.5 * B.dt, lds + C::misc + 16);
-                } else segw_rows_step_helper<MODEL, NCH>(B, c, h - 1, NCH - 1);
+                } else segw_rows_step_helper<MODEL, NCH>(B, c, h - 2, NCH - 2);
             }
             segw_barrier();
             asm volatile("s_barrier" ::: "memory");
