@@ -2189,10 +2189,11 @@ GD StepOut step_phase(BLK& K, const RowCtx<MODEL>& ctx, const RowState& rs, int 
             const bool cs = pass == 1 || ncomp == 0;
             segw_post_rows<MODEL, NCH>(K, cs ? SEGW_STEP_CS : SEGW_STEP, (double)pass, ctx.kappa, ctx.omega, ctx.Delta, mu_t, tau);
             RowCtx<MODEL> cm = ctx;
-            if (!(cs && NCH == 2)) cm.mask = 0;   // (the helpers take all obstacle rows -- unless the only one is busy with the costates)
+            // (the helpers take all obstacle rows -- unless the only one has the costates first: then half of them stay here)
+            cm.mask = (cs && NCH == 2) ? (cm.mask & seg_obs_share(0, 2)) : 0;
             visit_rows<MODEL>(cm, xs, us, op);
             segw_join();
-            segw_rows_step_add<MODEL, NCH>(K.lds, K.P.ll.seg, k, cs ? 1 : 0, op, gAx, gBx);
+            segw_rows_step_add<MODEL, NCH>(K.lds, K.P.ll.seg, k, (cs && NCH > 2) ? 1 : 0, op, gAx, gBx);
         } else
 #endif
         visit_rows<MODEL>(ctx, xs, us, op);

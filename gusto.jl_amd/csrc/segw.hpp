@@ -31,7 +31,7 @@
 //   STEP     the step pass of the predictor, likewise
 //   STEP_CS  the step pass that ends with new costates: helper 1 computes them for all knots from the P | Pi records (record
 //            seg_lo(c) - 1 = (0 | I): nu behind an interface = lam0 + dlam falls out of the same formula) with the first knot's
-//            closing equation, the other helpers share the obstacle rows (two waves: the main wave keeps them); join
+//            closing equation, the other helpers share the obstacle rows (two waves: helper and main wave take half of them each); join
 // A command is a word in LDS and two workgroup barriers (post: the main wave has drained what the helpers read; join: everybody has
 // drained its stores); the phases themselves stay barrier-free one-wave code on disjoint knots and LDS.
 #pragma once
@@ -539,6 +539,7 @@ template <int MODEL, int NCH> GD void segw_helper(const KParams& P, double* lds)
                 if (h == 1) {
                     costate_pass_seg<MODEL, NCH>(SweepView<MODEL>::make(B));
                     if (B.tid == 0) costate_close_x1<MODEL>(B, 0.5 * B.dt, lds + C::misc + 16);
+                    if constexpr (NCH == 2) segw_rows_step_helper<MODEL, NCH>(B, c, 1, 2);   // (the only helper: then half of the obstacle rows)
                 } else segw_rows_step_helper<MODEL, NCH>(B, c, h - 2, NCH - 2);
             }
             segw_barrier();
