@@ -195,7 +195,8 @@ class GustoError(RuntimeError):
 
 class BatchSolver:
     """Thin owner of one gusto_handle: a batch of SCP problems of one model on one GPU."""
-    # gusto_set_decomposition applied to every new dubins_car handle (0 = the library's choice); the lane-kernel tests set it
+    # gusto_set_decomposition applied to every new handle of the models it means something for (0 = the library's choice); tests set
+    # it: 2 (a lane per problem) reaches dubins_car handles, 1 / 3 / 4 (one / two / four waves per problem) the 12/13-state models
     default_decomposition = 0
 
     def __init__(self, model, N, batch_cap, hist_cap=64, device=0, boxes=None, spheres=None, scp_params=None,
@@ -215,8 +216,9 @@ class BatchSolver:
                                               C.byref(model_params) if model_params is not None else None), "set_params")
         if ipm_opts is not None:
             self._chk(self.L.gusto_set_ipm_opts(self.h, C.byref(ipm_opts)), "set_ipm_opts")
-        if BatchSolver.default_decomposition and model == DUBINS_CAR and type(self) is BatchSolver:
-            self.set_decomposition(BatchSolver.default_decomposition)
+        if BatchSolver.default_decomposition and type(self) is BatchSolver:
+            if (model == DUBINS_CAR) if BatchSolver.default_decomposition == 2 else (model in (ASTROBEE_SE3, ASTROBEE_SE3_MANIFOLD)):
+                self.set_decomposition(BatchSolver.default_decomposition)
         self.set_env(boxes, spheres)
 
     def _create(self, model, N, batch_cap, hist_cap, device):
@@ -278,7 +280,8 @@ class BatchSolver:
                                                None if W is None else W.ctypes.data), "set_trust_state")
 
     def set_decomposition(self, decomposition):
-        """0 auto, 1 a wave per problem, 2 a lane per problem (dubins_car; gusto_hip.h: gusto_set_decomposition)."""
+        """0 auto, 1 one wave per problem, 2 a lane per problem (dubins_car, -DGUSTO_WITH_LANE builds), 3 / 4 two / four waves per
+        problem (astrobeeSE3, astrobeeSE3manifold: csrc/segw.hpp); gusto_hip.h: gusto_set_decomposition."""
         self._chk(self.L.gusto_set_decomposition(self.h, int(decomposition)), "set_decomposition")
 
     def set_schedule(self, probe_iters=2, min_batch=2048):

@@ -204,7 +204,7 @@ int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch) {
 }
 
 int gusto_set_decomposition(gusto_handle h, int decomposition) {
-    if (!h || decomposition < GUSTO_DECOMP_AUTO || decomposition > GUSTO_DECOMP_LANE) return GUSTO_ERR_ARG;
+    if (!h || decomposition < GUSTO_DECOMP_AUTO || decomposition > GUSTO_DECOMP_WAVE4) return GUSTO_ERR_ARG;
     { int rc = setter_enter(h); if (rc) return rc; }
     // (a lane per problem exists for the models without obstacle rows -- dubins_car; the others keep their wave per problem)
 #ifndef GUSTO_WITH_LANE

@@ -84,22 +84,31 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     const bool masked = mode == 0 && h->n_active >= 0;    // gusto_set_active: only the listed problems are handed out
     if (masked) P.n_fresh = h->n_active;
     int NTL = NT;
+    const bool want_chains = h->decomposition == GUSTO_DECOMP_WAVE2 || h->decomposition == GUSTO_DECOMP_WAVE4;
+    bool have_chains = false;
 #if GUSTO_SEG_W2
     // a batch that leaves SIMDs without a wave runs several waves per problem, the KKT solve's sequential phases as Riccati segments
-    // side by side (scp_kernel_w2, segw.hpp): four waves while every problem has a CU of its own, two up to the batch size where
-    // the one-wave kernel's three problems per CU win (measured: astrobeeSE3 4096, astrobeeSE3manifold 2048 .. 4096)
+    // side by side and the obstacle rows shared (scp_kernel_w2, segw.hpp): four waves up to two problems per CU, two up to the batch
+    // size where the one-wave kernel's three problems per CU win (measured: astrobeeSE3 4096 .. 8192, astrobeeSE3manifold 2048 .. 4096)
     if constexpr (seg2_big<MODEL>()) {
         int nch = 0;
-        if (NT == 64 && P.n_fresh <= cus && h->N >= 4 * GUSTO_SEG_MIN_N) nch = 4;
+        if (NT == 64 && P.n_fresh <= 2 * cus && h->N >= 4 * GUSTO_SEG_MIN_N) nch = 4;
         else if (NT == 64 && P.n_fresh <= 8 * cus && h->N >= 2 * GUSTO_SEG_MIN_N) nch = 2;
+        if (h->decomposition == GUSTO_DECOMP_WAVE) nch = 0;
+        if (want_chains) { nch = (h->decomposition == GUSTO_DECOMP_WAVE4) ? 4 : 2; if (NT != 64 || h->N < nch * GUSTO_SEG_MIN_N) nch = 0; }
         if (const char* e = dev_env("GUSTO_DEV_W2")) { nch = atoi(e); if (nch == 1) nch = 2; if ((nch != 2 && nch != 4) || NT != 64 || h->N < nch * GUSTO_SEG_MIN_N) nch = 0; }
         if (nch) {
             P.ll = make_lds_layout<MODEL>(h->N, false, nch);
             lds = (size_t)P.ll.total * sizeof(double);
             kern = (nch == 4) ? &scp_kernel_w2<MODEL, 4> : &scp_kernel_w2<MODEL, 2>; NTL = 64 * nch;
+            have_chains = true;
         }
     }
 #endif
+    if (want_chains && !have_chains) {
+        h->err = "GUSTO_DECOMP_WAVE2 / WAVE4: no such kernel for this model, horizon or waves-per-problem setting";
+        return GUSTO_ERR_ARG;
+    }
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // Persistent launch: as many workgroups as the GPU keeps resident (slots), each with its own workspace
     HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NTL, lds));

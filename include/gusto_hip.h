@@ -140,8 +140,14 @@ int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch);
  * idle and spends its time on 3 x 3 blocks); other models ignore the setting.  AUTO (default) = WAVE: as measured on MI355X
  * the LANE kernel is correct (same trips, statuses and trajectories to 1e-12) but slower at the BASELINE batch sizes, because a
  * wavefront runs as long as the longest of its 64 problems.  The scheduler of gusto_set_schedule belongs
- * to the WAVE kernel. */
-enum { GUSTO_DECOMP_AUTO = 0, GUSTO_DECOMP_WAVE = 1, GUSTO_DECOMP_LANE = 2 };
+ * to the WAVE kernel.
+ * WAVE2 / WAVE4 (round 6; astrobeeSE3 and astrobeeSE3manifold, N <= 64): two or four wavefronts per problem -- the horizon split into
+ * as many Riccati chains, a wave each, joined by coarse LQR stages, and each knot's obstacle rows shared between the waves
+ * (csrc/segw.hpp).  For batches that leave SIMDs without a wave: AUTO takes WAVE4 up to two problems per CU, WAVE2 up to eight,
+ * one wave per problem beyond (measured on MI355X); WAVE forces one wave per problem.  Same subproblems to the same tolerances;
+ * the iterates differ in rounding (the KKT solve is reassociated), the SCP iteration counts do not on the test batches.  A model
+ * or horizon without these kernels answers GUSTO_ERR_ARG at gusto_solve. */
+enum { GUSTO_DECOMP_AUTO = 0, GUSTO_DECOMP_WAVE = 1, GUSTO_DECOMP_LANE = 2, GUSTO_DECOMP_WAVE2 = 3, GUSTO_DECOMP_WAVE4 = 4 };
 int gusto_set_decomposition(gusto_handle h, int decomposition);
 /* run on a caller-owned hipStream_t (NULL = a new stream owned by the handle).  Like every setter it first completes
  * a pending gusto_solve_async on the stream that solve was enqueued on. */
