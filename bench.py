@@ -325,6 +325,37 @@ def other_configs(P, g, torch, dev_ord, steps=3, warmup=1, live=True):
         }
     except Exception as e:
         out["trajopt"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    # ... and the shards ONE GPU holds of the 8-GPU configurations (BASELINE.json configs[3] / [4]: 8192 / 8 and 2048 / 8 problems),
+    # which leave SIMDs without a wave: kernel time with one, two and four waves per problem (gusto_set_decomposition,
+    # csrc/segw.hpp) and as the library chooses
+    try:
+        for cfg, B in ((4, 1024), (5, 256)):
+            c = CONFIGS[cfg]
+            model, boxes, spheres, (x0, glo, ghi, tf) = workload(P, g, cfg, B, 0)
+            dv = [torch.from_numpy(a).to(torch.device("cuda", dev_ord)) for a in (x0, glo, ghi, tf)]
+            e = {"workload": f"{c['name'].split(' batch=')[0]} batch={B} (one GPU's shard of the 8-GPU configuration), N={c['N']}", "problems": B,
+                 "unit": "ms, HIP-event kernel time of one launch"}
+            for name, dec in (("one_wave", 1), ("two_waves", 3), ("four_waves", 4), ("auto", 0)):
+                s = g.BatchSolver(model, c["N"], B, hist_cap=MAX_ITER + 34, device=dev_ord, boxes=boxes, spheres=spheres)
+                s.set_decomposition(dec)
+                ms = []
+                for i in range(warmup + steps):
+                    s.set_problems_dev(B, *[d.data_ptr() for d in dv])
+                    s.solve_async(MAX_ITER)
+                    s.wait()
+                    if i >= warmup:
+                        ms.append(s.last_solve_ms())
+                st = s.status()
+                e[name + "_ms"] = float(np.mean(ms))
+                if dec == 0:
+                    e["converged"] = int(st["converged"].sum())
+                    e["value"] = e["converged"] / (e["auto_ms"] * 1e-3)
+                    e["value_unit"] = "converged trajectories/s (kernel time, auto)"
+                    e["workgroup_lds_bytes_auto"] = int(s.launch_info()[1])
+                s.close()
+            out[f"{cfg}_shard"] = e
+    except Exception as e:
+        out["shards"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return out
 
 

@@ -1887,15 +1887,30 @@ template <int MODEL, class BLK, int NCH = 0> GD void mid_phase(BLK& K, int k, bo
         const LPtr<double> L = K.lds;
         const int sb = K.P.ll.seg;
         const int ri = K.tid < n ? K.tid : 0;
-        int ck = 0;
+        // theta per chain (the last chain's with the goal terms).  Through LDS -- helper 1's block is idle here --: lane (c, j) adds entry
+        // j of chain c's knots, then the NCH n sums travel by v_readlane.  (As NCH n masked values through wave_reduce_n this was
+        // 52 x 23 DPP / readlane instructions for four chains: 4.8 k cycles per solve; now ~1 k.)
+        double r[NCH * n];
+        {
+            constexpr int MAXL = (64 + NCH - 1) / NCH + 1;   // knots of a chain at most (N <= 64)
+            const int tb = sb + SB::sPG2(0);
+            if (act) {
 #pragma unroll
-        for (int c = 1; c < NCH; c++) ck += (k >= seg_lo(c, N, NCH)) ? 1 : 0;
-        double r[NCH * n];   // theta per chain (the last chain's with the goal terms)
+                for (int j = 0; j < n; j++) L[tb + k * n + j] = th[j];
+            }
+            K.sync();
+            const int t = K.tid < NCH * n ? K.tid : NCH * n - 1, tc = t / n, tj = t % n;
+            const int k0 = seg_lo(tc, N, NCH), k1 = seg_lo(tc + 1, N, NCH);
+            double v[MAXL];
 #pragma unroll
-        for (int c = 0; c < NCH; c++)
+            for (int q = 0; q < MAXL; q++) v[q] = L[tb + ((k0 + q < k1) ? k0 + q : k0) * n + tj];
+            __builtin_amdgcn_sched_barrier(0);
+            double s = 0;
 #pragma unroll
-            for (int j = 0; j < n; j++) r[c * n + j] = (ck == c) ? th[j] : 0.0;
-        wave_reduce_n<NCH * n>(r, OpSum());
+            for (int q = 0; q < MAXL; q++) s += (k0 + q < k1) ? v[q] : 0.0;
+#pragma unroll
+            for (int e = 0; e < NCH * n; e++) r[e] = readlane_f64(s, e);
+        }
         MT_(PF_M_RED);
         auto row = [&](int o, double* v) {
 #pragma unroll
