@@ -1930,62 +1930,95 @@ template <int MODEL, class BLK, int NCH = 0> GD void mid_phase(BLK& K, int k, bo
             for (int l = 0; l < n; l++) s += a[l] * x[l];
             return s;
         };
-        // p_hat of interface j = the costate offset in front of what lies behind it, seen from the costate iterate lam0 there
-        double pcU[n], thcU[n], uD[NI > 1 ? NI : 1], wD[NI > 1 ? NI : 1];
+        // p_hat of an interface = the costate offset in front of what lies behind it, seen from the costate iterate lam0 there
+        auto lam0 = [&](int j, const double* pc, double* ph) {
+            const int o = seg_lo(j + 1, N, NCH) * n;
 #pragma unroll
-        for (int l = 0; l < n; l++) { pcU[l] = L[sb + SB::PBV(NI) + l]; thcU[l] = r[NI * n + l]; }
-        static_for<1, NI>([&](auto JJ) {   // fold the vectors from the back: interfaces NI - 1 .. 1
-            constexpr int j = NI - decltype(JJ)::value;
-            const int I = sb + SB::IF(j), lam0 = seg_lo(j + 1, N, NCH) * n;
-            double ph[n], rT[n], rS[n], rP[n], cT[n], cPi[n], rPj[n];
-            row(I + SB::Tt, rT); row(I + SB::Sg, rS); row(I + SB::Pa, rP); col(I + SB::Tt, cT);
-            col(I + SB::PIc, cPi); row(sb + SB::CH(j) + SB::Pif, rPj);
+            for (int l = 0; l < n; l++) ph[l] = pc[l] - K.nu[o + l];
+        };
+        auto ufrom = [&](int o, double* v) {
 #pragma unroll
-            for (int l = 0; l < n; l++) ph[l] = pcU[l] - K.nu[lam0 + l];
-            const double pfj = L[sb + SB::PBV(j) + ri];
-            __builtin_amdgcn_sched_barrier(0);
-            const double u = dot(rT, r + j * n) - dot(rS, ph), w = dot(rP, r + j * n) + dot(cT, ph);
-            uD[j] = u; wD[j] = w;
-            double uU[n], wU[n];
-            bcast(u, uU); bcast(w, wU);
-            double te = 0;   // (thcU is the same in every lane: this lane's entry of it)
+            for (int l = 0; l < n; l++) v[l] = L[o + l];
+        };
+        auto pick = [&](const double* vU) {   // this lane's entry of a vector every lane holds
+            double e = 0;
 #pragma unroll
-            for (int l = 0; l < n; l++) te = (ri == l) ? thcU[l] : te;
-            const double thn = te + dot(cPi, uU), pcn = pfj + dot(rPj, wU);
-            bcast(thn, thcU); bcast(pcn, pcU);
-        });
-        double xiv, dlv, mu;
-        double muU[n];
-        {   // the first interface: mu_g, then its state and costate increment
-            const int I = sb + SB::IF(0), lam0 = seg_lo(1, N, NCH) * n;
-            double ph[n], rT[n], rS[n], rP[n], cT[n], rG[n], rA1[n], rA2[n], rA3[n];
+            for (int l = 0; l < n; l++) e = (ri == l) ? vU[l] : e;
+            return e;
+        };
+        if constexpr (NCH == 2) {   // one interface: mu_g, then its state and costate increment
+            const int I = sb + SB::IF(0);
+            double pf1[n], ph[n], rT[n], rS[n], rP[n], cT[n], rG[n], rA1[n], rA2[n], rA3[n];
             row(I + SB::Tt, rT); row(I + SB::Sg, rS); row(I + SB::Pa, rP); col(I + SB::Tt, cT);
             row(sb + SB::Gci, rG); row(sb + SB::A1, rA1); row(I + SB::A2, rA2); row(I + SB::A3, rA3);
-#pragma unroll
-            for (int l = 0; l < n; l++) ph[l] = pcU[l] - K.nu[lam0 + l];
+            ufrom(sb + SB::PBV(1), pf1);
+            lam0(0, pf1, ph);
             __builtin_amdgcn_sched_barrier(0);
             const double w1 = dot(rT, r) - dot(rS, ph), v3 = dot(rP, r) + dot(cT, ph);
-            double w1U[n];
+            double w1U[n], muU[n];
             bcast(w1, w1U);
-            mu = dot(rG, thcU) + dot(rA1, w1U);
+            double mu = dot(rG, r + n) + dot(rA1, w1U);
             mu = K.is_goal(ri) ? mu : 0.0;
             bcast(mu, muU);
-            xiv = w1 - dot(rA2, muU); dlv = v3 + dot(rA3, muU);
+            const double xiv = w1 - dot(rA2, muU), dlv = v3 + dot(rA3, muU);
             if (K.tid < n) { mugn[K.tid] = mu; L[sb + SB::XI(0) + K.tid] = xiv; L[sb + SB::LAM(0) + K.tid] = dlv; }
+        } else {
+            // four chains, merged as a tree (segw.hpp: seg_fold_tree_*): (C0 | C1) and (C2 | C3), then the pairs at interface 1
+            static_assert(NCH == 4, "two or four chains");
+            const int I0 = sb + SB::IF(0), I1 = sb + SB::IF(1), I2 = sb + SB::IF(2), C1 = sb + SB::CH(1), C2 = sb + SB::CH(2);
+            double u0, w0, u2, w2, u0U[n], u2U[n], w2U[n];
+            {   // the two outer interfaces, each from its own chains' vectors
+                double pfa[n], pfb[n], ph0[n], ph2[n], rT[n], rS[n], rP[n], cT[n], rT2[n], rS2[n], rP2[n], cT2[n];
+                row(I0 + SB::Tt, rT); row(I0 + SB::Sg, rS); row(I0 + SB::Pa, rP); col(I0 + SB::Tt, cT);
+                row(I2 + SB::Tt, rT2); row(I2 + SB::Sg, rS2); row(I2 + SB::Pa, rP2); col(I2 + SB::Tt, cT2);
+                ufrom(sb + SB::PBV(1), pfa); ufrom(sb + SB::PBV(3), pfb);
+                lam0(0, pfa, ph0); lam0(2, pfb, ph2);
+                __builtin_amdgcn_sched_barrier(0);
+                u0 = dot(rT, r) - dot(rS, ph0); w0 = dot(rP, r) + dot(cT, ph0);
+                u2 = dot(rT2, r + 2 * n) - dot(rS2, ph2); w2 = dot(rP2, r + 2 * n) + dot(cT2, ph2);
+                bcast(u0, u0U); bcast(u2, u2U); bcast(w2, w2U);
+            }
+            double th01U[n], th23U[n], p23U[n];
+            {   // the pairs: theta of (C0 C1), theta and front costate offset of (C2 C3)
+                double cP1[n], cP3[n], rP2_[n];
+                col(C1 + SB::Pif, cP1); col(I2 + SB::PIc, cP3); row(C2 + SB::Pif, rP2_);
+                const double pf2 = L[sb + SB::PBV(2) + ri];
+                __builtin_amdgcn_sched_barrier(0);
+                const double th01 = pick(r + n) + dot(cP1, u0U), th23 = pick(r + 3 * n) + dot(cP3, u2U), p23 = pf2 + dot(rP2_, w2U);
+                bcast(th01, th01U); bcast(th23, th23U); bcast(p23, p23U);
+            }
+            double xi1, dl1, muU[n], xi1U[n], dl1U[n];
+            {   // interface 1: mu_g, its state and costate increment
+                double ph1[n], rT[n], rS[n], rP[n], cT[n], rG[n], rA1[n], rA2[n], rA3[n];
+                row(I1 + SB::Tt, rT); row(I1 + SB::Sg, rS); row(I1 + SB::Pa, rP); col(I1 + SB::Tt, cT);
+                row(sb + SB::Gci, rG); row(sb + SB::A1, rA1); row(I1 + SB::A2, rA2); row(I1 + SB::A3, rA3);
+                lam0(1, p23U, ph1);
+                __builtin_amdgcn_sched_barrier(0);
+                const double w1 = dot(rT, th01U) - dot(rS, ph1), v3 = dot(rP, th01U) + dot(cT, ph1);
+                double w1U[n];
+                bcast(w1, w1U);
+                double mu = dot(rG, th23U) + dot(rA1, w1U);
+                mu = K.is_goal(ri) ? mu : 0.0;
+                bcast(mu, muU);
+                xi1 = w1 - dot(rA2, muU); dl1 = v3 + dot(rA3, muU);
+                if (K.tid < n) { mugn[K.tid] = mu; L[sb + SB::XI(1) + K.tid] = xi1; L[sb + SB::LAM(1) + K.tid] = dl1; }
+                bcast(xi1, xi1U); bcast(dl1, dl1U);
+            }
+            {   // the outer interfaces: 0 hangs on interface 1's multiplier, 2 on its state and on mu_g
+                double rA2[n], rA3[n], cP2[n], rT[n], rP[n], rB2[n], rB3[n], zU[n];
+                row(I0 + SB::A2, rA2); row(I0 + SB::A3, rA3); col(C2 + SB::Pif, cP2);
+                row(I2 + SB::Tt, rT); row(I2 + SB::Pa, rP); row(I2 + SB::A2, rB2); row(I2 + SB::A3, rB3);
+                __builtin_amdgcn_sched_barrier(0);
+                const double xi0 = u0 - dot(rA2, dl1U), dl0 = w0 + dot(rA3, dl1U);
+                const double z = dot(cP2, xi1U);    // Pi_2' xi_1
+                bcast(z, zU);
+                const double xi2 = u2 + dot(rT, zU) - dot(rB2, muU), dl2 = w2 + dot(rP, zU) + dot(rB3, muU);
+                if (K.tid < n) {
+                    L[sb + SB::XI(0) + K.tid] = xi0; L[sb + SB::LAM(0) + K.tid] = dl0;
+                    L[sb + SB::XI(2) + K.tid] = xi2; L[sb + SB::LAM(2) + K.tid] = dl2;
+                }
+            }
         }
-        static_for<1, NI>([&](auto JJ) {   // the other interfaces, front to back: y = the state at the interface in front
-            constexpr int j = decltype(JJ)::value;
-            const int I = sb + SB::IF(j);
-            double cPj[n], rT[n], rP[n], rA2[n], rA3[n], xiU[n], zU[n];
-            col(sb + SB::CH(j) + SB::Pif, cPj); row(I + SB::Tt, rT); row(I + SB::Pa, rP); row(I + SB::A2, rA2); row(I + SB::A3, rA3);
-            __builtin_amdgcn_sched_barrier(0);
-            bcast(xiv, xiU);
-            const double z = dot(cPj, xiU);    // Pi_j' xi_{j-1}
-            bcast(z, zU);
-            xiv = uD[j] + dot(rT, zU) - dot(rA2, muU);
-            dlv = wD[j] + dot(rP, zU) + dot(rA3, muU);
-            if (K.tid < n) { L[sb + SB::XI(j) + K.tid] = xiv; L[sb + SB::LAM(j) + K.tid] = dlv; }
-        });
     } else
     if constexpr (BLK::ONE) {
         if (K.goalmask != 0) wave_reduce_n<n>(th, OpSum());

@@ -422,6 +422,7 @@ template <int MODEL, int NCH> __global__ void __launch_bounds__(64 * NCH, 1) scp
 #endif
     if constexpr (seg2_big<MODEL>()) {
         if (threadIdx.x >= 64) { segw_helper<MODEL, NCH>(P, lds); return; }
+        if constexpr (NCH == 4) { if (threadIdx.x == 0) *seg_tree_flag<MODEL>(lds, P.ll.seg) = 0; }   // (read after the first command's barriers)
         scp_kernel_body<MODEL, true, NCH>(P, lds);
         segw_exit(lds, P.ll.seg + SegB<MODEL, NCH>::MBX);
     }

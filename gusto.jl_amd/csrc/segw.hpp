@@ -15,14 +15,13 @@
 //       interface:  xi = Ta' (Pi_A' y + th_A) - Sig (ph + Pi_B lam'),   dlam = Pa (Pi_A' y + th_A) + Ta (ph + Pi_B lam')
 // -- products only, no inverse of a compliance (a chain may have an uncontrollable direction), and no output is a difference of large
 // terms.  lam0 = the CURRENT costate iterate at the interface: the chain in front starts its backward vector sweep from it, so every
-// coarse quantity vanishes with the Newton step.  The chains are FOLDED from the back (interface j joins chain j to the fold of the
-// chains j + 1 .. NCH - 1; the terminal multiplier lam' of every fold is the goal multiplier mu_g), then the interfaces are resolved
-// front to back.  Prototype, run against the oracle's sequential recursion with 2 and 4 chains: tools/proto/segriccati.c,
+// coarse quantity vanishes with the Newton step.  Four chains are merged as a tree, (C0 | C1) and (C2 | C3) side by side and then
+// the two pairs; the interfaces are resolved from the middle one outwards.  Prototype (its chains folded from the back one by one), run against the oracle's sequential recursion with 2 and 4 chains: tools/proto/segriccati.c,
 // profiles/r06_segmented_riccati_proto.txt.  Reference path: the convex subproblem of scp_gusto.jl:104,178-314 (JuMP.optimize!).
 //
 // Who runs what (wave 0 = MAIN: the one-wave program, and the last chain; wave h >= 1 = helper, chain h - 1):
-//   FACTOR   every wave its chain's factor sweep; join; helper 1 folds the chains' matrices (seg_fold_factor) while the main wave
-//            builds the predictor's right-hand side; join
+//   FACTOR   every wave its chain's factor sweep; join; helper 1 (four chains: and helper 3) merges the chains' matrices (seg_merge)
+//            while the main wave builds the predictor's right-hand side; join
 //   BACK     every wave its chain's backward vector sweep; join.  The main wave's mid phase then folds the vectors, gets mu_g and
 //            every interface's (xi, dlam)
 //   FWD      every wave its chain's forward sweep; join
@@ -98,15 +97,15 @@ template <int n> struct MMTile {
     }
 };
 
-// The matrices of the coarse stages, chains folded from the back (one wave; sGd enters as the last chain's Gd and leaves as the goal
-// Hessian of the whole horizon, its inverse -> sP -> SegB::Gci by inv_spd_block).
-template <int MODEL, int NCH, class BLK> GD void seg_fold_factor(BLK& K, double* fail) {
+// One merge of the matrices (one wave): the chain(s) in front of an interface, compliance Gd_A at LDS offset `Gdf`, with what lies
+// behind it, (P, Pi) at `Pc`, `PIc` and Gd at `GdB`.  Leaves the interface's Ta', Sig, Pa, A2, A3 in the block `I` and the merged
+// Gd = Gd_B + Pi_B' Sig Pi_B IN PLACE of Gd_B; X1 is n x n scratch.  Returns false on a zero / non-finite pivot.
+template <int MODEL, int NCH, class BLK> GD bool seg_merge(BLK& K, int I, int Gdf, int Pc, int PIc, int GdB, int X1) {
     using SB = SegB<MODEL, NCH>;
     constexpr int n = SB::n, NN = n * n, RN = (NN + 63) / 64;
     static_assert(n <= 16, "one MFMA tile");
     const LPtr<double> L = K.lds;
-    const int tid = K.tid, sb = K.P.ll.seg;
-    const int oGd = LdsC<MODEL, true>::sGd, oSP = LdsC<MODEL, true>::sP;
+    const int tid = K.tid;
     MMTile<n> T(K.lds, tid);
     const v4d Z = {0, 0, 0, 0};
     int ei[RN], ej[RN];
@@ -114,67 +113,100 @@ template <int MODEL, int NCH, class BLK> GD void seg_fold_factor(BLK& K, double*
 #pragma unroll
     for (int r = 0; r < RN; r++) { const int e = tid + 64 * r; on[r] = e < NN; ei[r] = on[r] ? e / n : 0; ej[r] = on[r] ? e % n : 0; }
     bool ok = true;
-    const int X1 = sb + SB::X1, X2 = sb + SB::X2;
+    // X = I + P_B Gd_A -> X1, inverted in place by Gauss-Jordan without pivoting (X = I + (PSD)(PSD): eigenvalues >= 1)
+    T.put(X1, T.mm(T.A(Pc), T.B(Gdf), T.eye()));
+    K.sync();
+    for (int c = 0; c < n; c++) {
+        const double piv = L[X1 + c * n + c];
+        if (!(fabs(piv) > 0.0) || !isfinite(piv)) ok = false;
+        const double d = rcp_nr(piv);
+        double wij[RN], wcj[RN], wic[RN], w[RN];
 #pragma unroll
-    for (int j = NCH - 2; j >= 0; j--) {
-        const int I = sb + SB::IF(j), Pc = I + SB::Pc, PIc = I + SB::PIc, Gdf = sb + SB::CH(j) + SB::Gdf;
-        // X = I + Pc Gd_j -> X1, inverted in place by Gauss-Jordan without pivoting (X = I + (PSD)(PSD): eigenvalues >= 1)
-        T.put(X1, T.mm(T.A(Pc), T.B(Gdf), T.eye()));
-        K.sync();
-        for (int c = 0; c < n; c++) {
-            const double piv = L[X1 + c * n + c];
-            if (!(fabs(piv) > 0.0) || !isfinite(piv)) ok = false;
-            const double d = rcp_nr(piv);
-            double wij[RN], wcj[RN], wic[RN], w[RN];
+        for (int r = 0; r < RN; r++) { wij[r] = L[X1 + ei[r] * n + ej[r]]; wcj[r] = L[X1 + c * n + ej[r]]; wic[r] = L[X1 + ei[r] * n + c]; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < RN; r++) { wij[r] = L[X1 + ei[r] * n + ej[r]]; wcj[r] = L[X1 + c * n + ej[r]]; wic[r] = L[X1 + ei[r] * n + c]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < RN; r++) {
-                const int i = ei[r], jj = ej[r];
-                const double rowc = (jj == c) ? d : wcj[r] * d;
-                const double other = (jj == c) ? -(wic[r] * d) : wij[r] - wic[r] * (wcj[r] * d);
-                w[r] = (i == c) ? rowc : other;
-            }
-            K.sync();
-#pragma unroll
-            for (int r = 0; r < RN; r++) if (on[r]) L[X1 + ei[r] * n + ej[r]] = w[r];
-            K.sync();
-        }
-        // X1 = Ta:  Tt = Ta', Sig = Gd_j Ta (both triangles from one mean: the transpose comes from the transposed product, the same
-        // terms in the same order), Pa = Ta Pc, A3 = Ta Pic
-        {
-            const auto aG = T.A(Gdf), bX = T.B(X1), aXt = T.A(X1, true), bGt = T.B(Gdf, true), aX = T.A(X1), bP = T.B(Pc), bPi = T.B(PIc);
-            const v4d ta = T.C(X1);
-            const v4d s1 = T.mm(aG, bX, Z), s2 = T.mm(aXt, bGt, Z), pa = T.mm(aX, bP, Z), a3 = T.mm(aX, bPi, Z);
-            v4d sg;
-#pragma unroll
-            for (int q = 0; q < 4; q++) sg[q] = 0.5 * (s1[q] + s2[q]);
-            T.put(I + SB::Tt, ta, true); T.put(I + SB::Sg, sg); T.put(I + SB::Pa, pa); T.put(I + SB::A3, a3);
+        for (int r = 0; r < RN; r++) {
+            const int i = ei[r], jj = ej[r];
+            const double rowc = (jj == c) ? d : wcj[r] * d;
+            const double other = (jj == c) ? -(wic[r] * d) : wij[r] - wic[r] * (wcj[r] * d);
+            w[r] = (i == c) ? rowc : other;
         }
         K.sync();
-        T.put(I + SB::A2, T.mm(T.A(I + SB::Sg), T.B(PIc), Z));                 // A2 = Sig Pic
-        K.sync();
-        T.put(oGd, T.mm(T.A(PIc, true), T.B(I + SB::A2), T.C(oGd)));           // Gd += Pic' A2
-        if (j > 0) {   // the fold of the chains j .. NCH - 1, seen from interface j - 1
-            const int Pj = sb + SB::CH(j) + SB::Pf, PIj = sb + SB::CH(j) + SB::Pif, In = sb + SB::IF(j > 0 ? j - 1 : 0);
-            const auto aPi = T.A(PIj);
-            T.put(X2, T.mm(aPi, T.B(I + SB::Pa), Z));                          // Pi_j Pa
-            T.put(In + SB::PIc, T.mm(aPi, T.B(I + SB::A3), Z));                // Pic' = Pi_j Ta Pic
-            K.sync();
-            T.put(In + SB::Pc, T.mm(T.A(X2), T.B(PIj, true), T.C(Pj)));        // Pc' = P_j + Pi_j Pa Pi_j'
-        }
+#pragma unroll
+        for (int r = 0; r < RN; r++) if (on[r]) L[X1 + ei[r] * n + ej[r]] = w[r];
         K.sync();
     }
+    // X1 = Ta:  Tt = Ta', Sig = Gd_A Ta (both triangles from one mean: the transpose comes from the transposed product, the same
+    // terms in the same order), Pa = Ta P_B, A3 = Ta Pi_B
+    {
+        const auto aG = T.A(Gdf), bX = T.B(X1), aXt = T.A(X1, true), bGt = T.B(Gdf, true), aX = T.A(X1), bP = T.B(Pc), bPi = T.B(PIc);
+        const v4d ta = T.C(X1);
+        const v4d s1 = T.mm(aG, bX, Z), s2 = T.mm(aXt, bGt, Z), pa = T.mm(aX, bP, Z), a3 = T.mm(aX, bPi, Z);
+        v4d sg;
+#pragma unroll
+        for (int q = 0; q < 4; q++) sg[q] = 0.5 * (s1[q] + s2[q]);
+        T.put(I + SB::Tt, ta, true); T.put(I + SB::Sg, sg); T.put(I + SB::Pa, pa); T.put(I + SB::A3, a3);
+    }
+    K.sync();
+    T.put(I + SB::A2, T.mm(T.A(I + SB::Sg), T.B(PIc), Z));                 // A2 = Sig Pi_B
+    K.sync();
+    T.put(GdB, T.mm(T.A(PIc, true), T.B(I + SB::A2), T.C(GdB)));           // Gd_B += Pi_B' A2
+    K.sync();
+    return ok;
+}
+// ... and the merged chain's P = P_A + Pi_A Pa Pi_A', Pi = Pi_A Ta Pi_B (the interface block `I` holds Pa, A3 = Ta Pi_B): -> oP, oPi
+template <int MODEL, int NCH, class BLK> GD void seg_merge_front(BLK& K, int I, int Pj, int PIj, int oP, int oPi, int X2) {
+    using SB = SegB<MODEL, NCH>;
+    MMTile<SB::n> T(K.lds, K.tid);
+    const v4d Z = {0, 0, 0, 0};
+    const auto aPi = T.A(PIj);
+    T.put(X2, T.mm(aPi, T.B(I + SB::Pa), Z));                              // Pi_A Pa
+    T.put(oPi, T.mm(aPi, T.B(I + SB::A3), Z));
+    K.sync();
+    T.put(oP, T.mm(T.A(X2), T.B(PIj, true), T.C(Pj)));
+    K.sync();
+}
+// the goal Hessian of the whole horizon is in sGd: its inverse (inv_spd_block: sGd -> sP) -> Gci, and A1 = Gci Pi' with the Pi behind
+// the interface that carries mu_g
+template <int MODEL, int NCH, class BLK> GD void seg_fold_finish(BLK& K, double* fail, int PIc) {
+    using SB = SegB<MODEL, NCH>;
+    const int sb = K.P.ll.seg, oSP = LdsC<MODEL, true>::sP;
+    MMTile<SB::n> T(K.lds, K.tid);
+    const v4d Z = {0, 0, 0, 0};
     inv_spd_block<MODEL>(K, fail);
     K.sync();
-    {
-        const v4d gi = T.C(oSP);
-        T.put(sb + SB::Gci, gi);
-        T.put(sb + SB::A1, T.mm(T.A(oSP), T.B(sb + SB::IF(0) + SB::PIc, true), Z));   // A1 = Gdc^-1 Pic'
-    }
-    if (!ok) *fail = 1.0;
+    const v4d gi = T.C(oSP);
+    T.put(sb + SB::Gci, gi);
+    T.put(sb + SB::A1, T.mm(T.A(oSP), T.B(PIc, true), Z));
     K.sync();
+}
+// two chains: the one merge (helper 1)
+template <int MODEL, class BLK> GD void seg_fold_factor2(BLK& K, double* fail) {
+    using SB = SegB<MODEL, 2>;
+    const int sb = K.P.ll.seg, I = sb + SB::IF(0);
+    if (!seg_merge<MODEL, 2>(K, I, sb + SB::CH(0) + SB::Gdf, I + SB::Pc, I + SB::PIc, LdsC<MODEL, true>::sGd, sb + SB::X1)) *fail = 1.0;
+    seg_fold_finish<MODEL, 2>(K, fail, I + SB::PIc);
+}
+// four chains, merged as a TREE: (C0 | C1) on helper 1 and (C2 | C3) on helper 3 side by side, then (C0 C1 | C2 C3) on helper 1 --
+// the multiplier behind interfaces 1 and 2 is mu_g, the one behind interface 0 is interface 1's.  The two helpers meet through a
+// sequence number in LDS (workgroup barriers belong to the main wave's commands).
+template <int MODEL> GD int* seg_tree_flag(double* lds, int sb) { return reinterpret_cast<int*>(lds + sb + SegB<MODEL, 4>::MBX + 16); }
+template <int MODEL, class BLK> GD void seg_fold_tree_rear(BLK& K, double* fail, int seq) {      // helper 3 (chain 2's wave)
+    using SB = SegB<MODEL, 4>;
+    const int sb = K.P.ll.seg, I = sb + SB::IF(2), In = sb + SB::IF(1), scr = sb + SB::sPG2(2);   // (its own block is idle: scratch)
+    if (!seg_merge<MODEL, 4>(K, I, sb + SB::CH(2) + SB::Gdf, I + SB::Pc, I + SB::PIc, LdsC<MODEL, true>::sGd, scr)) *fail = 1.0;
+    seg_merge_front<MODEL, 4>(K, I, sb + SB::CH(2) + SB::Pf, sb + SB::CH(2) + SB::Pif, In + SB::Pc, In + SB::PIc, scr + SB::NNp);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (K.tid == 0) __hip_atomic_store(seg_tree_flag<MODEL>(K.lds, sb), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int MODEL, class BLK> GD void seg_fold_tree_front(BLK& K, double* fail, int seq) {     // helper 1 (chain 0's wave)
+    using SB = SegB<MODEL, 4>;
+    const int sb = K.P.ll.seg, I0 = sb + SB::IF(0), I1 = sb + SB::IF(1), C1 = sb + SB::CH(1);
+    if (!seg_merge<MODEL, 4>(K, I0, sb + SB::CH(0) + SB::Gdf, C1 + SB::Pf, C1 + SB::Pif, C1 + SB::Gdf, sb + SB::X1)) *fail = 1.0;   // Gd_1 -> Gd_01
+    while (__hip_atomic_load(seg_tree_flag<MODEL>(K.lds, sb), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (!seg_merge<MODEL, 4>(K, I1, C1 + SB::Gdf, I1 + SB::Pc, I1 + SB::PIc, LdsC<MODEL, true>::sGd, sb + SB::X1)) *fail = 1.0;
+    seg_fold_finish<MODEL, 4>(K, fail, I1 + SB::PIc);
 }
 
 // ---- the ring-buffered one-wave vector sweeps of ipm.hpp over a RANGE of knots (operands from the global Phicl records) ----
@@ -479,15 +511,52 @@ template <int MODEL, int NCH, class BLK> GD void seg_chain_forward(const BLK& B,
     forward_sweep_ring_rng<MODEL>(B, lo, c == NCH - 1 ? hi : hi - 1, c == 0 ? -1 : B.P.ll.seg + SB::XI(c > 0 ? c - 1 : 0));
 }
 
-// The helper wave h = 1 .. NCH - 1 (chain h - 1).  Its view of the problem (some 45 base pointers, scalar loads from the kernel
-// arguments) is rebuilt when the problem changes, not per command: it sat on the critical path of every phase.
-template <int MODEL, int NCH> GD void segw_helper(const KParams& P, double* lds) {
+// The helper wave h = 1 .. NCH - 1 (chain h - 1).  What it runs are real calls, like the main wave's phases: inlined into the kernel
+// they shared its register allocation (1300 spilled SGPRs, 320 VGPRs) and every piece added there slowed the sweeps of all helpers.
+template <int MODEL, int NCH> __device__ __noinline__ void segw_h_factor_call(typename Blk<MODEL, true>::Args a, int c) {
+    using SB = SegB<MODEL, NCH>;
+    Blk<MODEL, true> B(a, gusto_dyn_lds);
+    SweepView<MODEL> K = SweepView<MODEL>::make(B);
+    const int sb = B.P.ll.seg;
+    K.sPG = gusto_dyn_lds + sb + SB::sPG2(0) + c * SB::HLB; K.sHh = gusto_dyn_lds + sb + SB::Lw2(0) + c * SB::HLB;   // its own operand buffers
+    Prof pfd;
+    seg_chain_factor<MODEL, NCH>(K, c, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, pfd);
+}
+template <int MODEL, int NCH> __device__ __noinline__ void segw_h_fold_call(typename Blk<MODEL, true>::Args a, int h, int seq) {
+    Blk<MODEL, true> B(a, gusto_dyn_lds);
+    double* fail = gusto_dyn_lds + LdsC<MODEL, true>::misc + 8;
+    if constexpr (NCH == 2) seg_fold_factor2<MODEL>(B, fail);
+    else if (h == 3) seg_fold_tree_rear<MODEL>(B, fail, seq);
+    else seg_fold_tree_front<MODEL>(B, fail, seq);
+}
+template <int MODEL, int NCH> __device__ __noinline__ void segw_h_back_call(typename Blk<MODEL, true>::Args a, int c) {
+    Blk<MODEL, true> B(a, gusto_dyn_lds);
+    seg_chain_backward<MODEL, NCH>(B, c);
+}
+template <int MODEL, int NCH> __device__ __noinline__ void segw_h_fwd_call(typename Blk<MODEL, true>::Args a, int c) {
+    Blk<MODEL, true> B(a, gusto_dyn_lds);
+    seg_chain_forward<MODEL, NCH>(B, c);
+}
+template <int MODEL, int NCH> __device__ __noinline__ void segw_h_rows_call(typename Blk<MODEL, true>::Args a, bool step, int hi, int rank, int nshare) {
+    Blk<MODEL, true> B(a, gusto_dyn_lds);
+    if (step) segw_rows_step_helper<MODEL, NCH>(B, hi, rank, nshare);
+    else segw_rows_resid_helper<MODEL, NCH>(B, hi, rank, nshare);
+}
+template <int MODEL, int NCH> __device__ __noinline__ void segw_h_costate_call(typename Blk<MODEL, true>::Args a) {
+    Blk<MODEL, true> B(a, gusto_dyn_lds);
+    costate_pass_seg<MODEL, NCH>(SweepView<MODEL>::make(B));
+    if (B.tid == 0) costate_close_x1<MODEL>(B, 0.5 * B.dt, gusto_dyn_lds + LdsC<MODEL, true>::misc + 16);
+}
+// (two waves per problem: the one helper's phases stay inlined in the kernel, with its view of the problem -- some 45 base pointers,
+// scalar loads from the kernel arguments -- rebuilt when the problem changes and not per command: ten commands per interior point
+// iteration, 3.5 % of the kernel's time as calls; its code is small enough for the kernel's register allocation)
+template <int MODEL> GD void segw_helper2(const KParams& P, double* lds) {
+    constexpr int NCH = 2;
     using SB = SegB<MODEL, NCH>;
     using BLK = Blk<MODEL, true>;
     using C = LdsC<MODEL, true>;
     const LPtr<double> L = lds;
     const int sb = P.ll.seg, mb = sb + SB::MBX;
-    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c = h - 1;
     Prof pfd;
     asm volatile("s_barrier" ::: "memory");
     int cmd = (int)L[mb];
@@ -501,11 +570,11 @@ template <int MODEL, int NCH> GD void segw_helper(const KParams& P, double* lds)
         do {
             if (cmd == SEGW_FACTOR) {
                 SweepView<MODEL> K = SweepView<MODEL>::make(B);
-                K.sPG = lds + sb + SB::sPG2(0) + c * SB::HLB; K.sHh = lds + sb + SB::Lw2(0) + c * SB::HLB;   // its own operand buffers
-#ifdef GUSTO_PROFILE   // (slots 29 .. 31, helper 1: its factor sweep, its wait at the join, the fold)
+                K.sPG = lds + sb + SB::sPG2(0); K.sHh = lds + sb + SB::Lw2(0);   // its own operand buffers
+#ifdef GUSTO_PROFILE   // (slots 29 .. 31: its factor sweep, its backward sweeps, the merge)
                 const long long t0 = clock64();
 #endif
-                seg_chain_factor<MODEL, NCH>(K, c, fail, pfd);
+                seg_chain_factor<MODEL, NCH>(K, 0, fail, pfd);
 #ifdef GUSTO_PROFILE
                 const long long t1 = clock64();
 #endif
@@ -513,9 +582,9 @@ template <int MODEL, int NCH> GD void segw_helper(const KParams& P, double* lds)
 #ifdef GUSTO_PROFILE
                 const long long t2 = clock64();
 #endif
-                if (h == 1) seg_fold_factor<MODEL, NCH>(B, fail);
+                seg_fold_factor2<MODEL>(B, fail);
 #ifdef GUSTO_PROFILE
-                if (h == 1 && B.tid == 0 && P.prof) {
+                if (B.tid == 0 && P.prof) {
                     const long long t3 = clock64();
                     long long* o = P.prof + (size_t)B.b * PROF_N;
                     o[29] += t1 - t0; o[31] += t3 - t2;
@@ -525,27 +594,82 @@ template <int MODEL, int NCH> GD void segw_helper(const KParams& P, double* lds)
 #ifdef GUSTO_PROFILE
                 const long long t0 = clock64();
 #endif
-                seg_chain_backward<MODEL, NCH>(B, c);
+                seg_chain_backward<MODEL, NCH>(B, 0);
 #ifdef GUSTO_PROFILE
-                if (h == 1 && B.tid == 0 && P.prof) P.prof[(size_t)B.b * PROF_N + 30] += clock64() - t0;   // (slot 30: helper 1's backward sweeps)
+                if (B.tid == 0 && P.prof) P.prof[(size_t)B.b * PROF_N + 30] += clock64() - t0;
 #endif
             } else if (cmd == SEGW_FWD) {
-                seg_chain_forward<MODEL, NCH>(B, c);
-            } else if (cmd == SEGW_ROWS_R) {         // (the helpers take ALL obstacle rows: the main wave has the other rows and the stage cost)
-                segw_rows_resid_helper<MODEL, NCH>(B, c, h - 1, NCH - 1);
+                seg_chain_forward<MODEL, NCH>(B, 0);
+            } else if (cmd == SEGW_ROWS_R) {         // (the helper takes ALL obstacle rows: the main wave has the other rows and the stage cost)
+                segw_rows_resid_helper<MODEL, NCH>(B, 0, 0, 1);
             } else if (cmd == SEGW_STEP) {
-                segw_rows_step_helper<MODEL, NCH>(B, c, h - 1, NCH - 1);
+                segw_rows_step_helper<MODEL, NCH>(B, 0, 0, 1);
             } else if (cmd == SEGW_STEP_CS) {
-                if (h == 1) {
-                    costate_pass_seg<MODEL, NCH>(SweepView<MODEL>::make(B));
-                    if (B.tid == 0) costate_close_x1<MODEL>(B, 0.5 * B.dt, lds + C::misc + 16);
-                    if constexpr (NCH == 2) segw_rows_step_helper<MODEL, NCH>(B, c, 1, 2);   // (the only helper: then half of the obstacle rows)
-                } else segw_rows_step_helper<MODEL, NCH>(B, c, h - 2, NCH - 2);
+                costate_pass_seg<MODEL, NCH>(SweepView<MODEL>::make(B));
+                if (B.tid == 0) costate_close_x1<MODEL>(B, 0.5 * B.dt, lds + C::misc + 16);
+                segw_rows_step_helper<MODEL, NCH>(B, 0, 1, 2);   // (then half of the obstacle rows)
             }
             segw_barrier();
             asm volatile("s_barrier" ::: "memory");
             cmd = (int)L[mb];
         } while (cmd != SEGW_EXIT && L[mb + 2] == pb);
+    }
+}
+template <int MODEL, int NCH> GD void segw_helper(const KParams& P, double* lds) {
+    if constexpr (NCH == 2) { segw_helper2<MODEL>(P, lds); return; }
+    using SB = SegB<MODEL, NCH>;
+    using BLK = Blk<MODEL, true>;
+    const LPtr<double> L = lds;
+    const int sb = P.ll.seg, mb = sb + SB::MBX;
+    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c = h - 1;
+    [[maybe_unused]] int fseq = 0;   // (factorisations so far: what the two merging helpers of the four-chain tree meet on)
+    for (;;) {
+        asm volatile("s_barrier" ::: "memory");
+        const int cmd = (int)L[mb];
+        if (cmd == SEGW_EXIT) return;
+        typename BLK::Args a;
+        a.Pk = (const KParams*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // (this function is inlined into the kernel; KParams is its first argument)
+        a.b = (int)L[mb + 2]; a.slot = (int)L[mb + 3]; a.goalmask = (unsigned)L[mb + 4]; a.boxmask = (unsigned)L[mb + 5]; a.dt = L[mb + 6];
+        if (cmd == SEGW_FACTOR) {
+#ifdef GUSTO_PROFILE   // (slots 29 .. 31, helper 1: its factor sweep, its backward sweeps, its share of the merges)
+            const long long t0 = clock64();
+#endif
+            segw_h_factor_call<MODEL, NCH>(a, c);
+#ifdef GUSTO_PROFILE
+            const long long t1 = clock64();
+#endif
+            segw_barrier();
+#ifdef GUSTO_PROFILE
+            const long long t2 = clock64();
+#endif
+            fseq++;
+            if (NCH == 2 || h == 1 || h == 3) segw_h_fold_call<MODEL, NCH>(a, h, fseq);
+#ifdef GUSTO_PROFILE
+            if (h == 1 && (threadIdx.x & 63) == 0 && P.prof) {
+                const long long t3 = clock64();
+                long long* o = P.prof + (size_t)a.b * PROF_N;
+                o[29] += t1 - t0; o[31] += t3 - t2;
+            }
+#endif
+        } else if (cmd == SEGW_BACK) {
+#ifdef GUSTO_PROFILE
+            const long long t0 = clock64();
+#endif
+            segw_h_back_call<MODEL, NCH>(a, c);
+#ifdef GUSTO_PROFILE
+            if (h == 1 && (threadIdx.x & 63) == 0 && P.prof) P.prof[(size_t)a.b * PROF_N + 30] += clock64() - t0;
+#endif
+        } else if (cmd == SEGW_FWD) {
+            segw_h_fwd_call<MODEL, NCH>(a, c);
+        } else if (cmd == SEGW_ROWS_R || cmd == SEGW_STEP) {   // (the helpers take ALL obstacle rows: the main wave has the other rows and the stage cost)
+            segw_h_rows_call<MODEL, NCH>(a, cmd == SEGW_STEP, c, h - 1, NCH - 1);
+        } else if (cmd == SEGW_STEP_CS) {
+            if (h == 1) {
+                segw_h_costate_call<MODEL, NCH>(a);
+                if constexpr (NCH == 2) segw_h_rows_call<MODEL, NCH>(a, true, c, 1, 2);   // (the only helper: then half of the obstacle rows)
+            } else segw_h_rows_call<MODEL, NCH>(a, true, c, h - 2, NCH - 2);
+        }
+        segw_barrier();
     }
 }
 

@@ -49,4 +49,10 @@ done
 for m in 2 3; do   # matrix-core counters of the 12/13-state kernels (v_mfma_f64_16x16x4_f64 in the factor sweep)
   timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/mfma_m$m -o c -- python bench.py --config $((m + 2)) --steps 1 --warmup 0 --no-extras --no-cpu-baseline > $OUT/mfma_m$m.log 2>&1
 done
+# the wave-per-chain kernels (csrc/segw.hpp): batch-size sweep of the decompositions, kernel statistics of the one-GPU shards of configs 4 / 5
+timeout 900 python tools/chains_sweep.py $OUT/chains_sweep.jsonl > $OUT/chains_sweep.log 2>&1
+for w in "2 1024" "3 256"; do
+  set -- $w
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_shard_m$1 -o stats -- python tools/gpu_time.py $1 $2 50 > $OUT/stats_shard_m$1.log 2>&1
+done
 ls -R $OUT | head -80
