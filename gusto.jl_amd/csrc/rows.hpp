@@ -35,6 +35,7 @@ template <int MODEL> struct RowCtx {
     GPtr<const double> goal_lo;
     GPtr<const double> goal_hi;
     unsigned boxmask;           // coordinates of x_N with BoxGoal rows (Blk::boxmask)
+    bool skip_ctl = false;      // the control rows of this knot are another wave's (segw.hpp: four waves per problem)
 #ifdef GUSTO_PROFILE
     Prof* pf = nullptr;   // sub-phase stamps of the row passes (PF_R*)
     int pfb = 0;
@@ -115,6 +116,34 @@ template <int MODEL, class Op> GD void visit_obs_rows(const RowCtx<MODEL>& c, co
             constexpr int q = decltype(Q)::value;
             if (ov[q]) lin_row<false, 0, T::WS, FX_OBS + q>(op, oslot[q], ROW_PEN, xs, ob[q], oc[q], kw, 0.0);
         });
+    }
+}
+
+// cci_*_accel_bound on k = 1..N-1 only (freeflyer_se2.jl:236-245,380-381): the two control rows of a knot of the freeflyer / astrobee
+// models (a function of its own: with four waves per problem a helper wave runs them, segw.hpp)
+template <int MODEL, class Op> GD void visit_ctl_rows(const RowCtx<MODEL>& c, const double* us, Op& op) {
+    using T = MT<MODEL>;
+    constexpr int n = T::n;
+    constexpr bool is2 = MODEL == GUSTO_FREEFLYER_SE2, FB = Op::FIX_BATCH;
+    const gusto_model_params& mp = c.P->mp;
+    const int slot_u = T::NFIX + c.P->n_obs + 2 * n;
+    if (c.k < c.N - 1) {
+        constexpr int nf = is2 ? 2 : 3, im = is2 ? 2 : 3, nm = is2 ? 1 : 3;
+        double af[nf], am[nm];
+#pragma unroll
+        for (int j = 0; j < nf; j++) af[j] = 1.0 / (mp.mass * mp.mass);
+#pragma unroll
+        for (int j = 0; j < nm; j++) { const double ji = 1.0 / mp.Jdiag[is2 ? 2 : j]; am[j] = ji * ji; }
+        if constexpr (FB) {
+            int fs[OBS_BATCH];
+#pragma unroll
+            for (int q = 0; q < OBS_BATCH; q++) fs[q] = slot_u + (q < 1 ? 0 : 1);
+            op.obs_load(fs);
+        }
+        quad_row<true, 0, nf, (FB ? FX_OBS + 0 : T::NFIX)>(op, slot_u, ROW_HARD, us, af, nullptr, -mp.hard_limit_accel * mp.hard_limit_accel,
+                              1.0 / (mp.hard_limit_accel * mp.hard_limit_accel), 0.0);
+        quad_row<true, im, nm, (FB ? FX_OBS + 1 : T::NFIX + 1)>(op, slot_u + 1, ROW_HARD, us, am, nullptr, -mp.hard_limit_alpha * mp.hard_limit_alpha,
+                               1.0 / (mp.hard_limit_alpha * mp.hard_limit_alpha), 0.0);
     }
 }
 
@@ -265,24 +294,7 @@ template <int MODEL, class Op> GD void visit_rows(const RowCtx<MODEL>& c, const 
         c.tick(1);   // fixed state rows; then the obstacle rows (visit_obs_rows)
         visit_obs_rows<MODEL>(c, xs, op, c.mask);
         c.tick(2);   // obstacle rows
-        if (c.k < c.N - 1) {  // cci_*_accel_bound on k = 1..N-1 only (freeflyer_se2.jl:236-245,380-381)
-            constexpr int nf = is2 ? 2 : 3, im = is2 ? 2 : 3, nm = is2 ? 1 : 3;
-            double af[nf], am[nm];
-#pragma unroll
-            for (int j = 0; j < nf; j++) af[j] = 1.0 / (mp.mass * mp.mass);
-#pragma unroll
-            for (int j = 0; j < nm; j++) { const double ji = 1.0 / mp.Jdiag[is2 ? 2 : j]; am[j] = ji * ji; }
-            if constexpr (FB) {
-                int fs[OBS_BATCH];
-#pragma unroll
-                for (int q = 0; q < OBS_BATCH; q++) fs[q] = slot_u + (q < 1 ? 0 : 1);
-                op.obs_load(fs);
-            }
-            quad_row<true, 0, nf, (FB ? FX_OBS + 0 : T::NFIX)>(op, slot_u, ROW_HARD, us, af, nullptr, -mp.hard_limit_accel * mp.hard_limit_accel,
-                                  1.0 / (mp.hard_limit_accel * mp.hard_limit_accel), 0.0);
-            quad_row<true, im, nm, (FB ? FX_OBS + 1 : T::NFIX + 1)>(op, slot_u + 1, ROW_HARD, us, am, nullptr, -mp.hard_limit_alpha * mp.hard_limit_alpha,
-                                   1.0 / (mp.hard_limit_alpha * mp.hard_limit_alpha), 0.0);
-        }
+        if (!c.skip_ctl) visit_ctl_rows<MODEL>(c, us, op);
 #undef GUSTO_FXB
     } else {  // DubinsCar: csi_max/min_bound_constraints, cci_max/min_bound_constraints (dynamics.jl:56-81)
         static_for<0, n>([&](auto I) {

@@ -333,73 +333,6 @@ GD int sched_pop(const KParams& P, bool& cont, int& from) {   // from: the level
     }
 }
 
-// the persistent loop of a resident workgroup: problems from the scheduler until it has none left
-// (NCH > 0: the main wave of scp_kernel_w2 -- the one-wave program, its sequential phases shared with the helper waves)
-template <int MODEL, bool ONEWAVE, int NCH> GD void scp_kernel_body(const KParams& P, double* lds) {
-    const int slot = blockIdx.x;
-    for (;;) {
-        int b = 0, ci = 0, from = 0;
-        if constexpr (ONEWAVE) {
-            bool c = false;
-            b = sched_pop(P, c, from); ci = c;
-        } else {
-            __shared__ int sh_b, sh_cont, sh_from;
-            __syncthreads();               // (everyone is done with the previous problem's LDS)
-            if (threadIdx.x < 64) {        // wave 0 asks the scheduler, the others get the answer through LDS
-                bool c = false;
-                b = sched_pop(P, c, from);
-                if (threadIdx.x == 0) { sh_b = b; sh_cont = c; sh_from = from; }
-            }
-            __syncthreads();
-            b = sh_b; ci = sh_cont; from = sh_from;
-        }
-        if (b < 0) return;
-        const bool cont = ci != 0;
-        const int visits = cont ? (b >> 24) : 0;     // time slices this problem has had in this gusto_solve call
-        b &= (1 << 24) - 1;
-        // hipcc (ROCm 7.2) otherwise forms some of the problem's base addresses from the UNMASKED register (seen in the
-        // ISA: s_and_b32 for tf[b], but v_mad_u64_u32 with the raw entry for goal_lo + b * n): pin the masked value
-        asm volatile("" : "+v"(b));
-        b = __builtin_amdgcn_readfirstlane(b);
-        if (cont) {   // the state another workgroup left in HBM: drop whatever this CU's L1 still holds of it.  ONE lane
-            // issues the invalidate (the L1 is the CU's, not the lane's), then the workgroup synchronises.
-            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            blk_sync<ONEWAVE>();
-        }
-#ifdef GUSTO_SCHED_DEBUG
-        if (b >= P.B) { if (threadIdx.x == 0) printf("sched: bad b %d (ci %d visits %d) slot %d\n", b, ci, visits, slot); return; }
-#endif
-        // slices: one trip each while probing; then a problem of penalty level 0 goes on in slices of slice_q trips (it is
-        // requeued behind the others of its level, and ahead of them all once its penalty weight is raised), a problem of a
-        // higher level runs to its end
-        const bool sliced = P.mode == 0 && P.probe_visits > 0;
-        const int trips = !sliced ? (1 << 30) : (visits < P.probe_visits) ? 1 : (P.slice_q > 0 && cont && from == 0) ? P.slice_q : (1 << 30);
-        // a problem that starts its last slice will not be pushed again (SQ_PROBING: the problems that still may be)
-        if (sliced && trips == (1 << 30) && threadIdx.x == 0)
-            __hip_atomic_fetch_sub(P.queue + SQ_PROBING, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const int lvl = scp_problem<MODEL, ONEWAVE, NCH>(P, lds, b, slot, cont, trips);
-        blk_sync<ONEWAVE>();               // the next problem reuses this workgroup's LDS and workspace slot
-        if constexpr (!ONEWAVE) __syncthreads();
-        if (threadIdx.x == 0) {
-#ifdef GUSTO_SCHED_DEBUG
-            printf("sched: slot %d problem %d cont %d visits %d trips %d -> lvl %d\n", slot, b, (int)cont, visits, trips, lvl);
-#endif
-            if (lvl >= 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // state first ...
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lvl >= 1) atomicAdd(P.queue + SQ_HI, 1);
-                const int idx = atomicAdd(P.queue + SQ_TAIL + lvl * SQ_STRIDE, 1);
-                __hip_atomic_store(P.lists + (size_t)lvl * P.list_cap + idx, ((visits + 1) << 24) | b, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);                                                        // ... then the entry
-            }
-            // the problem stopped inside a finite slice: it will not be pushed again
-            // (release: the tail increment and the entry above are visible to whoever sees the counter drop)
-            if (sliced && trips != (1 << 30) && lvl < 0)
-                __hip_atomic_fetch_sub(P.queue + SQ_PROBING, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 template <int MODEL, bool ONEWAVE> __global__ void __launch_bounds__(ONEWAVE ? 64 : 256, ONEWAVE ? MT<MODEL>::WAVES_PER_EU : 1)
 scp_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -407,7 +340,11 @@ scp_kernel(const KParams P) {
     if (threadIdx.x == 0) gusto_dbg_lds_limit() = __builtin_amdgcn_groupstaticsize() + (unsigned)P.ll.total * 8u;
     __syncthreads();
 #endif
-    scp_kernel_body<MODEL, ONEWAVE, 0>(P, lds);
+#define GUSTO_BODY_NCH 0
+#define GUSTO_BODY_EXIT return
+#include "scp_body.inc"
+#undef GUSTO_BODY_NCH
+#undef GUSTO_BODY_EXIT
 }
 
 #if GUSTO_SEG_W2
@@ -423,8 +360,12 @@ template <int MODEL, int NCH> __global__ void __launch_bounds__(64 * NCH, 1) scp
     if constexpr (seg2_big<MODEL>()) {
         if (threadIdx.x >= 64) { segw_helper<MODEL, NCH>(P, lds); return; }
         if constexpr (NCH == 4) { if (threadIdx.x == 0) *seg_tree_flag<MODEL>(lds, P.ll.seg) = 0; }   // (read after the first command's barriers)
-        scp_kernel_body<MODEL, true, NCH>(P, lds);
-        segw_exit(lds, P.ll.seg + SegB<MODEL, NCH>::MBX);
+        constexpr bool ONEWAVE = true;
+#define GUSTO_BODY_NCH NCH
+#define GUSTO_BODY_EXIT segw_exit(lds, P.ll.seg + SegB<MODEL, NCH>::MBX); return
+#include "scp_body.inc"
+#undef GUSTO_BODY_NCH
+#undef GUSTO_BODY_EXIT
     }
 }
 #endif
