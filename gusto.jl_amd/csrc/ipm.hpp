@@ -2717,7 +2717,7 @@ template <int MODEL, class BLK, int NCH = 0> GD void ipm_solve(BLK& K, double De
             pf.tick(PF_FACTOR);
             GUSTO_REFRESH_K();
             seg_done = true;
-            if (*fail != 0.0) { segw_join(); break; }   // (the barriers of the waves stay paired)
+            if (*fail != 0.0) { if constexpr (NCH == 4) segw_join(); segw_join(); break; }   // (the barriers of the waves stay paired)
         }
 #endif
 #if GUSTO_SEG2
@@ -2830,7 +2830,8 @@ template <int MODEL, class BLK, int NCH = 0> GD void ipm_solve(BLK& K, double De
             bool swp = false;
 #if GUSTO_SEG_W2
             if constexpr (SEGB) {
-                if (pass == 0) {   // the fold of this factorisation is done
+                if (pass == 0) {   // the merges of this factorisation are done (four chains: the barrier between the tree's two levels first)
+                    if constexpr (NCH == 4) segw_join();
                     segw_join();
                     pf.tick(PF_POSTF);   // (the wait for it)
                     if (*fail != 0.0) { seg_fail = true; break; }

@@ -359,7 +359,6 @@ template <int MODEL, int NCH> __global__ void __launch_bounds__(64 * NCH, 1) scp
 #endif
     if constexpr (seg2_big<MODEL>()) {
         if (threadIdx.x >= 64) { segw_helper<MODEL, NCH>(P, lds); return; }
-        if constexpr (NCH == 4) { if (threadIdx.x == 0) *seg_tree_flag<MODEL>(lds, P.ll.seg) = 0; }   // (read after the first command's barriers)
         constexpr bool ONEWAVE = true;
 #define GUSTO_BODY_NCH NCH
 #define GUSTO_BODY_EXIT segw_exit(lds, P.ll.seg + SegB<MODEL, NCH>::MBX); return

@@ -20,8 +20,8 @@
 // profiles/r06_segmented_riccati_proto.txt.  Reference path: the convex subproblem of scp_gusto.jl:104,178-314 (JuMP.optimize!).
 //
 // Who runs what (wave 0 = MAIN: the one-wave program, and the last chain; wave h >= 1 = helper, chain h - 1):
-//   FACTOR   every wave its chain's factor sweep; join; helper 1 (four chains: and helper 3) merges the chains' matrices (seg_merge)
-//            while the main wave builds the predictor's right-hand side; join
+//   FACTOR   every wave its chain's factor sweep; join; helper 1 merges the chains' matrices (seg_merge) while the main wave builds
+//            the predictor's right-hand side (four chains: helpers 1 and 3 the two pairs, a barrier, helper 1 the pairs); join
 //   BACK     every wave its chain's backward vector sweep; join.  The main wave's mid phase then folds the vectors, gets mu_g and
 //            every interface's (xi, dlam)
 //   FWD      every wave its chain's forward sweep; join
@@ -187,25 +187,24 @@ template <int MODEL, class BLK> GD void seg_fold_factor2(BLK& K, double* fail) {
     if (!seg_merge<MODEL, 2>(K, I, sb + SB::CH(0) + SB::Gdf, I + SB::Pc, I + SB::PIc, LdsC<MODEL, true>::sGd, sb + SB::X1)) *fail = 1.0;
     seg_fold_finish<MODEL, 2>(K, fail, I + SB::PIc);
 }
-// four chains, merged as a TREE: (C0 | C1) on helper 1 and (C2 | C3) on helper 3 side by side, then (C0 C1 | C2 C3) on helper 1 --
-// the multiplier behind interfaces 1 and 2 is mu_g, the one behind interface 0 is interface 1's.  The two helpers meet through a
-// sequence number in LDS (workgroup barriers belong to the main wave's commands).
-template <int MODEL> GD int* seg_tree_flag(double* lds, int sb) { return reinterpret_cast<int*>(lds + sb + SegB<MODEL, 4>::MBX + 16); }
-template <int MODEL, class BLK> GD void seg_fold_tree_rear(BLK& K, double* fail, int seq) {      // helper 3 (chain 2's wave)
+// four chains, merged as a TREE: (C0 | C1) on helper 1 and (C2 | C3) on helper 3 side by side (level 1), a workgroup barrier, then
+// (C0 C1 | C2 C3) on helper 1 (level 2) -- the multiplier behind interfaces 1 and 2 is mu_g, the one behind interface 0 is interface 1's.
+template <int MODEL, class BLK> GD void seg_fold_tree_level1(BLK& K, double* fail, int h) {
     using SB = SegB<MODEL, 4>;
-    const int sb = K.P.ll.seg, I = sb + SB::IF(2), In = sb + SB::IF(1), scr = sb + SB::sPG2(2);   // (its own block is idle: scratch)
-    if (!seg_merge<MODEL, 4>(K, I, sb + SB::CH(2) + SB::Gdf, I + SB::Pc, I + SB::PIc, LdsC<MODEL, true>::sGd, scr)) *fail = 1.0;
-    seg_merge_front<MODEL, 4>(K, I, sb + SB::CH(2) + SB::Pf, sb + SB::CH(2) + SB::Pif, In + SB::Pc, In + SB::PIc, scr + SB::NNp);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (K.tid == 0) __hip_atomic_store(seg_tree_flag<MODEL>(K.lds, sb), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int sb = K.P.ll.seg;
+    if (h == 3) {          // chain 2's wave: (C2 | C3) and the pair's (P, Pi), which interface 1 sees behind it
+        const int I = sb + SB::IF(2), In = sb + SB::IF(1), scr = sb + SB::sPG2(2);   // (its own block is idle: scratch)
+        if (!seg_merge<MODEL, 4>(K, I, sb + SB::CH(2) + SB::Gdf, I + SB::Pc, I + SB::PIc, LdsC<MODEL, true>::sGd, scr)) *fail = 1.0;
+        seg_merge_front<MODEL, 4>(K, I, sb + SB::CH(2) + SB::Pf, sb + SB::CH(2) + SB::Pif, In + SB::Pc, In + SB::PIc, scr + SB::NNp);
+    } else if (h == 1) {   // chain 0's wave: (C0 | C1); chain 1's Gd becomes the pair's
+        const int I0 = sb + SB::IF(0), C1 = sb + SB::CH(1);
+        if (!seg_merge<MODEL, 4>(K, I0, sb + SB::CH(0) + SB::Gdf, C1 + SB::Pf, C1 + SB::Pif, C1 + SB::Gdf, sb + SB::X1)) *fail = 1.0;
+    }
 }
-template <int MODEL, class BLK> GD void seg_fold_tree_front(BLK& K, double* fail, int seq) {     // helper 1 (chain 0's wave)
+template <int MODEL, class BLK> GD void seg_fold_tree_level2(BLK& K, double* fail) {      // helper 1
     using SB = SegB<MODEL, 4>;
-    const int sb = K.P.ll.seg, I0 = sb + SB::IF(0), I1 = sb + SB::IF(1), C1 = sb + SB::CH(1);
-    if (!seg_merge<MODEL, 4>(K, I0, sb + SB::CH(0) + SB::Gdf, C1 + SB::Pf, C1 + SB::Pif, C1 + SB::Gdf, sb + SB::X1)) *fail = 1.0;   // Gd_1 -> Gd_01
-    while (__hip_atomic_load(seg_tree_flag<MODEL>(K.lds, sb), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(4);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (!seg_merge<MODEL, 4>(K, I1, C1 + SB::Gdf, I1 + SB::Pc, I1 + SB::PIc, LdsC<MODEL, true>::sGd, sb + SB::X1)) *fail = 1.0;
+    const int sb = K.P.ll.seg, I1 = sb + SB::IF(1);
+    if (!seg_merge<MODEL, 4>(K, I1, sb + SB::CH(1) + SB::Gdf, I1 + SB::Pc, I1 + SB::PIc, LdsC<MODEL, true>::sGd, sb + SB::X1)) *fail = 1.0;
     seg_fold_finish<MODEL, 4>(K, fail, I1 + SB::PIc);
 }
 
@@ -513,21 +512,27 @@ template <int MODEL, int NCH, class BLK> GD void seg_chain_forward(const BLK& B,
 
 // The helper wave h = 1 .. NCH - 1 (chain h - 1).  What it runs are real calls, like the main wave's phases: inlined into the kernel
 // they shared its register allocation (1300 spilled SGPRs, 320 VGPRs) and every piece added there slowed the sweeps of all helpers.
-template <int MODEL, int NCH> __device__ __noinline__ void segw_h_factor_call(typename Blk<MODEL, true>::Args a, int c) {
+// (the chain is a template parameter, like the main wave's: one called sweep per chain)
+template <int MODEL, int NCH, int CH> __device__ __noinline__ void segw_h_factor_chain(typename Blk<MODEL, true>::Args a) {
     using SB = SegB<MODEL, NCH>;
     Blk<MODEL, true> B(a, gusto_dyn_lds);
     SweepView<MODEL> K = SweepView<MODEL>::make(B);
     const int sb = B.P.ll.seg;
-    K.sPG = gusto_dyn_lds + sb + SB::sPG2(0) + c * SB::HLB; K.sHh = gusto_dyn_lds + sb + SB::Lw2(0) + c * SB::HLB;   // its own operand buffers
+    K.sPG = gusto_dyn_lds + sb + SB::sPG2(CH); K.sHh = gusto_dyn_lds + sb + SB::Lw2(CH);   // its own operand buffers
     Prof pfd;
-    seg_chain_factor<MODEL, NCH>(K, c, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, pfd);
+    seg_chain_factor<MODEL, NCH>(K, CH, gusto_dyn_lds + LdsC<MODEL, true>::misc + 8, pfd);
 }
-template <int MODEL, int NCH> __device__ __noinline__ void segw_h_fold_call(typename Blk<MODEL, true>::Args a, int h, int seq) {
+template <int MODEL, int NCH> GD void segw_h_factor_call(typename Blk<MODEL, true>::Args a, int c) {
+    if (c == 0) segw_h_factor_chain<MODEL, NCH, 0>(a);
+    else if (c == 1) segw_h_factor_chain<MODEL, NCH, (NCH > 2 ? 1 : 0)>(a);
+    else segw_h_factor_chain<MODEL, NCH, (NCH > 2 ? 2 : 0)>(a);
+}
+template <int MODEL, int NCH> __device__ __noinline__ void segw_h_fold_call(typename Blk<MODEL, true>::Args a, int h, int level) {
     Blk<MODEL, true> B(a, gusto_dyn_lds);
     double* fail = gusto_dyn_lds + LdsC<MODEL, true>::misc + 8;
     if constexpr (NCH == 2) seg_fold_factor2<MODEL>(B, fail);
-    else if (h == 3) seg_fold_tree_rear<MODEL>(B, fail, seq);
-    else seg_fold_tree_front<MODEL>(B, fail, seq);
+    else if (level == 1) seg_fold_tree_level1<MODEL>(B, fail, h);
+    else seg_fold_tree_level2<MODEL>(B, fail);
 }
 template <int MODEL, int NCH> __device__ __noinline__ void segw_h_back_call(typename Blk<MODEL, true>::Args a, int c) {
     Blk<MODEL, true> B(a, gusto_dyn_lds);
@@ -622,7 +627,6 @@ template <int MODEL, int NCH> GD void segw_helper(const KParams& P, double* lds)
     const LPtr<double> L = lds;
     const int sb = P.ll.seg, mb = sb + SB::MBX;
     const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c = h - 1;
-    [[maybe_unused]] int fseq = 0;   // (factorisations so far: what the two merging helpers of the four-chain tree meet on)
     for (;;) {
         asm volatile("s_barrier" ::: "memory");
         const int cmd = (int)L[mb];
@@ -642,8 +646,9 @@ template <int MODEL, int NCH> GD void segw_helper(const KParams& P, double* lds)
 #ifdef GUSTO_PROFILE
             const long long t2 = clock64();
 #endif
-            fseq++;
-            if (NCH == 2 || h == 1 || h == 3) segw_h_fold_call<MODEL, NCH>(a, h, fseq);
+            if (h == 1 || h == 3) segw_h_fold_call<MODEL, NCH>(a, h, 1);   // the tree's first level: two merges side by side
+            segw_barrier();
+            if (h == 1) segw_h_fold_call<MODEL, NCH>(a, h, 2);
 #ifdef GUSTO_PROFILE
             if (h == 1 && (threadIdx.x & 63) == 0 && P.prof) {
                 const long long t3 = clock64();

@@ -29,6 +29,11 @@ for N in {Ns}:
         s = g.TrajOptSolver(pub, N, 6, boxes=bx, spheres=sp); s.set_problems(*batch); s.solve(6)
     else:
         s = g.BatchSolver(pub, N, 6, hist_cap=40, boxes=bx, spheres=sp); s.set_problems(*batch); s.solve(8)
+        for dec in ((1, 3, 4) if model in (2, 3) else ()):   # one / two / four waves per problem (csrc/segw.hpp; the default above: four)
+            d = g.BatchSolver(pub, N, 6, hist_cap=40, boxes=bx, spheres=sp); d.set_decomposition(dec); d.set_problems(*batch); d.solve(8)
+            print("model", model, "N", N, "decomposition", dec, "ok", bool(np.isfinite(d.traj()[0]).all()), d.status()["iterations"])
+            if not np.array_equal(d.status()["iterations"], s.status()["iterations"]):   # (a debug build once ran the four-wave helpers' sweeps into NaN)
+                print("out of bounds or worse: decomposition", dec, "disagrees with the default"); sys.exit(1)
     X, U = s.traj()
     print("model", model, "N", N, "ok", bool(np.isfinite(X).all()), s.status()["iterations"])
 '''
