@@ -373,10 +373,11 @@ __host__ __device__ constexpr int seg_split(int N) { return N >> 1; }   // two c
 template <int MODEL> constexpr bool seg2_big() { return GUSTO_SEG_W2 && MT<MODEL>::MFMA && MT<MODEL>::SWEEP_CALL && MT<MODEL>::NDEF == 0; }
 // LDS block of the segmented solve of these kernels, behind everything else (offsets relative to LdsLayout::seg).  NCH chains
 // (= waves per problem, 2 or 4): chain c covers the stages seg_lo(c) .. seg_lo(c + 1) - 1, interface j sits between chain j and
-// what lies behind it -- the chains j + 1 .. NCH - 1 FOLDED into one (seg.hpp: seg_fold_factor).
+// what lies behind it as the merge tree pairs them (segw.hpp: seg_merge; four chains: interfaces 0 and 2 inside the pairs (C0 | C1),
+// (C2 | C3), interface 1 between the pairs).
 __host__ __device__ constexpr int seg_lo(int c, int N, int NCH) { return (int)((long)N * c / NCH); }
 constexpr int SEGW_FACTOR = 1, SEGW_BACK = 2, SEGW_FWD = 3, SEGW_ROWS_R = 5, SEGW_STEP = 6, SEGW_STEP_CS = 7, SEGW_EXIT = 9;   // commands to the helper waves (segw.hpp)
-constexpr int SEG_RP = 15;   // values per knot a wave leaves of its share of a row pass (segw.hpp: RowPartR, RowPartS)
+constexpr int SEG_RP = 15;   // values per knot a wave leaves of its share of a row pass (segw.hpp: segw_rows_*)
 template <int MODEL, int NCH> struct SegB {
     static constexpr int n = MT<MODEL>::n, m = MT<MODEL>::m, NNp = (n * n + 1) & ~1, NPG = n * (n + m), NI = NCH - 1;
     // per interface: Ta', Sig, Pa = Ta Pc, A2 = Sig Pic, A3 = Ta Pic and the folded rear part's (Pc, Pic) -- the last chain's own sweep

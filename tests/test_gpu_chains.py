@@ -131,3 +131,34 @@ def test_odd_horizons():
             cv = out[WAVE][1]["converged"].astype(bool)
             if cv.any():
                 assert np.abs(out[dec][0] - out[WAVE][0])[cv].max() < 1e-4, (N, dec)
+
+
+@pytest.mark.parametrize("dec", [WAVE2, WAVE4])
+def test_resume_and_active_mask_with_chains(dec):
+    """the state machine around the chain kernels: solve(4) then solve(26) continues exactly like one solve(30) (scp_gusto.jl:67; bit for
+    bit: the same kernel runs the same trips), and gusto_set_active hands out only the listed problems (the others keep trajectory,
+    histories and counters untouched) -- the run of the listed ones does not depend on who else is in the launch."""
+    g, _ = _mods()
+    model, boxes, sph, batch = _batch(g, "astrobee_se3_manifold", 24)
+    a = g.BatchSolver(model, 50, 24, hist_cap=80, boxes=boxes, spheres=sph)
+    a.set_decomposition(dec); a.set_problems(*batch); a.solve(30)
+    Xa, Ua = a.traj(); sa = a.status()
+    b = g.BatchSolver(model, 50, 24, hist_cap=80, boxes=boxes, spheres=sph)
+    b.set_decomposition(dec); b.set_problems(*batch); b.solve(4)
+    assert (b.status()["iterations"] <= 4).all()
+    b.solve(26)
+    Xb, Ub = b.traj(); sb = b.status()
+    same = sa["iterations"] > 4          # (problems that stopped within the first call keep iterating on resume)
+    np.testing.assert_array_equal(sa["iterations"][same], sb["iterations"][same])
+    np.testing.assert_array_equal(Xa[same], Xb[same])
+    np.testing.assert_array_equal(Ua[same], Ub[same])
+    c = g.BatchSolver(model, 50, 24, hist_cap=80, boxes=boxes, spheres=sph)
+    c.set_decomposition(dec); c.set_problems(*batch)
+    X0, U0 = c.traj()
+    act = np.zeros(24, bool); act[[1, 5, 6, 17, 23]] = True
+    c.set_active(act); c.solve(30)
+    Xc, Uc = c.traj(); sc = c.status()
+    np.testing.assert_array_equal(Xc[~act], X0[~act])
+    assert (sc["iterations"][~act] == 0).all()
+    np.testing.assert_array_equal(sc["iterations"][act], sa["iterations"][act])
+    np.testing.assert_array_equal(Xc[act], Xa[act])
