@@ -183,3 +183,43 @@ def test_julia_wrapper_matches_the_c_header():
         assert [jl_type(t, c) for _, t, c in cf] == [t for _, t in jf], (cname, cf, jf)
     # the robot / model scalars reach the library: no C_NULL where gusto_model_params goes
     assert "Ref{GustoModelParams}" in jl and not re.search(r"gusto_set_params.*C_NULL", jl)
+
+
+def test_chain_kernel_layouts(tmp_path):
+    """the wave-per-chain kernels (csrc/segw.hpp) by their compile-time layouts, without a GPU: chains partition the horizon with at
+    least GUSTO_SEG_MIN_N stages each wherever launch_scp starts them, the obstacle shares partition a knot's active mask, a helper's
+    LDS block holds both its [Phi Gam] double buffer and its row partials, and the workgroups fit a CU's 160 KiB -- two two-wave
+    problems per CU at the BASELINE horizon (what the AUTO policy of launch.hpp assumes)."""
+    import json, subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "seg_layout")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "gusto.jl_amd", "csrc"), os.path.join(ROOT, "tests", "c", "seg_layout.hip"), "-o", exe],
+                          stderr=subprocess.DEVNULL)
+    d = json.loads(subprocess.check_output([exe]).decode())
+    LDS = 160 * 1024
+    for name in ("astrobee_se3", "astrobee_se3_manifold"):
+        m = d[name]
+        for N in ("16", "33", "50", "63", "64"):
+            one, two, four = m[N]
+            assert two == one + m["segB2"] and four == one + m["segB4"]
+            assert 8 * four <= LDS and 8 * two <= LDS, (name, N)
+        assert 2 * 8 * m["50"][1] <= LDS, name                       # two two-wave problems per CU at N = 50
+        assert 3 * 8 * m["50"][0] <= LDS < 4 * 8 * m["50"][0], name   # (and three one-wave problems, as DESIGN.md says)
+        for hlb in (m["hlb2"], m["hlb4"]):
+            assert hlb >= 2 * m["npg"] + 64 and hlb >= 64 * m["rp"]
+    for key, lo in d["lo"].items():
+        nch, N = map(int, key.split("_"))
+        assert lo[0] == 0 and lo[-1] == N and all(b > a for a, b in zip(lo, lo[1:]))
+        if N >= nch * d["min_n"]:
+            assert min(b - a for a, b in zip(lo, lo[1:])) >= d["min_n"], key
+        assert max(b - a for a, b in zip(lo, lo[1:])) - min(b - a for a, b in zip(lo, lo[1:])) <= 1, key
+    for ns in (1, 2, 3, 4):
+        masks = [int(d["share"][f"{r}_{ns}"], 16) for r in range(ns)]
+        acc = 0
+        for mk in masks:
+            assert acc & mk == 0
+            acc |= mk
+        assert acc == (1 << 64) - 1
