@@ -552,9 +552,10 @@ template <int MODEL, int NCH> __device__ __noinline__ void segw_h_costate_call(t
     costate_pass_seg<MODEL, NCH>(SweepView<MODEL>::make(B));
     if (B.tid == 0) costate_close_x1<MODEL>(B, 0.5 * B.dt, gusto_dyn_lds + LdsC<MODEL, true>::misc + 16);
 }
-// (two waves per problem: the one helper's phases stay inlined in the kernel, with its view of the problem -- some 45 base pointers,
-// scalar loads from the kernel arguments -- rebuilt when the problem changes and not per command: ten commands per interior point
-// iteration, 3.5 % of the kernel's time as calls; its code is small enough for the kernel's register allocation)
+// (two waves per problem: the one helper's small phases stay inlined in the kernel, with its view of the problem -- some 45 base
+// pointers, scalar loads from the kernel arguments -- rebuilt when the problem changes and not per command: ten commands per interior
+// point iteration, 3.5 % of the kernel's time if all were calls.  Its factor sweep and the merge ARE calls: 2 - 4 % faster with a
+// register allocation of their own)
 template <int MODEL> GD void segw_helper2(const KParams& P, double* lds) {
     constexpr int NCH = 2;
     using SB = SegB<MODEL, NCH>;
@@ -573,13 +574,11 @@ template <int MODEL> GD void segw_helper2(const KParams& P, double* lds) {
         BLK B(a, lds);
         double* fail = lds + C::misc + 8;
         do {
-            if (cmd == SEGW_FACTOR) {
-                SweepView<MODEL> K = SweepView<MODEL>::make(B);
-                K.sPG = lds + sb + SB::sPG2(0); K.sHh = lds + sb + SB::Lw2(0);   // its own operand buffers
+            if (cmd == SEGW_FACTOR) {   // (the two big pieces are calls here too: a register allocation of their own)
 #ifdef GUSTO_PROFILE   // (slots 29 .. 31: its factor sweep, its backward sweeps, the merge)
                 const long long t0 = clock64();
 #endif
-                seg_chain_factor<MODEL, NCH>(K, 0, fail, pfd);
+                segw_h_factor_chain<MODEL, NCH, 0>(a);
 #ifdef GUSTO_PROFILE
                 const long long t1 = clock64();
 #endif
@@ -587,7 +586,7 @@ template <int MODEL> GD void segw_helper2(const KParams& P, double* lds) {
 #ifdef GUSTO_PROFILE
                 const long long t2 = clock64();
 #endif
-                seg_fold_factor2<MODEL>(B, fail);
+                segw_h_fold_call<MODEL, NCH>(a, 1, 0);
 #ifdef GUSTO_PROFILE
                 if (B.tid == 0 && P.prof) {
                     const long long t3 = clock64();
@@ -609,7 +608,7 @@ template <int MODEL> GD void segw_helper2(const KParams& P, double* lds) {
                 segw_rows_resid_helper<MODEL, NCH>(B, 0, 0, 1);
             } else if (cmd == SEGW_STEP) {
                 segw_rows_step_helper<MODEL, NCH>(B, 0, 0, 1);
-            } else if (cmd == SEGW_STEP_CS) {
+            } else if (cmd == SEGW_STEP_CS) {   // (these as calls too: measured slower, 46.5 against 45.4 ms -- the view rebuilt per call)
                 costate_pass_seg<MODEL, NCH>(SweepView<MODEL>::make(B));
                 if (B.tid == 0) costate_close_x1<MODEL>(B, 0.5 * B.dt, lds + C::misc + 16);
                 segw_rows_step_helper<MODEL, NCH>(B, 0, 1, 2);   // (then half of the obstacle rows)
