@@ -563,7 +563,6 @@ template <int MODEL> GD void segw_helper2(const KParams& P, double* lds) {
     using C = LdsC<MODEL, true>;
     const LPtr<double> L = lds;
     const int sb = P.ll.seg, mb = sb + SB::MBX;
-    Prof pfd;
     asm volatile("s_barrier" ::: "memory");
     int cmd = (int)L[mb];
     while (cmd != SEGW_EXIT) {
@@ -572,7 +571,6 @@ template <int MODEL> GD void segw_helper2(const KParams& P, double* lds) {
         const double pb = L[mb + 2];
         a.b = (int)pb; a.slot = (int)L[mb + 3]; a.goalmask = (unsigned)L[mb + 4]; a.boxmask = (unsigned)L[mb + 5]; a.dt = L[mb + 6];
         BLK B(a, lds);
-        double* fail = lds + C::misc + 8;
         do {
             if (cmd == SEGW_FACTOR) {   // (the two big pieces are calls here too: a register allocation of their own)
 #ifdef GUSTO_PROFILE   // (slots 29 .. 31: its factor sweep, its backward sweeps, the merge)
