@@ -86,6 +86,7 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     int NTL = NT;
     const bool want_chains = h->decomposition == GUSTO_DECOMP_WAVE2 || h->decomposition == GUSTO_DECOMP_WAVE4;
     bool have_chains = false;
+    [[maybe_unused]] int nch_used = 0;
 #if GUSTO_SEG_W2
     // a batch that leaves SIMDs without a wave runs several waves per problem, the KKT solve's sequential phases as Riccati segments
     // side by side and the obstacle rows shared (scp_kernel_w2, segw.hpp): four waves up to two problems per CU, two up to the batch
@@ -101,7 +102,7 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
             P.ll = make_lds_layout<MODEL>(h->N, false, nch);
             lds = (size_t)P.ll.total * sizeof(double);
             kern = (nch == 4) ? &scp_kernel_w2<MODEL, 4> : &scp_kernel_w2<MODEL, 2>; NTL = 64 * nch;
-            have_chains = true;
+            have_chains = true; nch_used = nch;
         }
     }
 #endif
@@ -129,7 +130,12 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     // scheduler state of this launch (scp.hpp): counters to 0, waiting lists to -1
     // number of probing slices: the caller's (gusto_set_schedule) or the model's default (2; dubins_car 1)
     const int probe = h->sched_forced ? h->probe_iters : MT<MODEL>::SCHED_PROBE;
-    const bool dyn = mode == 0 && probe > 0 && probe < 128 && max_iter > probe && h->B >= h->probe_min_batch && h->B < (1 << 24);
+    // ... for batches of probe_min_batch problems and more (2048 unless the caller says otherwise) -- and, with the wave-per-chain
+    // kernels, for any batch that does not fit the resident workgroups at once (512 two-wave, 256 four-wave workgroups: measured,
+    // astrobeeSE3 B = 1024 25.4 -> 24.5 ms, B = 512 19.1 -> 17.7 ms; not for the manifold model's four-wave kernel, 36.2 -> 36.9 ms)
+    int min_batch = h->probe_min_batch;
+    if (!h->sched_forced && have_chains && (nch_used == 2 || MODEL != GUSTO_ASTROBEE_SE3_MANIFOLD)) min_batch = std::min(min_batch, slots + 1);
+    const bool dyn = mode == 0 && probe > 0 && probe < 128 && max_iter > probe && h->B >= min_batch && h->B < (1 << 24);
     memset(h->sched_init, 0, sizeof(h->sched_init));
     h->sched_init[SQ_PROBING] = dyn ? P.n_fresh : 0;     // every problem starts with its probing slices still ahead
     HIPCHK(h, hipMemcpyAsync(h->d_queue, h->sched_init, SQ_WORDS * sizeof(int), hipMemcpyHostToDevice, h->stream));
