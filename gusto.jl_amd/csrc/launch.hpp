@@ -89,12 +89,15 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     [[maybe_unused]] int nch_used = 0;
 #if GUSTO_SEG_W2
     // a batch that leaves SIMDs without a wave runs several waves per problem, the KKT solve's sequential phases as Riccati segments
-    // side by side and the obstacle rows shared (scp_kernel_w2, segw.hpp): four waves up to two problems per CU, two up to the batch
-    // size where the one-wave kernel's three problems per CU win (measured: astrobeeSE3 4096 .. 8192, astrobeeSE3manifold 2048 .. 4096)
+    // side by side and the obstacle rows shared (scp_kernel_w2, segw.hpp): four waves up to six problems per CU (one four-wave
+    // workgroup is resident per CU: up to six rounds under the longest-first scheduler), two up to the batch size where the one-wave
+    // kernel's three problems per CU win (measured, profiles/r06_wave_per_chain.txt: astrobeeSE3 4096 .. 8192, astrobeeSE3manifold
+    // 2048 .. 4096)
     if constexpr (seg2_big<MODEL>()) {
+        constexpr int TWO_UP_TO = (MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD) ? 8 : 16;
         int nch = 0;
-        if (NT == 64 && P.n_fresh <= 2 * cus && h->N >= 4 * GUSTO_SEG_MIN_N) nch = 4;
-        else if (NT == 64 && P.n_fresh <= 8 * cus && h->N >= 2 * GUSTO_SEG_MIN_N) nch = 2;
+        if (NT == 64 && P.n_fresh <= 6 * cus && h->N >= 4 * GUSTO_SEG_MIN_N) nch = 4;
+        else if (NT == 64 && P.n_fresh <= TWO_UP_TO * cus && h->N >= 2 * GUSTO_SEG_MIN_N) nch = 2;
         if (h->decomposition == GUSTO_DECOMP_WAVE) nch = 0;
         if (want_chains) { nch = (h->decomposition == GUSTO_DECOMP_WAVE4) ? 4 : 2; if (NT != 64 || h->N < nch * GUSTO_SEG_MIN_N) nch = 0; }
         if (const char* e = dev_env("GUSTO_DEV_W2")) { nch = atoi(e); if (nch == 1) nch = 2; if ((nch != 2 && nch != 4) || NT != 64 || h->N < nch * GUSTO_SEG_MIN_N) nch = 0; }
@@ -131,10 +134,12 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     // number of probing slices: the caller's (gusto_set_schedule) or the model's default (2; dubins_car 1)
     const int probe = h->sched_forced ? h->probe_iters : MT<MODEL>::SCHED_PROBE;
     // ... for batches of probe_min_batch problems and more (2048 unless the caller says otherwise) -- and, with the wave-per-chain
-    // kernels, for any batch that does not fit the resident workgroups at once (512 two-wave, 256 four-wave workgroups: measured,
-    // astrobeeSE3 B = 1024 25.4 -> 24.5 ms, B = 512 19.1 -> 17.7 ms; not for the manifold model's four-wave kernel, 36.2 -> 36.9 ms)
+    // kernels, for any batch that does not fit the resident workgroups at once (512 two-wave, 256 four-wave workgroups; measured:
+    // astrobeeSE3 B = 1024 two waves 25.4 -> 24.5 ms, B = 512 four waves 19.1 -> 17.7 ms, astrobeeSE3manifold B = 768 four waves
+    // 44.6 -> 37.1 ms, B = 1024 53.1 -> 45.8 ms; the manifold model's four-wave kernel from the third round on: 36.2 -> 36.9 ms at 512)
     int min_batch = h->probe_min_batch;
-    if (!h->sched_forced && have_chains && (nch_used == 2 || MODEL != GUSTO_ASTROBEE_SE3_MANIFOLD)) min_batch = std::min(min_batch, slots + 1);
+    if (!h->sched_forced && have_chains)
+        min_batch = std::min(min_batch, ((nch_used == 4 && MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD) ? 2 * slots : slots) + 1);
     const bool dyn = mode == 0 && probe > 0 && probe < 128 && max_iter > probe && h->B >= min_batch && h->B < (1 << 24);
     memset(h->sched_init, 0, sizeof(h->sched_init));
     h->sched_init[SQ_PROBING] = dyn ? P.n_fresh : 0;     // every problem starts with its probing slices still ahead

@@ -144,8 +144,8 @@ int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch);
  * to the WAVE kernel.
  * WAVE2 / WAVE4 (round 6; astrobeeSE3 and astrobeeSE3manifold, N <= 64): two or four wavefronts per problem -- the horizon split into
  * as many Riccati chains, a wave each, joined by coarse LQR stages, and each knot's obstacle rows shared between the waves
- * (csrc/segw.hpp).  For batches that leave SIMDs without a wave: AUTO takes WAVE4 up to two problems per CU, WAVE2 up to eight,
- * one wave per problem beyond (measured on MI355X); WAVE forces one wave per problem.  Same subproblems to the same tolerances;
+ * (csrc/segw.hpp).  For batches that leave SIMDs without a wave: AUTO takes WAVE4 up to six problems per CU, WAVE2 up to sixteen
+ * (astrobeeSE3manifold: eight), one wave per problem beyond (measured on MI355X); WAVE forces one wave per problem.  Same subproblems to the same tolerances;
  * the iterates differ in rounding (the KKT solve is reassociated), the SCP iteration counts do not on the test batches.  A model
  * or horizon without these kernels answers GUSTO_ERR_ARG at gusto_solve. */
 enum { GUSTO_DECOMP_AUTO = 0, GUSTO_DECOMP_WAVE = 1, GUSTO_DECOMP_LANE = 2, GUSTO_DECOMP_WAVE2 = 3, GUSTO_DECOMP_WAVE4 = 4 };

@@ -8,8 +8,8 @@ import gusto_jl_amd as g
 P = g.problems
 out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
 boxes, spheres = P.iss_corner_env(True)
-for model, name, gen, sizes in ((g.ASTROBEE_SE3, "astrobeeSE3", P.astrobee_se3_batch, (128, 256, 512, 1024, 2048, 4096, 8192)),
-                                (g.ASTROBEE_SE3_MANIFOLD, "astrobeeSE3manifold", P.astrobee_manifold_batch, (128, 256, 512, 1024, 2048, 4096))):
+for model, name, gen, sizes in ((g.ASTROBEE_SE3, "astrobeeSE3", P.astrobee_se3_batch, (128, 256, 512, 768, 1024, 1536, 2048, 4096, 8192)),
+                                (g.ASTROBEE_SE3_MANIFOLD, "astrobeeSE3manifold", P.astrobee_manifold_batch, (128, 256, 512, 768, 1024, 1536, 2048, 4096))):
     for B in sizes:
         batch = gen(B)
         e = {"model": name, "N": 50, "B": B}
