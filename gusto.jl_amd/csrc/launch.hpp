@@ -133,12 +133,13 @@ template <int MODEL> static int launch_scp(gusto_handle h, int mode, int max_ite
     // scheduler state of this launch (scp.hpp): counters to 0, waiting lists to -1
     // number of probing slices: the caller's (gusto_set_schedule) or the model's default (2; dubins_car 1)
     const int probe = h->sched_forced ? h->probe_iters : MT<MODEL>::SCHED_PROBE;
-    // ... for batches of probe_min_batch problems and more (2048 unless the caller says otherwise) -- and, with the wave-per-chain
-    // kernels, for any batch that does not fit the resident workgroups at once (512 two-wave, 256 four-wave workgroups; measured:
-    // astrobeeSE3 B = 1024 two waves 25.4 -> 24.5 ms, B = 512 four waves 19.1 -> 17.7 ms, astrobeeSE3manifold B = 768 four waves
-    // 44.6 -> 37.1 ms, B = 1024 53.1 -> 45.8 ms; the manifold model's four-wave kernel from the third round on: 36.2 -> 36.9 ms at 512)
+    // ... for batches of probe_min_batch problems and more (2048 unless the caller says otherwise) and for any batch that does not
+    // fit the resident workgroups at once (1024 for freeflyerSE2, 768 one-wave / 512 two-wave / 256 four-wave workgroups of the
+    // 12/13-state models; round 6, measured: freeflyerSE2 B = 1536 28.3 -> 26.4 ms, astrobeeSE3 B = 1024 two waves 25.4 -> 24.5 ms,
+    // B = 512 four waves 19.1 -> 17.7 ms, astrobeeSE3manifold B = 768 four waves 44.6 -> 37.1 ms, B = 1536 one wave 96.9 -> 83.7 ms;
+    // the manifold model's four-wave kernel from the third round on: 36.2 -> 36.9 ms at 512)
     int min_batch = h->probe_min_batch;
-    if (!h->sched_forced && have_chains)
+    if (!h->sched_forced)
         min_batch = std::min(min_batch, ((nch_used == 4 && MODEL == GUSTO_ASTROBEE_SE3_MANIFOLD) ? 2 * slots : slots) + 1);
     const bool dyn = mode == 0 && probe > 0 && probe < 128 && max_iter > probe && h->B >= min_batch && h->B < (1 << 24);
     memset(h->sched_init, 0, sizeof(h->sched_init));

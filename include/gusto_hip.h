@@ -129,9 +129,9 @@ int gusto_set_env_batch(gusto_handle h, int B, const int* n_box, const double* b
  * waits in the list of its penalty level (number of omega raises so far -- the problems whose omega was raised early are
  * the long ones); workgroups take the highest raised level waiting, then fresh problems (the ones that start deepest
  * inside an obstacle first), then level 0; from slice `probe_iters` on a problem runs to its end (freeflyerSE2 problems of
- * level 0: in slices of four iterations).  probe_iters = 0: first come, first served.  Without this call: batches of
- * >= 2048 problems -- with the wave-per-chain kernels (gusto_set_decomposition) any batch larger than the resident workgroups --,
- * 2 probing slices for freeflyerSE2, 1 for the other models.  Results do not depend on the schedule. */
+ * level 0: in slices of four iterations).  probe_iters = 0: first come, first served.  Without this call: every batch that
+ * does not fit the GPU's resident workgroups at once (and any batch of >= 2048 problems), 2 probing slices for freeflyerSE2,
+ * 1 for the other models.  Results do not depend on the schedule. */
 int gusto_set_schedule(gusto_handle h, int probe_iters, int min_batch);
 /* How a gusto_solve maps problems to the GPU (new; affects time only -- both kernels run scp_gusto.jl:49-176 on the same
  * subproblem, scp_gusto.jl:178-314, to the same tolerances).  WAVE: one wavefront per problem, lane k = knot k, the
