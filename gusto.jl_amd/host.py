@@ -532,8 +532,11 @@ def shard_bounds(B, world_size, rank):
 
 
 def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straightline, solver="hip", max_iter=30,
-                    force=False, device=0, devices=None):
+                    force=False, device=0, devices=None, decomposition=0):
     """All TOPs must share model and N (each may bring its own environment); one gusto_solve covers the whole list.
+
+    `decomposition` (gusto_set_decomposition; GuSTO handles only): 0 = the library's choice by batch size -- for the 12/13-state
+    models two or four wavefronts per problem while the batch leaves SIMDs idle --, 1 one wave per problem, 3 / 4 two / four.
 
     `devices` = list of GPU ordinals: the problems are sharded in contiguous blocks (shard_bounds) over
     one handle per entry, every shard is enqueued with gusto_solve_async and the shards run concurrently -- the
@@ -578,6 +581,8 @@ def solve_SCP_batch(TOSs, TOPs, solve_method=None, init_method=init_traj_straigh
         else:
             bs = BatchSolver(model.model_id, N, b1 - b0, hist_cap=_hist_cap(max_iter), device=dv,
                              boxes=TOP0.PD.env.boxes, spheres=TOP0.PD.env.spheres, scp_params=sp, model_params=mp)
+            if decomposition:
+                bs.set_decomposition(decomposition)
         if not same_env:
             bs.set_env_batch([t.PD.env.boxes for t in TOPs[b0:b1]], [t.PD.env.spheres for t in TOPs[b0:b1]])
         bs.set_problems(x0[b0:b1], lo[b0:b1], hi[b0:b1], tf[b0:b1], X0[b0:b1], U0[b0:b1])

@@ -34,7 +34,12 @@ end
 # Batch entry point (the reference has none): every TOP must share model and N (each may bring its own environment).  `devices` = GPU ordinals:
 # the problems are split in contiguous blocks of ceil(B/G) (SURVEY.md 8(e)), one handle per entry, every block enqueued
 # with gusto_solve_async so the GPUs run concurrently; the results come back in problem order.
-function solve_SCP_batch!(TOSs::Vector, TOPs::Vector, init_method=init_traj_straightline; max_iter=30, force=false, device=0, devices=nothing)
+# gusto_set_decomposition (include/gusto_hip.h): how a solve maps problems to the GPU.  AUTO picks by batch size -- for astrobeeSE3 /
+# astrobeeSE3manifold two or four wavefronts per problem (a wave per Riccati chain of the horizon) while the batch leaves SIMDs idle.
+const GUSTO_DECOMP_AUTO, GUSTO_DECOMP_WAVE, GUSTO_DECOMP_LANE, GUSTO_DECOMP_WAVE2, GUSTO_DECOMP_WAVE4 = Cint(0), Cint(1), Cint(2), Cint(3), Cint(4)
+
+function solve_SCP_batch!(TOSs::Vector, TOPs::Vector, init_method=init_traj_straightline; max_iter=30, force=false, device=0, devices=nothing,
+                          decomposition=GUSTO_DECOMP_AUTO)
   TOP0 = TOPs[1]; model, N = TOP0.PD.model, TOP0.N
   n, m, B = model.x_dim, model.u_dim, length(TOPs)
   all(T -> typeof(T.PD.model) == typeof(model) && T.N == N, TOPs) ||
@@ -63,6 +68,8 @@ function solve_SCP_batch!(TOSs::Vector, TOPs::Vector, init_method=init_traj_stra
     gusto_check(ccall((:gusto_create, libgusto_hip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint),
                       href, gusto_model_id(model), N, b1 - b0 + 1, gusto_hist_cap(max_iter), dv), href[], "create")
     h = href[]
+    decomposition == GUSTO_DECOMP_AUTO ||
+      gusto_check(ccall((:gusto_set_decomposition, libgusto_hip), Cint, (Ptr{Cvoid}, Cint), h, decomposition), h, "set_decomposition")
     gusto_check(ccall((:gusto_set_params, libgusto_hip), Cint, (Ptr{Cvoid}, Ref{GustoScpParams}, Ref{GustoModelParams}),
                       h, sp, gusto_model_params(TOP0.PD.robot, model)), h, "set_params")
     gusto_check(ccall((:gusto_set_env, libgusto_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}),
